@@ -1,0 +1,204 @@
+/*
+ * gpsiq.h — C-ABI of libgpsiq, the MI355X-native GPS L1 C/A IQ synthesiser.
+ *
+ * This library replaces ONE thing in Mictronics/multi-sdr-gps-sim: the per-sample
+ * synthesis loop and its int8/int16 pack that are inlined in gps_thread_ep()
+ * (reference gps.c:2767-2836 and gps.c:2839-2846).  Everything either side of it
+ * (RINEX/ephemeris/pseudorange host model above, fifo.h / sdr_* sinks below) stays
+ * as it is.  The reference has no function boundary at this point, so the boundary
+ * is defined here: plain C, plain pointers and sizes, no C++/torch types.
+ *
+ * Call-site map (reference file:line -> entry point that replaces it)
+ *   gps.c:2767-2846  per-block sample loop + pack      -> gpsiq_generate_block()
+ *   gps.c:2703-2933  the 10 Hz block loop, run ahead   -> gpsiq_generate_batch()
+ *   gps.c:2847-2865  HackRF 262144-element chunking /
+ *                    iqfile+Pluto one-block hand-off   -> gpsiq_chunker_*()
+ *   gps.c:272-309    codegen() C/A sequence             -> gpsiq_prn_code()   (table built in-library)
+ *   gps.c:145-213    sinTable512 / cosTable512          -> gpsiq_carrier_table() (table built in-library)
+ *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
+ *
+ * NCO definition ("identical fixed-point NCO word widths", BASELINE.json north_star).
+ * The reference advances both NCOs with sequential double additions (gps.h:17
+ * FLOAT_CARR_PHASE; gps.c:2789, 2821).  libgpsiq and its CPU oracle evaluate the
+ * same recurrences in closed form on integers:
+ *   carrier: phase accumulator of GPSIQ_CARR_FRAC_BITS = 59 bits (cycles, wraps mod 1),
+ *            LUT index = top 9 bits               (gps.c:2775 floor(carr_phase*512))
+ *   code   : chip counter + GPSIQ_CODE_FRAC_BITS = 56 fractional bits
+ *                                                  (gps.c:2789-2817)
+ * for sample n of a block, with every quantity an exact integer:
+ *   P(n) = (carr_phase + n*carr_step) mod 2^59          idx  = P(n) >> 50
+ *   T(n) = code_frac + n*code_step                      A(n) = chip0 + (T(n) >> 56)
+ *   chip = A(n) % 1023      period = A(n) / 1023        bit  = (icode + period) / 20
+ *   neg  = prn_chip[chip] ^ ((nav_bits >> bit) & 1)   (dataBit*codeCA == -1  <=>  neg == 1)
+ *   I   += neg ? -TC[idx] : TC[idx]   with TC[k] = (int)(cosTable512[k]*gain)  (C truncation)
+ *   Q   += neg ? -TS[idx] : TS[idx]   with TS[k] = (int)(sinTable512[k]*gain)
+ * and the outputs are (short)I,(short)Q (gps.c:2834-2835), or (signed char)((short)x >> 4)
+ * for 8-bit sinks (gps.c:2845).  SURVEY.md section 0 fact 3 explains why >= 56 bits.
+ */
+#ifndef GPSIQ_H
+#define GPSIQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSIQ_MAX_CHAN        16    /* reference MAX_CHAN is 12 (gps.h:36); BASELINE configs 3/5 use 16 */
+#define GPSIQ_N_DWRD          60    /* gps.h:52 N_DWRD */
+#define GPSIQ_CA_SEQ_LEN      1023  /* gps.h:58 */
+#define GPSIQ_CARR_FRAC_BITS  59
+#define GPSIQ_CODE_FRAC_BITS  56
+#define GPSIQ_MAX_NAV_BITS    32    /* nav bits one block may touch (20 ms each) */
+#define GPSIQ_HACKRF_CHUNK    262144 /* sdr.h:33 HACKRF_TRANSFER_BUFFER_SIZE, in IQ elements */
+
+/* sample formats == simulator_t.sample_size in bytes (gps-sim.h:26-27 SC08 / SC16) */
+#define GPSIQ_SC08 1
+#define GPSIQ_SC16 2
+
+/* sink kinds == sdr_type_t (gps-sim.h:30-32); only affects chunking, gps.c:2847-2865 */
+#define GPSIQ_SINK_IQFILE   1
+#define GPSIQ_SINK_HACKRF   2
+#define GPSIQ_SINK_PLUTOSDR 3
+
+/* error codes: 0 ok, negative on failure (the sdr_* convention, sdr.c:48-66, uses 0 / -1) */
+#define GPSIQ_OK             0
+#define GPSIQ_E_ARG         -1   /* bad argument (NULL, nchan > GPSIQ_MAX_CHAN, prn out of range ...) */
+#define GPSIQ_E_RANGE       -2   /* descriptor outside what the NCO format represents */
+#define GPSIQ_E_DEVICE      -3   /* HIP runtime error, see gpsiq_last_error() */
+#define GPSIQ_E_NOMEM       -4
+#define GPSIQ_E_STATE       -5   /* call order (e.g. launch before descriptors are resident) */
+
+/* Per-channel block descriptor: exactly the channel_t fields (gps.h:213-236) plus
+ * gain[i] (gps.c:2300, 2756-2763) that the sample loop reads, with the state the
+ * host refresh leaves at gps.c:2766.  dataBit/codeCA are not carried: they are
+ * functions of (dwrd, iword, ibit) and (ca, code_phase) (gps.c:2058-2059). */
+typedef struct gpsiq_chan {
+    int32_t  prn;                 /* 1..32; <= 0 marks an unused slot (gps.c:2772) */
+    int32_t  iword;               /* 0..59  word index into dwrd  (gps.c:2049) */
+    int32_t  ibit;                /* 0..29  bit inside the word   (gps.c:2052) */
+    int32_t  icode;               /* 0..19  code period inside the bit (gps.c:2055) */
+    double   f_carr;              /* Hz, Doppler (gps.c:2042) */
+    double   f_code;              /* Hz, chipping rate (gps.c:2043) */
+    double   carr_phase;          /* cycles in [0,1) (gps.c:2214); see gpsiq_generate_block */
+    double   code_phase;          /* chips in [0,1023) (gps.c:2047) */
+    double   gain;                /* gain[i] (gps.c:2756) */
+    uint32_t dwrd[GPSIQ_N_DWRD];  /* nav words, bits 29..0 used (gps.c:2811) */
+} gpsiq_chan_t;
+
+/* Quantised descriptor: what the device kernel (and the oracle's closed form)
+ * consumes.  48 bytes; one per (block, channel slot). */
+typedef struct gpsiq_qchan {
+    uint64_t carr_phase;  /* [0, 2^59) units of 2^-59 cycle */
+    int64_t  carr_step;   /* per sample, units of 2^-59 cycle, |step| < 2^58 */
+    uint64_t code_frac;   /* [0, 2^56) units of 2^-56 chip */
+    uint64_t code_step;   /* per sample, units of 2^-56 chip, < 2^57 (2 chips/sample) */
+    double   gain;
+    uint32_t nav_bits;    /* bit b = data bit of the b-th nav-bit period this block touches */
+    uint16_t chip0;       /* 0..1022 */
+    uint8_t  icode;       /* 0..19 */
+    uint8_t  prn;         /* 1..32, 0 = unused slot */
+} gpsiq_qchan_t;
+
+typedef struct gpsiq_ctx gpsiq_ctx_t;
+
+/* ---- library / tables (no device needed) -------------------------------- */
+const char *gpsiq_version(void);
+/* last error text of the calling thread ("" if none) */
+const char *gpsiq_last_error(void);
+/* C/A code of one PRN as 0/1 chips; replaces codegen() gps.c:272-309 */
+int gpsiq_prn_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN]);
+/* carrier LUTs; replace cosTable512 / sinTable512 gps.c:145-213 */
+void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512[512]);
+
+/* Quantise nchan descriptors for a block of nsamp samples at fs Hz.
+ * delt = 1.0/fs as in gps.c:2298; steps are rint(f*delt*2^F).
+ * carry_in: if non-NULL, carry_in[i] replaces the phase derived from ch[i].carr_phase.
+ * carry_out: if non-NULL, receives the exact carrier phase after nsamp samples
+ *            (the only state the loop hands to the next block, gps.c:2821).
+ * Unused slots (prn <= 0) produce prn = 0.  out has nchan entries. */
+int gpsiq_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
+                   gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out);
+
+/* ---- device context ------------------------------------------------------ */
+/* device = HIP device ordinal.  Fails (GPSIQ_E_DEVICE) when no GPU is present:
+ * there is no CPU fallback in this library. */
+int  gpsiq_create(gpsiq_ctx_t **ctx, int device);
+void gpsiq_destroy(gpsiq_ctx_t *ctx);
+
+/* Drop-in for one pass of gps.c:2767-2846: synthesise one block of nsamp complex
+ * samples from the channel state at gps.c:2766 and write 2*nsamp IQ elements
+ * (int8 for GPSIQ_SC08, int16 for GPSIQ_SC16) to the HOST buffer dst
+ * (iq->data8 / iq->data16 of the acquired fifo buffer).  Synchronous.
+ * carr_phase_out[i] (may be NULL) receives the carrier phase after the block, as
+ * the loop leaves it in chan[i].carr_phase.  The context remembers the exact
+ * 59-bit phase per slot: when the next call passes back the same prn and the same
+ * carr_phase double it handed out, the exact value is continued; any other value
+ * (allocateChannel re-initialising a slot, gps.c:2208-2214) re-seeds from the double. */
+int gpsiq_generate_block(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
+                         int nsamp, double fs, int sample_size,
+                         void *dst, double *carr_phase_out);
+
+/* Run-ahead form of the 10 Hz loop (gps.c:2703): ch is [nblocks][nchan], all blocks
+ * prepared by the host model first (it never reads the loop's output except
+ * carr_phase).  Block 0 seeds the carrier from ch[0][i].carr_phase; later blocks
+ * continue exactly, re-seeding a slot from its carr_phase only when its prn changes.
+ * dst receives nblocks*2*nsamp elements; dst_is_device != 0 means dst is a device
+ * pointer on the context's device (no D2H). */
+int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan,
+                         int nsamp, double fs, int sample_size,
+                         void *dst, int dst_is_device);
+
+/* ---- resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
+/* Copy nblocks*nchan quantised descriptors ([nblocks][nchan]) to the device. */
+int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
+/* Launch synthesis of blocks [block0, block0+nblocks) of the resident descriptors into
+ * the DEVICE buffer dst; block b is written at dst + (b-block0)*block_stride_bytes
+ * (block_stride_bytes >= 2*nsamp*sample_size, multiple of 16).  Asynchronous on
+ * hip_stream (a hipStream_t passed as void*; NULL = the context's own stream).
+ * variant selects the kernel: 0 = default, see gpsiq_variant_name(). */
+int gpsiq_launch(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, int sample_size,
+                 void *dst, size_t block_stride_bytes, void *hip_stream, int variant);
+int gpsiq_synchronize(gpsiq_ctx_t *ctx, void *hip_stream);
+/* Time iters back-to-back launches with HIP events on hip_stream; returns the mean
+ * kernel-launch duration in milliseconds in *ms_per_launch. */
+int gpsiq_time_launches(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, int sample_size,
+                        void *dst, size_t block_stride_bytes, void *hip_stream, int variant,
+                        int iters, float *ms_per_launch);
+int         gpsiq_num_variants(void);
+const char *gpsiq_variant_name(int variant);
+
+/* ---- hand-off to fifo.h buffers (gps.c:2847-2865) -------------------------- */
+/* Element-exact restatement of the chunking rules, independent of the FIFO
+ * implementation: the caller supplies acquire/enqueue callbacks with the fifo.h
+ * semantics (fifo.h:45-55).  struct layout of the buffers is fifo.h:19-25. */
+typedef struct gpsiq_iq_buf {       /* field-for-field struct iq_buf, fifo.h:19-25 */
+    signed char  *data8;
+    signed short *data16;
+    unsigned int  totalLength;
+    unsigned int  validLength;
+    struct gpsiq_iq_buf *next;
+} gpsiq_iq_buf_t;
+
+typedef struct gpsiq_chunker {
+    gpsiq_iq_buf_t *(*acquire)(void *user);           /* fifo_acquire  */
+    void            (*enqueue)(void *user, gpsiq_iq_buf_t *buf); /* fifo_enqueue */
+    void            *user;
+    gpsiq_iq_buf_t  *cur;          /* buffer being filled (gps.c:2698) */
+    int              sink_kind;    /* GPSIQ_SINK_* */
+    int              sample_size;  /* GPSIQ_SC08 / GPSIQ_SC16 */
+} gpsiq_chunker_t;
+
+int gpsiq_chunker_init(gpsiq_chunker_t *ck, int sink_kind, int sample_size,
+                       gpsiq_iq_buf_t *(*acquire)(void *), void (*enqueue)(void *, gpsiq_iq_buf_t *),
+                       void *user);
+/* Push one block of nelem = 2*nsamp already-packed elements (int8 or int16 per
+ * sample_size) through the rules of gps.c:2839-2865.  Returns number of buffers
+ * enqueued, or negative on error (acquire returned NULL = FIFO halted). */
+int gpsiq_chunker_push(gpsiq_chunker_t *ck, const void *elems, size_t nelem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSIQ_H */

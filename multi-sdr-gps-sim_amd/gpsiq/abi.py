@@ -1,0 +1,30 @@
+"""numpy views of the C-ABI structs in include/gpsiq.h (layout checked by tests)."""
+import numpy as np
+
+MAX_CHAN = 16
+N_DWRD = 60
+CA_SEQ_LEN = 1023
+CARR_FRAC_BITS = 59
+CODE_FRAC_BITS = 56
+SC08, SC16 = 1, 2
+SINK_IQFILE, SINK_HACKRF, SINK_PLUTOSDR = 1, 2, 3
+HACKRF_CHUNK = 262144
+
+# gpsiq_chan_t (mirrors the channel_t fields the loop reads, reference gps.h:213-236)
+CHAN_DTYPE = np.dtype([
+    ("prn", "<i4"), ("iword", "<i4"), ("ibit", "<i4"), ("icode", "<i4"),
+    ("f_carr", "<f8"), ("f_code", "<f8"), ("carr_phase", "<f8"), ("code_phase", "<f8"),
+    ("gain", "<f8"), ("dwrd", "<u4", (N_DWRD,)),
+], align=True)
+assert CHAN_DTYPE.itemsize == 296
+
+# gpsiq_qchan_t
+QCHAN_DTYPE = np.dtype([
+    ("carr_phase", "<u8"), ("carr_step", "<i8"), ("code_frac", "<u8"), ("code_step", "<u8"),
+    ("gain", "<f8"), ("nav_bits", "<u4"), ("chip0", "<u2"), ("icode", "u1"), ("prn", "u1"),
+], align=True)
+assert QCHAN_DTYPE.itemsize == 48
+
+
+def elem_dtype(sample_size):
+    return np.int8 if sample_size == SC08 else np.int16

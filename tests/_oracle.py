@@ -1,0 +1,174 @@
+"""ctypes bindings of the CPU checker (oracle/liboracle.so, oracle/_ref/libgpsref.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+import sys
+sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+from gpsiq.abi import CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, elem_dtype  # noqa: E402
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, path):
+        L = self.lib = C.CDLL(path)
+        L.oracle_sin512.restype = C.c_int
+        L.oracle_cos512.restype = C.c_int
+        L.oracle_codegen.argtypes = [C.c_int, C.c_void_p]
+        L.oracle_block_float.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_quantize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_block_fixed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_block_fixed_seq.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_block_fixed_range.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_int, C.c_void_p]
+        L.oracle_chunk_plan.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
+
+    def tables(self):
+        s = np.array([self.lib.oracle_sin512(k) for k in range(512)], dtype=np.int32)
+        c = np.array([self.lib.oracle_cos512(k) for k in range(512)], dtype=np.int32)
+        return s, c
+
+    def codegen(self, prn):
+        ca = np.zeros(1023, dtype=np.uint8)
+        rc = self.lib.oracle_codegen(prn, _ptr(ca))
+        if rc:
+            raise ValueError(rc)
+        return ca
+
+    def block_float(self, ch, nsamp, fs, sample_size):
+        ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+        out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
+        carr = np.zeros(len(ch), dtype=np.float64)
+        rc = self.lib.oracle_block_float(_ptr(ch), len(ch), nsamp, fs, sample_size, _ptr(out), _ptr(carr))
+        if rc:
+            raise ValueError(rc)
+        return out, carr
+
+    def quantize(self, ch, fs, nsamp, carry_in=None):
+        ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+        q = np.zeros(len(ch), dtype=QCHAN_DTYPE)
+        cout = np.zeros(len(ch), dtype=np.uint64)
+        cin = None if carry_in is None else np.ascontiguousarray(carry_in, dtype=np.uint64)
+        rc = self.lib.oracle_quantize(_ptr(ch), len(ch), fs, nsamp, _ptr(q),
+                                      None if cin is None else _ptr(cin), _ptr(cout))
+        if rc:
+            raise ValueError(rc)
+        return q, cout
+
+    def quantize_blocks(self, desc, fs, nsamp):
+        """[nblocks][nchan] descriptors -> quantised, carrier carried exactly between
+        blocks (re-seeded when a slot's prn changes), as gpsiq_generate_batch does."""
+        nb, nc = desc.shape
+        q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+        carry = None
+        for b in range(nb):
+            cin = None
+            if b > 0:
+                cin = carry.copy()
+                for c in range(nc):
+                    if desc[b, c]["prn"] != desc[b - 1, c]["prn"]:
+                        cin[c] = np.uint64(int(np.floor(np.ldexp(desc[b, c]["carr_phase"], 59))))
+            q[b], carry = self.quantize(desc[b], fs, nsamp, cin)
+        return q
+
+    def block_fixed(self, q, nsamp, sample_size, seq=False):
+        q = np.ascontiguousarray(q, dtype=QCHAN_DTYPE)
+        out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
+        fn = self.lib.oracle_block_fixed_seq if seq else self.lib.oracle_block_fixed
+        rc = fn(_ptr(q), len(q), nsamp, sample_size, _ptr(out))
+        if rc:
+            raise ValueError(rc)
+        return out
+
+    def block_fixed_range(self, q, n0, cnt, sample_size):
+        q = np.ascontiguousarray(q, dtype=QCHAN_DTYPE)
+        out = np.zeros(2 * cnt, dtype=elem_dtype(sample_size))
+        rc = self.lib.oracle_block_fixed_range(_ptr(q), len(q), n0, cnt, sample_size, _ptr(out))
+        if rc:
+            raise ValueError(rc)
+        return out
+
+    def chunk_plan(self, sink_kind, nelem, nblocks):
+        buf = np.zeros(4 * (nblocks + 1) + (nelem * nblocks) // 262144 + 8, dtype=np.uint64)
+        n = self.lib.oracle_chunk_plan(sink_kind, nelem, nblocks, _ptr(buf), len(buf))
+        if n < 0:
+            raise ValueError(n)
+        return buf[:n].astype(np.int64)
+
+
+class Ref:
+    """The reference's own lines (oracle/ref_slice.c)."""
+
+    def __init__(self, path):
+        L = self.lib = C.CDLL(path)
+        L.ref_run_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p]
+        L.ref_compute_code_phase.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int, C.c_double,
+                                             C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
+
+    def tables(self):
+        s = np.zeros(512, dtype=np.int32)
+        c = np.zeros(512, dtype=np.int32)
+        assert self.lib.ref_tables(_ptr(s), _ptr(c)) == 0
+        return s, c
+
+    def codegen(self, prn):
+        ca = np.zeros(1023, dtype=np.int32)
+        self.lib.ref_codegen(prn, _ptr(ca))
+        return ca.astype(np.uint8)
+
+    def run_blocks(self, desc, fs, sample_size, sdr_type=1):
+        """desc [nblocks][nchan] -> (elements in enqueue order, chunk lengths, carr_out)"""
+        desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+        nb, nc = desc.shape
+        nelem = 2 * (fs // 10) * nb
+        out = np.zeros(nelem, dtype=elem_dtype(sample_size))
+        chunks = np.zeros(nelem // 262144 + nb + 8, dtype=np.uint64)
+        carr = np.zeros((nb, nc), dtype=np.float64)
+        n_out = C.c_size_t(0)
+        n_chunks = C.c_int(0)
+        rc = self.lib.ref_run_blocks(_ptr(desc), nb, nc, int(fs), sample_size, sdr_type,
+                                     _ptr(out), nelem, C.byref(n_out), _ptr(chunks), len(chunks),
+                                     C.byref(n_chunks), _ptr(carr))
+        if rc:
+            raise RuntimeError(rc)
+        return out[: n_out.value], chunks[: n_chunks.value].astype(np.int64), carr
+
+    def compute_code_phase(self, rho0_range, rho0_g, g0, rho1_range, dt, dwrd, prn):
+        out = np.zeros(1, dtype=CHAN_DTYPE)
+        dwrd = np.ascontiguousarray(dwrd, dtype=np.uint32)
+        rc = self.lib.ref_compute_code_phase(rho0_range, rho0_g[0], rho0_g[1], g0[0], g0[1],
+                                             rho1_range, dt, _ptr(dwrd), prn, _ptr(out))
+        if rc:
+            raise RuntimeError(rc)
+        return out[0]
+
+
+def load_oracle():
+    path = os.path.join(ORACLE_DIR, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    return Oracle(path)
+
+
+def load_ref():
+    path = os.path.join(ORACLE_DIR, "_ref", "libgpsref.so")
+    if not os.path.exists(path) and os.path.exists("/root/reference/gps.c"):
+        build()
+    return Ref(path) if os.path.exists(path) else None
