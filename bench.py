@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the libgpsiq hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (one gpsiq_launch through the C-ABI) over one
+batch of --blocks 0.1 s blocks of synthetic channel descriptors, with the
+quantised descriptors already resident in HBM; the IQ output goes to a device ring of
+blocks*block_bytes (>= 2 GiB by default, far beyond the 256 MiB Infinity Cache) so
+that the writes really reach HBM.  Workload = BASELINE.json metric: 2.6 Msps, int8,
+16 channels.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the time
+axis is sharded: rank r owns blocks [r*B, (r+1)*B) of one N*B-block timeline, its
+carrier phases seeded by the exact closed-form prefix; no collective touches the data
+path (weak scaling: per-GPU work is fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     — algorithmic IQ bytes per launch / mean launch duration (HIP events on
+                 the launch stream) against the 8 TB/s HBM peak,
+  cpu_baseline — the reference's own loop (oracle/_ref, kind "reference") or our port
+                 of it (oracle/, kind "port") timed on this host, 1 core, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fs", type=float, default=2.6e6)
+    ap.add_argument("--nchan", type=int, default=16)
+    ap.add_argument("--sample-size", type=int, default=1, choices=(1, 2), help="1 = int8 IQ, 2 = int16 IQ")
+    ap.add_argument("--blocks", type=int, default=0, help="0.1 s blocks per step per GPU (0: enough for a 2 GiB ring)")
+    ap.add_argument("--variant", type=str, default="auto")
+    ap.add_argument("--seed", type=int, default=20250215)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-blocks", type=int, default=299, help="blocks of the CPU baseline sample (299 = 30 s, config 1)")
+    ap.add_argument("--sweep", action="store_true", help="also time every kernel variant (extra stderr lines)")
+    return ap.parse_args()
+
+
+def cpu_baseline(desc, fs, nsamp, sample_size, nblocks):
+    """Time the reference CPU path on this host, one core (the reference has exactly one
+    generation thread, gps-sim.c:314).  Checker code only: nothing here is on the GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    ref = _oracle.load_ref()
+    d = np.ascontiguousarray(desc[:nblocks])
+    t0 = time.perf_counter()
+    if ref is not None:
+        kind = "reference"
+        ref.run_blocks(d, int(fs), sample_size, 1)
+    else:
+        kind = "port"
+        orc = _oracle.load_oracle()
+        for b in range(nblocks):
+            orc.block_float(d[b], nsamp, fs, sample_size)
+    dt = time.perf_counter() - t0
+    return {"value": round(nblocks * nsamp / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
+            "sample": f"first {nblocks} blocks ({nblocks * 0.1:.1f} s of signal) of the same workload, "
+                      f"{'oracle/_ref: reference gps.c:2767-2865 compiled in place' if kind == 'reference' else 'oracle_block_float'}, "
+                      f"gcc -O2, {dt:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    import torch
+    import gpsiq
+    from gpsiq.scenario import synth_blocks
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libgpsiq has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    fs, nchan, ss = args.fs, args.nchan, args.sample_size
+    nsamp = int(round(fs / 10))                      # NUM_IQ_SAMPLES, reference sdr.h:26
+    blk_bytes = 2 * nsamp * ss
+    stride = (blk_bytes + 15) & ~15
+    nblocks = args.blocks or -(-(2 << 30) // stride)  # ring >= 2 GiB
+    variant = gpsiq.variants()[args.variant]
+
+    # one global timeline of world*nblocks blocks; this rank's shard is [rank*nblocks, ...)
+    # Descriptors: distinct code/Doppler state per block for a short pattern, tiled over
+    # the timeline (host generation cost only), then quantised with the exact carrier prefix.
+    pattern = synth_blocks(min(64, nblocks), nchan, seed=args.seed)
+    reps = -(-nblocks * world // len(pattern))
+    desc_all = np.concatenate([pattern] * reps)[: nblocks * world]
+    q_all, _ = gpsiq.quantize_blocks(desc_all, fs, nsamp)
+    q = q_all[rank * nblocks:(rank + 1) * nblocks]
+
+    ctx = gpsiq.Context(local_rank)
+    ctx.set_descriptors(q)
+    ring = torch.empty(nblocks * stride, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.launch(0, nblocks, nsamp, ss, ring.data_ptr(), stride, stream=stream, variant=variant)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([t_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
+    else:
+        t_max = t_local
+    launch_ms = e0.elapsed_time(e1) / args.steps       # HIP events on the launch stream
+
+    if args.sweep and rank == 0:
+        for name, v in gpsiq.variants().items():
+            if name == "auto":
+                continue
+            try:
+                ms = min(ctx.time_launches(0, nblocks, nsamp, ss, ring.data_ptr(), stride, 5, stream=stream, variant=v)
+                         for _ in range(3))
+                print(f"[sweep] variant {name}: {ms:.3f} ms/launch, {nblocks * nsamp / ms / 1e6:.1f} Gsamples/s",
+                      file=sys.stderr)
+            except gpsiq.GpsiqError as e:
+                print(f"[sweep] variant {name}: {e}", file=sys.stderr)
+
+    if rank == 0:
+        samples_step = nblocks * nsamp * world
+        value = samples_step * args.steps / t_max / 1e6
+        alg_bytes = nblocks * blk_bytes                 # algorithmic: 2 or 4 B per complex sample, reads ~0
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"{int(fs)}_{nchan}_{ss}_{nblocks}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "IQ Msamples/s @16ch int8" if (nchan == 16 and ss == 1) else f"IQ Msamples/s @{nchan}ch int{8 * ss}",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"{fs / 1e6:g} Msps int{8 * ss} IQ, {nchan} channels, {nblocks} x 0.1 s blocks per GPU per step "
+                                   f"({nblocks * 0.1:.1f} s of signal, {nblocks * stride / 2**30:.2f} GiB ring), time-sharded x{world}",
+                       "fs_hz": fs, "channels": nchan, "sample_bytes": ss, "blocks_per_gpu": nblocks,
+                       "samples_per_block": nsamp, "variant": args.variant,
+                       "x_realtime": round(value * 1e6 / fs, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc_all, fs, nsamp, ss, min(args.cpu_blocks, nblocks))
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,301 @@
+// gpsiq_device.cpp — device half of the C-ABI in include/gpsiq.h: context, resident
+// descriptors, launches, the synchronous drop-in entry points.  HIP runtime only.
+// There is deliberately no CPU path here: without a GPU gpsiq_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gpsiq_internal.h"
+
+namespace gpsiq {
+hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
+                          void *dst, size_t block_stride, int block0, int nblocks,
+                          const DeviceTables *tab, hipStream_t stream);
+}
+
+using namespace gpsiq;
+
+struct gpsiq_ctx {
+    int           device = -1;
+    hipStream_t   stream = nullptr;
+    DeviceTables *d_tab = nullptr;
+    // resident descriptors
+    gpsiq_qchan_t *d_desc = nullptr;
+    size_t         desc_cap = 0;      // in descriptors
+    int            nblocks = 0, nchan = 0;
+    uint64_t       max_code_step = 0;
+    // staging for the synchronous entry points
+    void          *d_out = nullptr;
+    size_t         out_cap = 0;
+    void          *h_pinned = nullptr;
+    size_t         pinned_cap = 0;
+    // carrier carry per slot (gpsiq_generate_block)
+    uint64_t carry[GPSIQ_MAX_CHAN] = {};
+    double   handed[GPSIQ_MAX_CHAN] = {};
+    int      carry_prn[GPSIQ_MAX_CHAN] = {};
+};
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(GPSIQ_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));             \
+    } while (0)
+
+static int ensure_desc(gpsiq_ctx *c, size_t n)
+{
+    if (n <= c->desc_cap) return GPSIQ_OK;
+    if (c->d_desc) HIP_TRY(hipFree(c->d_desc));
+    c->d_desc = nullptr; c->desc_cap = 0;
+    HIP_TRY(hipMalloc((void **) &c->d_desc, n * sizeof(gpsiq_qchan_t)));
+    c->desc_cap = n;
+    return GPSIQ_OK;
+}
+
+static int ensure_out(gpsiq_ctx *c, size_t bytes)
+{
+    if (bytes > c->out_cap) {
+        if (c->d_out) HIP_TRY(hipFree(c->d_out));
+        c->d_out = nullptr; c->out_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_out, bytes));
+        c->out_cap = bytes;
+    }
+    return GPSIQ_OK;
+}
+
+static int pick_variant(const gpsiq_ctx *c, int variant)
+{
+    if (variant == kAuto)
+        return c->max_code_step <= kRowsMaxCodeStep ? kRows : kGeneric;
+    return variant;
+}
+
+static int check_launch(const gpsiq_ctx *c, int block0, int nblocks, int nsamp, int sample_size,
+                        const void *dst, size_t stride, int variant)
+{
+    if (!c) return fail(GPSIQ_E_ARG, "null context");
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    if (nsamp < 0 || nblocks < 0 || block0 < 0) return fail(GPSIQ_E_ARG, "negative size");
+    if (!c->d_desc || block0 + nblocks > c->nblocks)
+        return fail(GPSIQ_E_STATE, "blocks [%d,%d) not resident (have %d)", block0, block0 + nblocks, c->nblocks);
+    if (!dst && nblocks && nsamp) return fail(GPSIQ_E_ARG, "null destination");
+    if (stride < (size_t) 2 * (size_t) nsamp * (size_t) sample_size || (stride & 3))
+        return fail(GPSIQ_E_ARG, "block stride %zu too small or not a multiple of 4", stride);
+    if (variant < 0 || variant >= kNumVariants) return fail(GPSIQ_E_ARG, "unknown variant %d", variant);
+    if (variant == kRows && c->max_code_step > kRowsMaxCodeStep)
+        return fail(GPSIQ_E_RANGE, "row kernel needs f_code/fs <= 31/63 chip per sample");
+    return GPSIQ_OK;
+}
+
+extern "C" {
+
+int gpsiq_create(gpsiq_ctx_t **out, int device)
+{
+    if (!out) return fail(GPSIQ_E_ARG, "null context pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(GPSIQ_E_DEVICE, "no HIP device (%s); libgpsiq has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(GPSIQ_E_ARG, "device %d outside 0..%d", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+    gpsiq_ctx *c = new (std::nothrow) gpsiq_ctx;
+    if (!c) return fail(GPSIQ_E_NOMEM, "out of memory");
+    c->device = device;
+    DeviceTables *h = new (std::nothrow) DeviceTables;
+    if (!h) { delete c; return fail(GPSIQ_E_NOMEM, "out of memory"); }
+    build_device_tables(h);
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **) &c->d_tab, sizeof(DeviceTables));
+    if (e == hipSuccess) e = hipMemcpy(c->d_tab, h, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    delete h;
+    if (e != hipSuccess) {
+        gpsiq_destroy(c);
+        return fail(GPSIQ_E_DEVICE, "context setup: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return GPSIQ_OK;
+}
+
+void gpsiq_destroy(gpsiq_ctx_t *c)
+{
+    if (!c) return;
+    if (c->device >= 0) (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    if (c->d_tab) (void) hipFree(c->d_tab);
+    if (c->d_desc) (void) hipFree(c->d_desc);
+    if (c->d_out) (void) hipFree(c->d_out);
+    if (c->h_pinned) (void) hipHostFree(c->h_pinned);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan)
+{
+    if (!c || !q) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t) nblocks * (size_t) nchan;
+    uint64_t mx = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (q[i].prn > 32) return fail(GPSIQ_E_ARG, "descriptor %zu: prn %u", i, q[i].prn);
+        if (!q[i].prn) continue;
+        if (q[i].chip0 >= GPSIQ_CA_SEQ_LEN || q[i].icode >= 20 || (q[i].code_frac >> GPSIQ_CODE_FRAC_BITS) ||
+            (q[i].code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(q[i].gain > -4.0e6 && q[i].gain < 4.0e6))
+            return fail(GPSIQ_E_RANGE, "descriptor %zu outside the NCO format", i);
+        if (q[i].code_step > mx) mx = q[i].code_step;
+    }
+    int rc = ensure_desc(c, n ? n : 1);
+    if (rc) return rc;
+    if (n) {
+        // make sure no launch still reads the previous descriptors
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(c->d_desc, q, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice));
+    }
+    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx;
+    return GPSIQ_OK;
+}
+
+int gpsiq_launch(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int sample_size,
+                 void *dst, size_t block_stride_bytes, void *hip_stream, int variant)
+{
+    int rc = check_launch(c, block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, variant);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    HIP_TRY(launch_variant(pick_variant(c, variant), c->d_desc, c->nchan, nsamp, sample_size, dst,
+                           block_stride_bytes, block0, nblocks, c->d_tab, s));
+    return GPSIQ_OK;
+}
+
+int gpsiq_synchronize(gpsiq_ctx_t *c, void *hip_stream)
+{
+    if (!c) return fail(GPSIQ_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(hip_stream ? (hipStream_t) hip_stream : c->stream));
+    return GPSIQ_OK;
+}
+
+int gpsiq_time_launches(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int sample_size,
+                        void *dst, size_t block_stride_bytes, void *hip_stream, int variant,
+                        int iters, float *ms_per_launch)
+{
+    if (!ms_per_launch || iters < 1) return fail(GPSIQ_E_ARG, "bad timing arguments");
+    int rc = check_launch(c, block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, variant);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    const int v = pick_variant(c, variant);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) {
+        hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, block_stride_bytes,
+                                      block0, nblocks, c->d_tab, s);
+        if (e != hipSuccess) {
+            (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+            return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    *ms_per_launch = ms / (float) iters;
+    return GPSIQ_OK;
+}
+
+int gpsiq_num_variants(void) { return kNumVariants; }
+
+const char *gpsiq_variant_name(int v)
+{
+    switch (v) {
+    case kAuto: return "auto";
+    case kGeneric: return "generic";
+    case kRows: return "rows";
+    default: return "?";
+    }
+}
+
+// ---- synchronous drop-in entry points ---------------------------------------
+
+static int run_to_host_or_device(gpsiq_ctx *c, const std::vector<gpsiq_qchan_t> &q, int nblocks, int nchan,
+                                 int nsamp, int sample_size, void *dst, int dst_is_device)
+{
+    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
+    const size_t stride = (blk_bytes + 15) & ~(size_t) 15;
+    int rc = gpsiq_set_descriptors(c, q.data(), nblocks, nchan);
+    if (rc) return rc;
+    if (!nblocks || !nsamp) return GPSIQ_OK;
+    if (dst_is_device && stride == blk_bytes) {
+        rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, dst, stride, nullptr, kAuto);
+        if (rc) return rc;
+        return gpsiq_synchronize(c, nullptr);
+    }
+    rc = ensure_out(c, stride * (size_t) nblocks);
+    if (rc) return rc;
+    rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, c->d_out, stride, nullptr, kAuto);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks,
+                             dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GPSIQ_OK;
+}
+
+int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
+                         int sample_size, void *dst, double *carr_phase_out)
+{
+    if (!c || !ch || !dst) return fail(GPSIQ_E_ARG, "null argument");
+    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "nchan %d outside 1..%d", nchan, GPSIQ_MAX_CHAN);
+    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    std::vector<gpsiq_qchan_t> q((size_t) nchan);
+    uint64_t next[GPSIQ_MAX_CHAN] = {};
+    const double delt = 1.0 / fs;
+    for (int i = 0; i < nchan; ++i) {
+        // continue the exact phase only if the caller hands back what we handed out
+        const bool cont = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
+        int rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[(size_t) i], &next[i]);
+        if (rc) return rc;
+    }
+    int rc = run_to_host_or_device(c, q, 1, nchan, nsamp, sample_size, dst, 0);
+    if (rc) return rc;
+    for (int i = 0; i < nchan; ++i) {
+        c->carry_prn[i] = ch[i].prn > 0 ? ch[i].prn : 0;
+        c->carry[i] = next[i];
+        c->handed[i] = ch[i].prn > 0 ? carr_phase_to_double(next[i]) : 0.0;
+        if (carr_phase_out) carr_phase_out[i] = ch[i].prn > 0 ? c->handed[i] : ch[i].carr_phase;
+    }
+    return GPSIQ_OK;
+}
+
+int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp,
+                         double fs, int sample_size, void *dst, int dst_is_device)
+{
+    if (!c || !ch || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+    uint64_t carry[GPSIQ_MAX_CHAN] = {};
+    int prev_prn[GPSIQ_MAX_CHAN] = {};
+    const double delt = 1.0 / fs;
+    for (int b = 0; b < nblocks; ++b) {
+        for (int i = 0; i < nchan; ++i) {
+            const gpsiq_chan_t &d = ch[(size_t) b * nchan + i];
+            const bool cont = b > 0 && d.prn > 0 && prev_prn[i] == d.prn;
+            uint64_t nxt = 0;
+            int rc = quantize_one(d, delt, nsamp, cont ? &carry[i] : nullptr, &q[(size_t) b * nchan + i], &nxt);
+            if (rc) return rc;
+            carry[i] = nxt;
+            prev_prn[i] = d.prn > 0 ? d.prn : 0;
+        }
+    }
+    return run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// gpsiq_host.cpp — host-side half of the C-ABI in include/gpsiq.h: tables, the
+// double -> fixed-point descriptor quantiser, and the fifo hand-off rules.  No device
+// code here; no dependency on anything under oracle/.
+#include "gpsiq_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace gpsiq {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// C/A code of one PRN (replaces codegen(), reference gps.c:272-309): G1 = x^10+x^3+1,
+// G2 = x^10+x^9+x^8+x^6+x^3+x^2+1, both all-ones at chip 0, chip = G1[i] ^ G2[i-delay].
+void ca_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN])
+{
+    uint8_t g1[GPSIQ_CA_SEQ_LEN], g2[GPSIQ_CA_SEQ_LEN];
+    uint32_t a = 0x3ff, b = 0x3ff;
+    for (int i = 0; i < GPSIQ_CA_SEQ_LEN; ++i) {
+        g1[i] = (a >> 9) & 1u;
+        g2[i] = (b >> 9) & 1u;
+        uint32_t fa = __builtin_parity(a & 0x204u);   // stages 3, 10
+        uint32_t fb = __builtin_parity(b & 0x3a6u);   // stages 2, 3, 6, 8, 9, 10
+        a = ((a << 1) | fa) & 0x3ffu;
+        b = ((b << 1) | fb) & 0x3ffu;
+    }
+    int lag = kG2Delay[prn - 1];
+    for (int i = 0; i < GPSIQ_CA_SEQ_LEN; ++i) {
+        int j = i - lag;
+        if (j < 0) j += GPSIQ_CA_SEQ_LEN;
+        chips[i] = g1[i] ^ g2[j];
+    }
+}
+
+void build_device_tables(DeviceTables *t)
+{
+    std::memset(t, 0, sizeof *t);
+    for (int prn = 1; prn <= 32; ++prn) {
+        uint8_t ca[GPSIQ_CA_SEQ_LEN];
+        ca_code(prn, ca);
+        for (int j = 0; j < kPrnExtWords * 32; ++j)
+            if (ca[j % GPSIQ_CA_SEQ_LEN])
+                t->prn_ext[prn - 1][j >> 5] |= 1u << (j & 31);
+    }
+    std::memcpy(t->quarter_wave, kQuarterWave, sizeof kQuarterWave);
+}
+
+static const uint64_t kCarrMask = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1;
+static const uint64_t kCodeMask = (UINT64_C(1) << GPSIQ_CODE_FRAC_BITS) - 1;
+
+uint64_t carr_phase_to_fixed(double cycles)
+{
+    return (uint64_t) std::floor(std::ldexp(cycles, GPSIQ_CARR_FRAC_BITS)) & kCarrMask;
+}
+
+double carr_phase_to_double(uint64_t fixed)
+{
+    return std::ldexp((double) (fixed & kCarrMask), -GPSIQ_CARR_FRAC_BITS);
+}
+
+// One channel, one block.  Returns GPSIQ_OK or an error with text set.
+int quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t *carry_in,
+                 gpsiq_qchan_t *q, uint64_t *carry_out)
+{
+    std::memset(q, 0, sizeof *q);
+    if (ch.prn <= 0) {
+        if (carry_out) *carry_out = 0;
+        return GPSIQ_OK;
+    }
+    if (ch.prn > 32) return fail(GPSIQ_E_ARG, "prn %d out of range 1..32", ch.prn);
+    const double carr_inc = ch.f_carr * delt;   // the operand of gps.c:2821
+    const double code_inc = ch.f_code * delt;   // the operand of gps.c:2789
+    if (!(std::fabs(carr_inc) < 0.5))
+        return fail(GPSIQ_E_RANGE, "prn %d: |f_carr/fs| = %g not < 0.5 cycle/sample", ch.prn, carr_inc);
+    if (!(code_inc > 0.0 && code_inc < 2.0))
+        return fail(GPSIQ_E_RANGE, "prn %d: f_code/fs = %g outside (0, 2) chips/sample", ch.prn, code_inc);
+    if (!(ch.carr_phase >= 0.0 && ch.carr_phase < 1.0))
+        return fail(GPSIQ_E_RANGE, "prn %d: carr_phase %g outside [0,1)", ch.prn, ch.carr_phase);
+    if (!(ch.code_phase >= 0.0 && ch.code_phase < (double) GPSIQ_CA_SEQ_LEN))
+        return fail(GPSIQ_E_RANGE, "prn %d: code_phase %g outside [0,1023)", ch.prn, ch.code_phase);
+    if (ch.iword < 0 || ch.iword >= GPSIQ_N_DWRD || ch.ibit < 0 || ch.ibit > 29 || ch.icode < 0 || ch.icode > 19)
+        return fail(GPSIQ_E_RANGE, "prn %d: iword/ibit/icode = %d/%d/%d out of range", ch.prn, ch.iword, ch.ibit, ch.icode);
+
+    q->prn = (uint8_t) ch.prn;
+    q->icode = (uint8_t) ch.icode;
+    q->gain = ch.gain;
+    q->carr_step = std::llrint(std::ldexp(carr_inc, GPSIQ_CARR_FRAC_BITS));
+    q->carr_phase = carry_in ? (*carry_in & kCarrMask) : carr_phase_to_fixed(ch.carr_phase);
+    const int whole = (int) ch.code_phase;
+    q->chip0 = (uint16_t) whole;
+    q->code_frac = (uint64_t) std::floor(std::ldexp(ch.code_phase - (double) whole, GPSIQ_CODE_FRAC_BITS)) & kCodeMask;
+    q->code_step = (uint64_t) std::llrint(std::ldexp(code_inc, GPSIQ_CODE_FRAC_BITS));
+
+    // Nav data bits this block can reach, in the order the loop walks them
+    // (gps.c:2795-2811: 20 code periods per bit, 30 bits per word).
+    const unsigned __int128 last = (unsigned __int128) q->code_frac +
+        (unsigned __int128) q->code_step * (unsigned __int128) (nsamp > 0 ? nsamp - 1 : 0);
+    const uint64_t chips_end = (uint64_t) whole + (uint64_t) (last >> GPSIQ_CODE_FRAC_BITS);
+    const uint64_t nbits = ((uint64_t) ch.icode + chips_end / GPSIQ_CA_SEQ_LEN) / 20 + 1;
+    if (nbits > GPSIQ_MAX_NAV_BITS)
+        return fail(GPSIQ_E_RANGE, "prn %d: block spans %llu nav bits (max %d)", ch.prn,
+                    (unsigned long long) nbits, GPSIQ_MAX_NAV_BITS);
+    int word = ch.iword, bit = ch.ibit;
+    for (unsigned b = 0; b < nbits; ++b) {
+        if (word >= GPSIQ_N_DWRD)
+            return fail(GPSIQ_E_RANGE, "prn %d: block runs past dwrd[%d]", ch.prn, GPSIQ_N_DWRD - 1);
+        q->nav_bits |= ((ch.dwrd[word] >> (29 - bit)) & 1u) << b;
+        if (++bit == 30) { bit = 0; ++word; }
+    }
+    if (carry_out)
+        *carry_out = (q->carr_phase + (uint64_t) q->carr_step * (uint64_t) nsamp) & kCarrMask;
+    return GPSIQ_OK;
+}
+
+}  // namespace gpsiq
+
+using namespace gpsiq;
+
+extern "C" {
+
+const char *gpsiq_version(void) { return "gpsiq 0.1 (gfx950)"; }
+
+const char *gpsiq_last_error(void) { return g_err; }
+
+int gpsiq_prn_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN])
+{
+    if (prn < 1 || prn > 32 || !chips) return fail(GPSIQ_E_ARG, "prn %d out of range 1..32", prn);
+    ca_code(prn, chips);
+    return GPSIQ_OK;
+}
+
+void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512_out[512])
+{
+    for (int k = 0; k < 512; ++k) {
+        if (sin512_out) sin512_out[k] = (int16_t) sin512(k);
+        if (cos512) cos512[k] = (int16_t) sin512(k + 128);
+    }
+}
+
+int gpsiq_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
+                   gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out)
+{
+    if (!ch || !out) return fail(GPSIQ_E_ARG, "null descriptor pointer");
+    if (nchan < 0 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "nchan %d outside 0..%d", nchan, GPSIQ_MAX_CHAN);
+    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
+    const double delt = 1.0 / fs;   // gps.c:2298
+    for (int c = 0; c < nchan; ++c) {
+        int rc = quantize_one(ch[c], delt, nsamp, carry_in ? &carry_in[c] : nullptr, &out[c],
+                              carry_out ? &carry_out[c] : nullptr);
+        if (rc != GPSIQ_OK) return rc;
+    }
+    return GPSIQ_OK;
+}
+
+int gpsiq_chunker_init(gpsiq_chunker_t *ck, int sink_kind, int sample_size,
+                       gpsiq_iq_buf_t *(*acquire)(void *), void (*enqueue)(void *, gpsiq_iq_buf_t *),
+                       void *user)
+{
+    if (!ck || !acquire || !enqueue) return fail(GPSIQ_E_ARG, "null chunker argument");
+    if (sink_kind < GPSIQ_SINK_IQFILE || sink_kind > GPSIQ_SINK_PLUTOSDR) return fail(GPSIQ_E_ARG, "bad sink kind %d", sink_kind);
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    ck->acquire = acquire; ck->enqueue = enqueue; ck->user = user;
+    ck->sink_kind = sink_kind; ck->sample_size = sample_size;
+    ck->cur = acquire(user);                       // gps.c:2698
+    return ck->cur ? GPSIQ_OK : fail(GPSIQ_E_STATE, "fifo halted: acquire returned NULL");
+}
+
+// gps.c:2839-2865 on whole runs of elements instead of one element at a time.
+int gpsiq_chunker_push(gpsiq_chunker_t *ck, const void *elems, size_t nelem)
+{
+    if (!ck || !elems) return fail(GPSIQ_E_ARG, "null chunker argument");
+    if (!ck->cur) return fail(GPSIQ_E_STATE, "fifo halted");
+    const size_t esz = (size_t) ck->sample_size;
+    const unsigned char *src = (const unsigned char *) elems;
+    int enq = 0;
+    while (nelem) {
+        gpsiq_iq_buf_t *b = ck->cur;
+        size_t room = ck->sink_kind == GPSIQ_SINK_HACKRF
+                          ? (size_t) GPSIQ_HACKRF_CHUNK - b->validLength     // gps.c:2849
+                          : (size_t) b->totalLength - b->validLength;
+        if (b->validLength + (room < nelem ? room : nelem) > b->totalLength)
+            return fail(GPSIQ_E_RANGE, "fifo buffer of %u elements too small", b->totalLength);
+        size_t n = room < nelem ? room : nelem;
+        unsigned char *dstp = esz == 2 ? (unsigned char *) (b->data16 + b->validLength)
+                                       : (unsigned char *) (b->data8 + b->validLength);
+        std::memcpy(dstp, src, n * esz);
+        b->validLength += (unsigned) n;
+        src += n * esz;
+        nelem -= n;
+        if (ck->sink_kind == GPSIQ_SINK_HACKRF && b->validLength == GPSIQ_HACKRF_CHUNK) {
+            ck->enqueue(ck->user, b);              // gps.c:2851-2853
+            ++enq;
+            if (!(ck->cur = ck->acquire(ck->user))) return fail(GPSIQ_E_STATE, "fifo halted");
+        } else if (nelem) {
+            return fail(GPSIQ_E_RANGE, "block does not fit the fifo buffer");
+        }
+    }
+    if (ck->sink_kind != GPSIQ_SINK_HACKRF) {      // gps.c:2860-2865
+        ck->enqueue(ck->user, ck->cur);
+        ++enq;
+        if (!(ck->cur = ck->acquire(ck->user))) return fail(GPSIQ_E_STATE, "fifo halted");
+    }
+    return enq;
+}
+
+}  // extern "C"

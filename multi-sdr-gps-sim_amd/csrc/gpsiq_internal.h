@@ -1,0 +1,31 @@
+// gpsiq_internal.h — shared between the host half and the device half of libgpsiq.
+#ifndef GPSIQ_INTERNAL_H
+#define GPSIQ_INTERNAL_H
+
+#include "../../include/gpsiq.h"
+#include "gpsiq_tables.h"
+
+namespace gpsiq {
+
+int  fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void ca_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN]);
+void build_device_tables(DeviceTables *t);
+uint64_t carr_phase_to_fixed(double cycles);
+double   carr_phase_to_double(uint64_t fixed);
+int  quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t *carry_in,
+                  gpsiq_qchan_t *q, uint64_t *carry_out);
+
+// Kernel variants (gpsiq_launch's `variant`).
+enum Variant {
+    kAuto = 0,      // fast when every resident descriptor allows it, else generic
+    kGeneric = 1,   // one sample per thread, full-width closed form per sample (any rate)
+    kRows = 2,      // 64-sample rows per wave, incremental NCOs, LDS-staged windows
+    kNumVariants
+};
+
+// The row kernel needs all 64 lanes of a row inside one 32-chip window:
+// 63*code_step + (1 chip) <= 32 chips.
+constexpr uint64_t kRowsMaxCodeStep = ((UINT64_C(31) << GPSIQ_CODE_FRAC_BITS) - 1) / 63;
+
+}  // namespace gpsiq
+#endif

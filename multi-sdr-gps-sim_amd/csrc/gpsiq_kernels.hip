@@ -1,0 +1,269 @@
+// gpsiq_kernels.hip — gfx950 (MI355X, wave64) kernels of libgpsiq.
+//
+// Replaces the per-sample loop of Mictronics/multi-sdr-gps-sim gps.c:2767-2836 and
+// the pack of gps.c:2839-2846 with the closed-form integer NCO model of
+// include/gpsiq.h.  One workgroup synthesises one tile of one 0.1 s block:
+//   * the per-channel gain LUT  TC/TS[k] = (int)(table[k]*gain)  (gps.c:2781-2782
+//     with dataBit*codeCA factored out) is built once per workgroup into LDS,
+//     packed (I | Q<<16) as two int16 — sums are taken mod 2^16, which is exactly
+//     what the reference's (short) store keeps (gps.c:2834-2835);
+//   * the 1023-chip C/A codes are staged in LDS bit-packed, with a wrap-around tail;
+//   * nothing is read from HBM per sample: the only traffic is the IQ write.
+// No MFMA: there is no contraction in this path; it is integer VALU + LDS gather.
+#include <hip/hip_runtime.h>
+
+#include "gpsiq_internal.h"
+
+namespace gpsiq {
+
+constexpr int kMaxChan = GPSIQ_MAX_CHAN;
+constexpr uint64_t kCodeFracMask = (UINT64_C(1) << GPSIQ_CODE_FRAC_BITS) - 1;
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dev_sin512(const int16_t *qw, int k)
+{
+    k &= 511;
+    int h = k & 255;
+    int v = qw[h < 128 ? h : 255 - h];
+    return k < 256 ? v : -v;
+}
+
+// Workgroup prologue shared by both kernels: descriptors, gain LUTs and C/A codes to LDS.
+template <int NT>
+__device__ __forceinline__ void stage_block(const gpsiq_qchan_t *__restrict__ q, int nchan,
+                                            const DeviceTables *__restrict__ tab,
+                                            gpsiq_qchan_t *qs, uint32_t (*lut)[512],
+                                            uint32_t (*ext)[kPrnExtWords])
+{
+    const int tid = threadIdx.x;
+    // 48-byte descriptors as 12 dwords each
+    for (int i = tid; i < nchan * 12; i += NT)
+        reinterpret_cast<uint32_t *>(qs)[i] = reinterpret_cast<const uint32_t *>(q)[i];
+    __syncthreads();
+    for (int e = tid; e < nchan * 512; e += NT) {
+        const int c = e >> 9, k = e & 511;
+        if (qs[c].prn == 0) continue;
+        const double g = qs[c].gain;
+        // (int)(int * double): exact int->double, one IEEE multiply, truncation toward 0
+        const int ts = (int) ((double) dev_sin512(tab->quarter_wave, k) * g);
+        const int tc = (int) ((double) dev_sin512(tab->quarter_wave, k + 128) * g);
+        lut[c][k] = ((uint32_t) tc & 0xffffu) | ((uint32_t) ts << 16);
+    }
+    for (int e = tid; e < nchan * kPrnExtWords; e += NT) {
+        const int c = e / kPrnExtWords, w = e % kPrnExtWords;
+        if (qs[c].prn == 0) continue;
+        ext[c][w] = tab->prn_ext[qs[c].prn - 1][w];
+    }
+    __syncthreads();
+}
+
+template <int FMT>
+__device__ __forceinline__ void store_sample(uint8_t *__restrict__ blk_dst, uint32_t n, uint32_t iq)
+{
+    if (FMT == GPSIQ_SC16) {
+        reinterpret_cast<uint32_t *>(blk_dst)[n] = iq;                      // gps.c:2842
+    } else {
+        // (signed char)(x >> 4) on each int16 half, arithmetic shift          gps.c:2845
+        const int i16 = (int16_t) (iq & 0xffffu), q16 = (int16_t) (iq >> 16);
+        reinterpret_cast<uint16_t *>(blk_dst)[n] =
+            (uint16_t) (((uint32_t) (i16 >> 4) & 0xffu) | (((uint32_t) (q16 >> 4) & 0xffu) << 8));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generic kernel: one sample per thread per step, every quantity of the closed form
+// evaluated at full width for that sample.  Works for any rate the descriptor format
+// allows; it is the fallback for sample rates too low for the row kernel, and an
+// independent second implementation the tests cross-check the row kernel against.
+constexpr int kGenericThreads = 256;
+
+template <int FMT>
+__global__ __launch_bounds__(kGenericThreads) void synth_generic(
+    const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
+    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block,
+    int tile_samples)
+{
+    __shared__ uint32_t lut[kMaxChan][512];
+    __shared__ uint32_t ext[kMaxChan][kPrnExtWords];
+    __shared__ gpsiq_qchan_t qs[kMaxChan];
+
+    const int blk = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    stage_block<kGenericThreads>(desc + (size_t) (block0 + blk) * nchan, nchan, tab, qs, lut, ext);
+    uint8_t *blk_dst = dst + (size_t) blk * block_stride;
+
+    const uint32_t n_begin = (uint32_t) tile * (uint32_t) tile_samples;
+    uint32_t n_end = n_begin + (uint32_t) tile_samples;
+    if (n_end > (uint32_t) nsamp) n_end = (uint32_t) nsamp;
+
+    for (uint32_t n = n_begin + threadIdx.x; n < n_end; n += kGenericThreads) {
+        int i_acc = 0, q_acc = 0;
+        for (int c = 0; c < nchan; ++c) {
+            const gpsiq_qchan_t &q = qs[c];
+            if (q.prn == 0) continue;
+            const uint64_t P = q.carr_phase + (uint64_t) q.carr_step * (uint64_t) n;
+            const uint32_t idx = (uint32_t) (P >> (GPSIQ_CARR_FRAC_BITS - 9)) & 511u;
+            const unsigned __int128 T = (unsigned __int128) q.code_frac +
+                                        (unsigned __int128) q.code_step * (unsigned __int128) n;
+            const uint64_t A = (uint64_t) q.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+            const uint32_t chip = (uint32_t) (A % GPSIQ_CA_SEQ_LEN);
+            const uint64_t period = A / GPSIQ_CA_SEQ_LEN;
+            const uint32_t bit = (uint32_t) ((q.icode + period) / 20);
+            const uint32_t neg = ((ext[c][chip >> 5] >> (chip & 31)) ^ (q.nav_bits >> (bit & 31))) & 1u;
+            const uint32_t v = lut[c][idx];
+            const int tc = (int16_t) (v & 0xffffu), ts = (int16_t) (v >> 16);
+            i_acc += neg ? -tc : tc;
+            q_acc += neg ? -ts : ts;
+        }
+        store_sample<FMT>(blk_dst, n, ((uint32_t) i_acc & 0xffffu) | ((uint32_t) q_acc << 16));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row kernel.  A "row" is 64 consecutive samples, one per lane of a wave, so that
+//   * IQ stores are one contiguous 128/256-byte run per wave instruction,
+//   * the carrier LUT indices of a wave are (nearly) consecutive -> conflict-free
+//     ds_read_b32 with broadcasts,
+//   * all lanes of a row sit inside one 32-chip window of the C/A code, which is a
+//     wave-uniform 32-bit word W (chip xor nav bit) prepared once per (channel,row):
+//     W[A mod 32] is the sign of absolute chip A, so a lane needs only the low 5
+//     bits of its own chip counter to find its sign — no mod-1023, no divisions.
+// Each wave owns kRowsPerWave consecutive rows.  Per channel it keeps two 64-bit
+// per-lane accumulators (carrier phase, code phase) and steps them by one row
+// (64 samples) with a 64-bit add each; the per-lane start values are exact
+// (64x32-bit products, wrapping mod 2^64 = mod 32 cycles / mod 256 chips).
+// Code phase word: [chips mod 256 : 8][fraction : 56]; carrier word: [5 don't-care]
+// [LUT index : 9][fraction : 50].
+constexpr int kWaves = 8;
+constexpr int kRowsPerWave = 32;
+constexpr int kRowsThreads = kWaves * 64;
+constexpr int kRowsTile = kWaves * kRowsPerWave * 64;   // 16384 samples
+constexpr int kWinRowsPerLane = kRowsPerWave * kMaxChan / 64;   // rows one lane prepares
+
+template <int FMT>
+__global__ __launch_bounds__(kRowsThreads) void synth_rows(
+    const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
+    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block)
+{
+    __shared__ uint32_t lut[kMaxChan][512];
+    __shared__ uint32_t ext[kMaxChan][kPrnExtWords];
+    __shared__ uint32_t win[kWaves][kMaxChan][kRowsPerWave];
+    __shared__ gpsiq_qchan_t qs[kMaxChan];
+
+    const int blk = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    stage_block<kRowsThreads>(desc + (size_t) (block0 + blk) * nchan, nchan, tab, qs, lut, ext);
+    uint8_t *blk_dst = dst + (size_t) blk * block_stride;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_wave = (uint32_t) tile * kRowsTile + (uint32_t) wave * (kRowsPerWave * 64);
+
+    // ---- windows: lane (c, g) prepares rows g*R .. g*R+R-1 of channel c -----------
+    {
+        const int c = lane & (kMaxChan - 1), g = lane / kMaxChan;
+        if (c < nchan && qs[c].prn != 0) {
+            const gpsiq_qchan_t &q = qs[c];
+            const uint32_t n_row = n_wave + (uint32_t) (g * kWinRowsPerLane) * 64u;
+            const unsigned __int128 T = (unsigned __int128) q.code_frac +
+                                        (unsigned __int128) q.code_step * (unsigned __int128) n_row;
+            uint64_t A = (uint64_t) q.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+            uint64_t fr = (uint64_t) T & kCodeFracMask;
+            uint32_t k = (uint32_t) (A % GPSIQ_CA_SEQ_LEN);          // chip inside the period
+            const uint64_t ic = q.icode + A / GPSIQ_CA_SEQ_LEN;
+            uint32_t bit = (uint32_t) (ic / 20), icur = (uint32_t) (ic % 20);
+            uint32_t a5 = (uint32_t) A;                                // only A mod 32 is used
+            const uint64_t row_step = q.code_step * 64u;
+            const uint32_t d_int = (uint32_t) (row_step >> GPSIQ_CODE_FRAC_BITS);
+            const uint64_t d_fr = row_step & kCodeFracMask;
+            const uint32_t nav = q.nav_bits;
+#pragma unroll
+            for (int r = 0; r < kWinRowsPerLane; ++r) {
+                // 32 chips starting at chip k of the (wrap-extended) code
+                const uint32_t lo = ext[c][k >> 5], hi = ext[c][(k >> 5) + 1];
+                uint32_t S = __builtin_amdgcn_alignbit(hi, lo, k & 31u);
+                // chips at window positions >= 1023-k belong to the next code period
+                const uint32_t to_wrap = GPSIQ_CA_SEQ_LEN - k;
+                const uint32_t next_mask = to_wrap < 32u ? (0xffffffffu << to_wrap) : 0u;
+                const uint32_t bit_next = icur == 19u ? bit + 1u : bit;
+                const uint32_t d0 = 0u - ((nav >> (bit & 31u)) & 1u);
+                const uint32_t d1 = 0u - ((nav >> (bit_next & 31u)) & 1u);
+                S ^= (d0 & ~next_mask) ^ (d1 & next_mask);
+                win[wave][c][g * kWinRowsPerLane + r] = __builtin_rotateleft32(S, a5 & 31u);
+                // advance one row
+                fr += d_fr;
+                const uint32_t adv = d_int + (uint32_t) (fr >> GPSIQ_CODE_FRAC_BITS);
+                fr &= kCodeFracMask;
+                a5 += adv;
+                k += adv;
+                if (k >= GPSIQ_CA_SEQ_LEN) {
+                    k -= GPSIQ_CA_SEQ_LEN;
+                    if (++icur == 20u) { icur = 0u; ++bit; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- synthesis -------------------------------------------------------------
+    s16x2 acc[kRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) acc[r] = (s16x2) (0);
+
+    const uint32_t n0 = n_wave + (uint32_t) lane;
+    for (int c = 0; c < nchan; ++c) {
+        const gpsiq_qchan_t &q = qs[c];
+        if (q.prn == 0) continue;
+        uint64_t P = q.carr_phase + (uint64_t) q.carr_step * (uint64_t) n0;
+        uint64_t Q = ((uint64_t) q.chip0 << GPSIQ_CODE_FRAC_BITS) + q.code_frac + q.code_step * (uint64_t) n0;
+        const uint64_t dP = (uint64_t) q.carr_step * 64u;
+        const uint64_t dQ = q.code_step * 64u;
+        const unsigned char *lut_c = reinterpret_cast<const unsigned char *>(lut[c]);
+        const uint32_t *win_c = win[wave][c];
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const uint32_t w = win_c[r];
+            const uint32_t b = (uint32_t) (Q >> 56);
+            const uint32_t m = (uint32_t) __builtin_amdgcn_sbfe((int) w, b, 1u);   // 0 or ~0
+            const uint32_t sgn = m | 0x00010001u;                                 // (+1,+1) or (-1,-1)
+            const uint32_t a = (uint32_t) (P >> 48) & 0x7fcu;                      // 4 * LUT index
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(lut_c + a);
+            acc[r] = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc[r];
+            P += dP;
+            Q += dQ;
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const uint32_t n = n0 + (uint32_t) r * 64u;
+        if (n < (uint32_t) nsamp)
+            store_sample<FMT>(blk_dst, n, __builtin_bit_cast(uint32_t, acc[r]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
+                          void *dst, size_t block_stride, int block0, int nblocks,
+                          const DeviceTables *tab, hipStream_t stream)
+{
+    if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    if (variant == kRows) {
+        const int tiles = (nsamp + kRowsTile - 1) / kRowsTile;
+        dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
+        if (sample_size == GPSIQ_SC16)
+            hipLaunchKernelGGL(synth_rows<GPSIQ_SC16>, grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles);
+        else
+            hipLaunchKernelGGL(synth_rows<GPSIQ_SC08>, grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles);
+    } else {
+        const int tile_samples = 4096;
+        const int tiles = (nsamp + tile_samples - 1) / tile_samples;
+        dim3 grid((unsigned) (tiles * nblocks)), block(kGenericThreads);
+        if (sample_size == GPSIQ_SC16)
+            hipLaunchKernelGGL(synth_generic<GPSIQ_SC16>, grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, tile_samples);
+        else
+            hipLaunchKernelGGL(synth_generic<GPSIQ_SC08>, grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, tile_samples);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gpsiq

@@ -1,0 +1,175 @@
+"""gpsiq — Python host binding of libgpsiq (the C-ABI in include/gpsiq.h).
+
+The shared library holds the hand-written gfx950 kernels; this module only marshals
+numpy descriptors and raw device pointers (e.g. ``torch.Tensor.data_ptr()``) into it.
+There is no fallback: if libgpsiq.so is missing the import fails, and without a GPU
+``Context()`` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,  # noqa: F401
+                  SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or make -C multi-sdr-gps-sim_amd/csrc); gpsiq has no non-HIP path")
+
+_lib = C.CDLL(LIB_PATH)
+
+
+class GpsiqError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"gpsiq error {code}: {text}")
+        self.code = code
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(_lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_version = _sig("gpsiq_version", C.c_char_p)
+_last_error = _sig("gpsiq_last_error", C.c_char_p)
+_prn_code = _sig("gpsiq_prn_code", _i, _i, _vp)
+_carrier_table = _sig("gpsiq_carrier_table", None, _vp, _vp)
+_quantize = _sig("gpsiq_quantize", _i, _vp, _i, _d, _i, _vp, _vp, _vp)
+_create = _sig("gpsiq_create", _i, C.POINTER(_vp), _i)
+_destroy = _sig("gpsiq_destroy", None, _vp)
+_generate_block = _sig("gpsiq_generate_block", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp)
+_generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i)
+_set_descriptors = _sig("gpsiq_set_descriptors", _i, _vp, _vp, _i, _i)
+_launch = _sig("gpsiq_launch", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i)
+_synchronize = _sig("gpsiq_synchronize", _i, _vp, _vp)
+_time_launches = _sig("gpsiq_time_launches", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i, _i, C.POINTER(C.c_float))
+_num_variants = _sig("gpsiq_num_variants", _i)
+_variant_name = _sig("gpsiq_variant_name", C.c_char_p, _i)
+
+
+def _check(rc):
+    if rc < 0:
+        raise GpsiqError(rc, _last_error().decode())
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def version():
+    return _version().decode()
+
+
+def variants():
+    return {_variant_name(v).decode(): v for v in range(_num_variants())}
+
+
+def prn_code(prn):
+    ca = np.zeros(1023, dtype=np.uint8)
+    _check(_prn_code(int(prn), _p(ca)))
+    return ca
+
+
+def carrier_table():
+    cos = np.zeros(512, dtype=np.int16)
+    sin = np.zeros(512, dtype=np.int16)
+    _carrier_table(_p(cos), _p(sin))
+    return cos, sin
+
+
+def quantize(ch, fs, nsamp, carry_in=None):
+    """One block: gpsiq_chan_t[nchan] -> (gpsiq_qchan_t[nchan], carry_out[nchan])."""
+    ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+    q = np.zeros(len(ch), dtype=QCHAN_DTYPE)
+    cout = np.zeros(len(ch), dtype=np.uint64)
+    cin = None if carry_in is None else np.ascontiguousarray(carry_in, dtype=np.uint64)
+    _check(_quantize(_p(ch), len(ch), float(fs), int(nsamp), _p(q), None if cin is None else _p(cin), _p(cout)))
+    return q, cout
+
+
+def quantize_blocks(desc, fs, nsamp, carry0=None):
+    """[nblocks][nchan] descriptors -> quantised descriptors with the carrier carried
+    exactly from block to block (the rule of gpsiq_generate_batch).  Returns (q, carry_end)."""
+    desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+    nb, nc = desc.shape
+    q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+    carry = carry0
+    for b in range(nb):
+        cin = None
+        if carry is not None:
+            cin = np.array(carry, dtype=np.uint64)
+            if b > 0:
+                for c in range(nc):
+                    if desc[b, c]["prn"] != desc[b - 1, c]["prn"]:
+                        cin[c] = np.uint64(int(np.floor(np.ldexp(float(desc[b, c]["carr_phase"]), 59))))
+        q[b], carry = quantize(desc[b], fs, nsamp, cin)
+    return q, carry
+
+
+class Context:
+    """One libgpsiq context = one GPU."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        _check(_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- drop-in entry points (host buffers) --
+    def generate_block(self, ch, nsamp, fs, sample_size):
+        ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+        out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
+        carr = np.zeros(len(ch), dtype=np.float64)
+        _check(_generate_block(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _p(out), _p(carr)))
+        return out, carr
+
+    def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None):
+        desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+        nb, nc = desc.shape
+        if device_ptr is not None:
+            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(device_ptr), 1))
+            return None
+        out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
+        _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(out), 0))
+        return out
+
+    # -- resident-descriptor path (device buffers) --
+    def set_descriptors(self, q):
+        q = np.ascontiguousarray(q, dtype=QCHAN_DTYPE)
+        nb, nc = q.shape
+        _check(_set_descriptors(self._h, _p(q), nb, nc))
+
+    def launch(self, block0, nblocks, nsamp, sample_size, device_ptr, block_stride, stream=None, variant=0):
+        _check(_launch(self._h, int(block0), int(nblocks), int(nsamp), int(sample_size), _vp(device_ptr),
+                       int(block_stride), _vp(stream) if stream else None, int(variant)))
+
+    def synchronize(self, stream=None):
+        _check(_synchronize(self._h, _vp(stream) if stream else None))
+
+    def time_launches(self, block0, nblocks, nsamp, sample_size, device_ptr, block_stride, iters,
+                      stream=None, variant=0):
+        ms = C.c_float(0.0)
+        _check(_time_launches(self._h, int(block0), int(nblocks), int(nsamp), int(sample_size), _vp(device_ptr),
+                              int(block_stride), _vp(stream) if stream else None, int(variant), int(iters),
+                              C.byref(ms)))
+        return ms.value

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own code (oracle/_ref/libgpsref.so).
+
+Run HERE (needs /root/reference to build oracle/_ref); the fixtures are data only:
+inputs (channel descriptors) and expected outputs (SHA-256 of every block the
+reference loop produced, the first 4096 elements verbatim, the carrier phase the loop
+left behind), plus the reference's LUTs and C/A codes.
+
+    python tests/golden/make_golden.py
+
+Each case records `t1_mismatch`: the number of elements per block where the fixed-point
+closed form (oracle_block_fixed, seeded with the reference's own carried carr_phase)
+differs from the reference's double-accumulator loop.  See DESIGN.md "Parity tiers".
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+
+import _oracle  # noqa: E402
+from gpsiq.abi import SC08, SC16, SINK_HACKRF, SINK_IQFILE  # noqa: E402
+from gpsiq.scenario import synth_blocks  # noqa: E402
+
+HEAD = 4096
+
+# name, fs, nchan, sample_size, nblocks, seed, tweak
+CASES = [
+    ("ref3M_12ch_sc08", 3000000, 12, SC08, 4, 101, None),       # the unmodified reference constants
+    ("cfg2_2M6_12ch_sc08", 2600000, 12, SC08, 4, 102, None),    # BASELINE config 1/2
+    ("bench_2M6_16ch_sc08", 2600000, 16, SC08, 3, 20250215, None),  # bench.py workload seed
+    ("cfg4_2M6_16ch_sc16", 2600000, 16, SC16, 3, 104, None),    # config 4 format
+    ("cfg3_10M_16ch_sc16", 10000000, 16, SC16, 2, 103, None),   # config 3
+    ("cfg5_25M_16ch_sc16", 25000000, 16, SC16, 1, 105, None),   # config 5, one block
+    ("wrap8_3M_16ch_sc08", 3000000, 16, SC08, 1, 106, "loud"),  # |sum| > 2047: int8 wraps (gps.c:2845)
+    ("navedge_3M_8ch_sc16", 3000000, 8, SC16, 2, 107, "navedge"),  # icode=19, ibit=29: word/bit roll-over
+    ("realloc_3M_8ch_sc08", 3000000, 8, SC08, 3, 108, "realloc"),  # slot emptied / re-allocated
+]
+
+
+def tweak(desc, kind):
+    if kind == "loud":
+        desc["gain"] = 1.9          # Pluto-style x2 gain (gps.c:2759): 16*250*1.9 > 2047*... wraps int8
+    elif kind == "navedge":
+        desc["icode"] = 19
+        desc["ibit"] = 29
+        desc["iword"][:] = np.arange(desc.shape[1])[None, :] % 58
+        desc["code_phase"] = 1022.0 + desc["code_phase"] / 1023.0
+    elif kind == "realloc":
+        desc["prn"][1, 2] = 0        # slot 2 empty in block 1
+        desc["prn"][2, 2] = 31       # re-allocated to another SV in block 2
+        desc["carr_phase"][2, 2] = 0.625
+        desc["prn"][:, 5] = 0        # slot 5 never used
+    return desc
+
+
+def main():
+    _oracle.build()
+    o, r = _oracle.load_oracle(), _oracle.load_ref()
+    assert r is not None, "oracle/_ref/libgpsref.so missing"
+
+    s, c = r.tables()
+    prn = np.stack([np.packbits(r.codegen(p), bitorder="little") for p in range(1, 33)])
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), sin512=s.astype(np.int16), cos512=c.astype(np.int16),
+                        prn_packed=prn)
+
+    for name, fs, nchan, ss, nb, seed, kind in CASES:
+        desc = tweak(synth_blocks(nb, nchan, seed=seed), kind)
+        ns = fs // 10
+        out, chunks, carr = r.run_blocks(desc, fs, ss, SINK_IQFILE)
+        assert len(out) == 2 * ns * nb and (chunks == 2 * ns).all()
+        sha = [hashlib.sha256(out[b * 2 * ns:(b + 1) * 2 * ns].tobytes()).hexdigest() for b in range(nb)]
+        head = np.stack([out[b * 2 * ns: b * 2 * ns + HEAD] for b in range(nb)])
+        t1 = []
+        for b in range(nb):
+            db = desc[b].copy()
+            if b > 0:
+                keep = desc[b]["prn"] == desc[b - 1]["prn"]
+                db["carr_phase"] = np.where(keep, carr[b - 1], db["carr_phase"])
+            q, _ = o.quantize(db, fs, ns)
+            fx = o.block_fixed(q, ns, ss, seq=True)
+            t1.append(int(np.count_nonzero(fx != out[b * 2 * ns:(b + 1) * 2 * ns])))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), desc=desc.view(np.uint8).reshape(nb, nchan, -1),
+                            fs=fs, nsamp=ns, sample_size=ss, sha256=np.array(sha), head=head, carr_out=carr,
+                            t1_mismatch=np.array(t1))
+        print(f"{name}: {nb} blocks x {ns} samples, T1 mismatching elements per block = {t1}")
+
+    # fifo chunking (gps.c:2847-2856): HackRF 262144-element buffers, partial buffer carried over
+    desc = synth_blocks(3, 4, seed=109)
+    out, chunks, _ = r.run_blocks(desc, 3000000, SC08, SINK_HACKRF)
+    np.savez_compressed(os.path.join(HERE, "hackrf_chunks.npz"), desc=desc.view(np.uint8).reshape(3, 4, -1),
+                        fs=3000000, nsamp=300000, sample_size=SC08, chunk_len=chunks,
+                        sha256=np.array([hashlib.sha256(out.tobytes()).hexdigest()]), n_elems=len(out))
+    print("hackrf_chunks:", chunks, len(out))
+
+
+if __name__ == "__main__":
+    main()

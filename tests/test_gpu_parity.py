@@ -1,0 +1,254 @@
+"""Parity tests proper: the HIP path through the C-ABI (libgpsiq.so) against the oracle.
+Bit-exact: this is integer/byte work.  Run on the MI355X box with `-m gpu`."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import gpsiq
+from gpsiq.abi import SC08, SC16
+from gpsiq.scenario import synth_blocks
+from test_golden import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = ["generic", "rows"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no CPU path in libgpsiq"
+    c = gpsiq.Context(0)
+    yield c
+    c.close()
+
+
+def run_device(ctx, q, nsamp, ss, variant, block0=0, nblocks=None):
+    """Launch on resident descriptors into a torch buffer; returns [nblocks][2*nsamp]."""
+    import torch
+    nb = q.shape[0] if nblocks is None else nblocks
+    blk = 2 * nsamp * ss
+    stride = (blk + 15) & ~15
+    buf = torch.full((nb * stride + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    ctx.launch(block0, nb, nsamp, ss, buf.data_ptr(), stride,
+               stream=torch.cuda.current_stream().cuda_stream, variant=gpsiq.variants()[variant])
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    assert (host[nb * stride:] == 0x5A).all(), "kernel wrote past the ring"
+    rows = host[: nb * stride].reshape(nb, stride)
+    if stride != blk:
+        assert (rows[:, blk:] == 0x5A).all(), "kernel wrote into the stride padding"
+    return np.ascontiguousarray(rows[:, :blk]).view(np.int8 if ss == SC08 else np.int16)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("fs,nchan,ss,nb", [
+    (2600000, 12, SC08, 3),      # BASELINE config 2
+    (2600000, 16, SC08, 2),      # BASELINE metric workload
+    (2600000, 16, SC16, 2),      # config 4 format
+    (3000000, 8, SC08, 2),       # reference constants
+    (10000000, 16, SC16, 1),     # config 3
+    (25000000, 16, SC16, 1),     # config 5
+])
+def test_blocks_bit_exact_vs_oracle(ctx, oracle, variant, fs, nchan, ss, nb):
+    d = synth_blocks(nb, nchan, seed=fs // 1000 + nchan + ss)
+    ns = fs // 10
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    ctx.set_descriptors(q)
+    got = run_device(ctx, q, ns, ss, variant)
+    for b in range(nb):
+        want = oracle.block_fixed(q[b], ns, ss, seq=True)
+        bad = np.nonzero(got[b] != want)[0]
+        assert bad.size == 0, f"block {b}: {bad.size} differing elements, first at {bad[:5]}"
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("nsamp", [1, 63, 64, 65, 1000, 16383, 16384, 16385, 40000])
+def test_ragged_block_lengths(ctx, oracle, variant, nsamp):
+    d = synth_blocks(2, 7, seed=nsamp)
+    q, _ = gpsiq.quantize_blocks(d, 2.6e6, nsamp)
+    ctx.set_descriptors(q)
+    for ss in (SC08, SC16):
+        got = run_device(ctx, q, nsamp, ss, variant)
+        for b in range(2):
+            assert np.array_equal(got[b], oracle.block_fixed(q[b], nsamp, ss))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_unused_slots_and_single_channel(ctx, oracle, variant):
+    d = synth_blocks(2, 16, seed=11)
+    d["prn"][:, [0, 3, 4, 15]] = 0
+    d["prn"][1, 7] = 0
+    ns = 30000
+    q, _ = gpsiq.quantize_blocks(d, 3e6, ns)
+    ctx.set_descriptors(q)
+    got = run_device(ctx, q, ns, SC16, variant)
+    for b in range(2):
+        assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, SC16))
+    d1 = synth_blocks(1, 1, seed=12)
+    q1, _ = gpsiq.quantize_blocks(d1, 3e6, ns)
+    ctx.set_descriptors(q1)
+    assert np.array_equal(run_device(ctx, q1, ns, SC08, variant)[0], oracle.block_fixed(q1[0], ns, SC08))
+    dz = synth_blocks(1, 4, seed=13)
+    dz["prn"][:] = 0                                  # nothing visible: silence
+    qz, _ = gpsiq.quantize_blocks(dz, 3e6, 5000)
+    ctx.set_descriptors(qz)
+    assert not run_device(ctx, qz, 5000, SC16, variant).any()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_boundary_phases(ctx, oracle, variant):
+    """Phases that sit exactly on chip / LUT / period / nav-bit / word boundaries, zero and
+    extreme Doppler, binary-fraction rates (every boundary is hit exactly)."""
+    ns = 70000
+    d = synth_blocks(1, 16, seed=21)[0]
+    d["code_phase"] = [0.0, 1.0, 1022.0, 1022.999999, 511.5, 0.25, 1022.5, 33.0, 0.0, 1000.0, 7.75, 1.5, 2.0, 3.0, 4.0, 5.0]
+    d["carr_phase"] = [0.0, 0.5, 1.0 - 2.0 ** -53, 1.0 / 512, 255.0 / 512, 0.75, 0.25, 2.0 ** -40, 0.0, 0.999, 0.1, 0.2, 0.3, 0.4, 0.6, 0.7]
+    fs = 4092000.0                                     # f_code/fs = 0.25 exactly when f_carr = 0
+    d["f_carr"] = [0.0, 0.0, fs / 512, -fs / 512, fs / 1024, -fs / 4096, 5000.0, -5000.0, 12345.678, -9876.5, 0.001, -0.001, 2500.0, -2500.0, 100.0, -100.0]
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    d["f_code"][:2] = 1.023e6
+    d["icode"] = [19, 0, 19, 19, 10, 19, 19, 0, 19, 19, 5, 6, 7, 8, 9, 18]
+    d["ibit"] = [29, 0, 29, 28, 15, 29, 29, 0, 29, 29, 1, 2, 3, 4, 5, 6]
+    d["iword"] = np.arange(16) * 3
+    for ss in (SC08, SC16):
+        q, _ = gpsiq.quantize(d, fs, ns)
+        ctx.set_descriptors(q[None, :])
+        got = run_device(ctx, q[None, :], ns, ss, variant)[0]
+        assert np.array_equal(got, oracle.block_fixed(q, ns, ss))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_int8_wraps_like_the_reference(ctx, oracle, variant):
+    """|sum| > 2047 must wrap modulo 256 after >>4, not saturate (gps.c:2845)."""
+    d = synth_blocks(1, 16, seed=31)
+    d["gain"] = 1.9
+    ns = 50000
+    q, _ = gpsiq.quantize_blocks(d, 2.6e6, ns)
+    ctx.set_descriptors(q)
+    g8 = run_device(ctx, q, ns, SC08, variant)[0]
+    g16 = run_device(ctx, q, ns, SC16, variant)[0]
+    assert (np.abs(g16.astype(np.int32)) > 2047).any(), "test input does not overflow int8"
+    assert np.array_equal(g8, (g16 >> 4).astype(np.int8))
+    assert np.array_equal(g8, oracle.block_fixed(q[0], ns, SC08))
+    d["gain"] = 300.0                                  # sums far beyond int16 too: (short) wraps, gps.c:2834
+    q, _ = gpsiq.quantize_blocks(d, 2.6e6, ns)
+    ctx.set_descriptors(q)
+    assert np.array_equal(run_device(ctx, q, ns, SC16, variant)[0], oracle.block_fixed(q[0], ns, SC16))
+
+
+def test_low_sample_rate_uses_generic_kernel(ctx, oracle):
+    """f_code/fs > 31/63: the row kernel's 32-chip window does not hold a row; auto falls
+    back to the generic kernel and asking for the row kernel is an error, not wrong output."""
+    d = synth_blocks(1, 6, seed=41)
+    fs, ns = 1.5e6, 20000
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    ctx.set_descriptors(q)
+    assert np.array_equal(run_device(ctx, q, ns, SC16, "auto")[0], oracle.block_fixed(q[0], ns, SC16))
+    with pytest.raises(gpsiq.GpsiqError) as e:
+        run_device(ctx, q, ns, SC16, "rows")
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_blocks_on_gpu(ctx, name):
+    """The committed captures of the reference's own loop, reproduced by the HIP path
+    (given each block's start state, as captured: tier T1, all with 0 differences)."""
+    g = load_case(name)
+    for b in range(len(g["sha"])):
+        db = g["desc"][b].copy()
+        if b:
+            keep = g["desc"][b]["prn"] == g["desc"][b - 1]["prn"]
+            db["carr_phase"] = np.where(keep, g["carr"][b - 1], db["carr_phase"])
+        q, _ = gpsiq.quantize(db, g["fs"], g["nsamp"])
+        ctx.set_descriptors(q[None, :])
+        got = run_device(ctx, q[None, :], g["nsamp"], g["ss"], "auto")[0]
+        assert hashlib.sha256(got.tobytes()).hexdigest() == g["sha"][b], (name, b)
+        assert np.array_equal(got[: g["head"].shape[1]], g["head"][b])
+
+
+def test_drop_in_block_calls_carry_the_carrier(ctx, oracle):
+    """gpsiq_generate_block called once per 0.1 s block, handing carr_phase back each time
+    (the drop-in pattern of INTEGRATION.md) == gpsiq_generate_batch == oracle with exact carry."""
+    fs, ns, nb, nc = 2.6e6, 26000, 4, 9
+    d = synth_blocks(nb, nc, seed=51)
+    d["prn"][2:, 4] = 0                                # slot 4 goes out of view
+    d["prn"][3, 6] = 30                                # slot 6 re-allocated to a new SV
+    d["carr_phase"][3, 6] = 0.8125
+    qo = oracle.quantize_blocks(d, fs, ns)
+    want = np.stack([oracle.block_fixed(qo[b], ns, SC16) for b in range(nb)])
+    batch = ctx.generate_batch(d, ns, fs, SC16)
+    assert np.array_equal(batch, want)
+    carr = None
+    for b in range(nb):
+        db = d[b].copy()
+        if carr is not None:
+            keep = d[b]["prn"] == d[b - 1]["prn"]
+            db["carr_phase"] = np.where(keep, carr, db["carr_phase"])
+        out, carr = ctx.generate_block(db, ns, fs, SC16)
+        assert np.array_equal(out, want[b]), b
+
+
+def test_time_sharding_is_seamless(ctx, oracle):
+    """Any sub-range of blocks launched on its own equals the same blocks of one big launch
+    (the property the multi-GPU time sharding rests on), and int8 == int16>>4 throughout."""
+    fs, ns, nb = 2.6e6, 260000, 12
+    d = synth_blocks(nb, 16, seed=61)
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    ctx.set_descriptors(q)
+    whole = run_device(ctx, q, ns, SC16, "auto")
+    parts = np.concatenate([run_device(ctx, q, ns, SC16, "auto", block0=b0, nblocks=n)
+                            for b0, n in ((0, 5), (5, 1), (6, 6))])
+    assert np.array_equal(whole, parts)
+    w8 = run_device(ctx, q, ns, SC08, "auto")
+    assert np.array_equal(w8, (whole >> 4).astype(np.int8))
+    for b in (0, 7, 11):
+        n0 = 1000 * b + 17
+        assert np.array_equal(whole[b][2 * n0: 2 * (n0 + 4096)], oracle.block_fixed_range(q[b], n0, 4096, SC16))
+
+
+def test_baseline_size_properties(ctx, oracle):
+    """BASELINE config 3 size (10 Msps, int16, 16 ch): 96 blocks = 384 MB per launch; checks
+    that do not need the oracle over the whole output: both kernels agree byte for byte,
+    int8 == int16>>4, and random windows match the oracle."""
+    import torch
+    fs, ns, nb = 10e6, 1000000, 96
+    pattern = synth_blocks(8, 16, seed=71)
+    d = np.concatenate([pattern] * (nb // 8))
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    ctx.set_descriptors(q)
+    stride = 4 * ns
+    a = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
+    b_ = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.launch(0, nb, ns, SC16, a.data_ptr(), stride, stream=s, variant=gpsiq.variants()["rows"])
+    ctx.launch(0, nb, ns, SC16, b_.data_ptr(), stride, stream=s, variant=gpsiq.variants()["generic"])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b_)
+    c = torch.empty(nb * 2 * ns, dtype=torch.uint8, device="cuda")
+    ctx.launch(0, nb, ns, SC08, c.data_ptr(), 2 * ns, stream=s, variant=gpsiq.variants()["rows"])
+    torch.cuda.synchronize()
+    assert torch.equal((a.view(torch.int16) >> 4).to(torch.int8), c.view(torch.int8))
+    rng = np.random.default_rng(5)
+    a16 = a.view(torch.int16)
+    for _ in range(12):
+        blk, n0 = int(rng.integers(nb)), int(rng.integers(ns - 2048))
+        got = a16[blk * 2 * ns + 2 * n0: blk * 2 * ns + 2 * (n0 + 2048)].cpu().numpy()
+        assert np.array_equal(got, oracle.block_fixed_range(q[blk], n0, 2048, SC16))
+
+
+def test_bad_arguments_are_errors(ctx):
+    d = synth_blocks(1, 2, seed=81)
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.launch(0, 5, 100, SC16, 1 << 20, 400)        # nothing resident yet / out of range
+    bad = d.copy()
+    bad["prn"][0, 0] = 40
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.generate_batch(bad, 100, 2.6e6, SC16)
+    bad = d.copy()
+    bad["code_phase"][0, 0] = 1023.0
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.generate_batch(bad, 100, 2.6e6, SC16)
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.generate_batch(d, 100, 2.6e6, 3)
