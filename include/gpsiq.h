@@ -155,8 +155,8 @@ int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, 
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
 /* Launch synthesis of blocks [block0, block0+nblocks) of the resident descriptors into
  * the DEVICE buffer dst; block b is written at dst + (b-block0)*block_stride_bytes
- * (block_stride_bytes >= 2*nsamp*sample_size, multiple of 16).  Asynchronous on
- * hip_stream (a hipStream_t passed as void*; NULL = the context's own stream).
+ * (block_stride_bytes >= 2*nsamp*sample_size, multiple of 4).  Asynchronous on
+ * hip_stream (a hipStream_t passed as void*; NULL = the HIP null stream).
  * variant selects the kernel: 0 = default, see gpsiq_variant_name(). */
 int gpsiq_launch(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, int sample_size,
                  void *dst, size_t block_stride_bytes, void *hip_stream, int variant);

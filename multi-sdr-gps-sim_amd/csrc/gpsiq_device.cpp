@@ -12,7 +12,7 @@
 namespace gpsiq {
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream);
+                          const DeviceTables *tab, hipStream_t stream, int max_active);
 }
 
 using namespace gpsiq;
@@ -26,6 +26,7 @@ struct gpsiq_ctx {
     size_t         desc_cap = 0;      // in descriptors
     int            nblocks = 0, nchan = 0;
     uint64_t       max_code_step = 0;
+    int            max_active = 0;      // most active channels in any resident block
     // staging for the synchronous entry points
     void          *d_out = nullptr;
     size_t         out_cap = 0;
@@ -68,7 +69,7 @@ static int ensure_out(gpsiq_ctx *c, size_t bytes)
 static int pick_variant(const gpsiq_ctx *c, int variant)
 {
     if (variant == kAuto)
-        return c->max_code_step <= kRowsMaxCodeStep ? kRows : kGeneric;
+        return c->max_code_step <= kRowsMaxCodeStep ? kRowsX : kGeneric;
     return variant;
 }
 
@@ -84,7 +85,7 @@ static int check_launch(const gpsiq_ctx *c, int block0, int nblocks, int nsamp, 
     if (stride < (size_t) 2 * (size_t) nsamp * (size_t) sample_size || (stride & 3))
         return fail(GPSIQ_E_ARG, "block stride %zu too small or not a multiple of 4", stride);
     if (variant < 0 || variant >= kNumVariants) return fail(GPSIQ_E_ARG, "unknown variant %d", variant);
-    if (variant == kRows && c->max_code_step > kRowsMaxCodeStep)
+    if ((variant == kRows || variant == kRowsX) && c->max_code_step > kRowsMaxCodeStep)
         return fail(GPSIQ_E_RANGE, "row kernel needs f_code/fs <= 31/63 chip per sample");
     return GPSIQ_OK;
 }
@@ -139,22 +140,33 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t) nblocks * (size_t) nchan;
     uint64_t mx = 0;
-    for (size_t i = 0; i < n; ++i) {
-        if (q[i].prn > 32) return fail(GPSIQ_E_ARG, "descriptor %zu: prn %u", i, q[i].prn);
-        if (!q[i].prn) continue;
-        if (q[i].chip0 >= GPSIQ_CA_SEQ_LEN || q[i].icode >= 20 || (q[i].code_frac >> GPSIQ_CODE_FRAC_BITS) ||
-            (q[i].code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(q[i].gain > -4.0e6 && q[i].gain < 4.0e6))
-            return fail(GPSIQ_E_RANGE, "descriptor %zu outside the NCO format", i);
-        if (q[i].code_step > mx) mx = q[i].code_step;
+    int max_active = 0;
+    // Device copy is compacted per block: active channels first, unused slots (zeroed)
+    // after them.  The sum over channels is commutative modulo 2^16, so slot order is free.
+    std::vector<gpsiq_qchan_t> packed(n);
+    for (int b = 0; b < nblocks; ++b) {
+        int na = 0;
+        for (int s = 0; s < nchan; ++s) {
+            const size_t i = (size_t) b * nchan + s;
+            if (q[i].prn > 32) return fail(GPSIQ_E_ARG, "descriptor %zu: prn %u", i, q[i].prn);
+            if (!q[i].prn) continue;
+            if (q[i].chip0 >= GPSIQ_CA_SEQ_LEN || q[i].icode >= 20 || (q[i].code_frac >> GPSIQ_CODE_FRAC_BITS) ||
+                (q[i].code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(q[i].gain > -4.0e6 && q[i].gain < 4.0e6))
+                return fail(GPSIQ_E_RANGE, "descriptor %zu outside the NCO format", i);
+            if (q[i].code_step > mx) mx = q[i].code_step;
+            packed[(size_t) b * nchan + na++] = q[i];
+        }
+        for (int s = na; s < nchan; ++s) std::memset(&packed[(size_t) b * nchan + s], 0, sizeof(gpsiq_qchan_t));
+        if (na > max_active) max_active = na;
     }
     int rc = ensure_desc(c, n ? n : 1);
     if (rc) return rc;
     if (n) {
         // make sure no launch still reads the previous descriptors
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(c->d_desc, q, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_desc, packed.data(), n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice));
     }
-    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx;
+    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx; c->max_active = max_active;
     return GPSIQ_OK;
 }
 
@@ -164,9 +176,9 @@ int gpsiq_launch(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int sample_
     int rc = check_launch(c, block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, variant);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    hipStream_t s = (hipStream_t) hip_stream;
     HIP_TRY(launch_variant(pick_variant(c, variant), c->d_desc, c->nchan, nsamp, sample_size, dst,
-                           block_stride_bytes, block0, nblocks, c->d_tab, s));
+                           block_stride_bytes, block0, nblocks, c->d_tab, s, c->max_active));
     return GPSIQ_OK;
 }
 
@@ -174,7 +186,7 @@ int gpsiq_synchronize(gpsiq_ctx_t *c, void *hip_stream)
 {
     if (!c) return fail(GPSIQ_E_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(hip_stream ? (hipStream_t) hip_stream : c->stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t) hip_stream));
     return GPSIQ_OK;
 }
 
@@ -186,7 +198,7 @@ int gpsiq_time_launches(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int 
     int rc = check_launch(c, block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, variant);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    hipStream_t s = (hipStream_t) hip_stream;
     const int v = pick_variant(c, variant);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -194,7 +206,7 @@ int gpsiq_time_launches(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int 
     HIP_TRY(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) {
         hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, block_stride_bytes,
-                                      block0, nblocks, c->d_tab, s);
+                                      block0, nblocks, c->d_tab, s, c->max_active);
         if (e != hipSuccess) {
             (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
             return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
@@ -217,6 +229,7 @@ const char *gpsiq_variant_name(int v)
     case kAuto: return "auto";
     case kGeneric: return "generic";
     case kRows: return "rows";
+    case kRowsX: return "rowsx";
     default: return "?";
     }
 }
@@ -232,13 +245,13 @@ static int run_to_host_or_device(gpsiq_ctx *c, const std::vector<gpsiq_qchan_t> 
     if (rc) return rc;
     if (!nblocks || !nsamp) return GPSIQ_OK;
     if (dst_is_device && stride == blk_bytes) {
-        rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, dst, stride, nullptr, kAuto);
+        rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, dst, stride, c->stream, kAuto);
         if (rc) return rc;
-        return gpsiq_synchronize(c, nullptr);
+        return gpsiq_synchronize(c, c->stream);
     }
     rc = ensure_out(c, stride * (size_t) nblocks);
     if (rc) return rc;
-    rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, c->d_out, stride, nullptr, kAuto);
+    rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, c->d_out, stride, c->stream, kAuto);
     if (rc) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks,
                              dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));

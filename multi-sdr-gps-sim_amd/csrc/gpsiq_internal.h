@@ -20,6 +20,7 @@ enum Variant {
     kAuto = 0,      // fast when every resident descriptor allows it, else generic
     kGeneric = 1,   // one sample per thread, full-width closed form per sample (any rate)
     kRows = 2,      // 64-sample rows per wave, incremental NCOs, LDS-staged windows
+    kRowsX = 3,     // same rows, channel-inner loop order with all NCO state in registers
     kNumVariants
 };
 

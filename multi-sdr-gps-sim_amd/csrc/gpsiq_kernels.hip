@@ -241,13 +241,161 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rows(
 }
 
 // ---------------------------------------------------------------------------
+// Row kernel, channel-inner order ("rowsx").  Same rows/windows/NCO words as synth_rows,
+// but the loop nest is rows (outer) x channels (inner, fully unrolled over NCH slots):
+//   * the per-lane NCO state of ALL channels stays in registers for the whole tile, so
+//     the 64x32-bit start products are paid once per tile, not once per row group;
+//   * the LUT base of every channel is a compile-time LDS offset (no address add);
+//   * the NCH LUT gathers of a row are independent -> issued back to back, their LDS
+//     latency overlaps instead of being exposed once per row;
+//   * the NCH windows of a row are one contiguous 4*NCH-byte broadcast read.
+// Descriptors arrive compacted (active channels first, see gpsiq_set_descriptors), the
+// slots >= the block's active count are dummies: zero LUT, zero phase, zero step.
+template <int FMT, int NCH>
+__global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
+    const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
+    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block)
+{
+    __shared__ uint32_t lut[NCH][512];
+    __shared__ uint32_t ext[NCH][kPrnExtWords];
+    __shared__ uint32_t win[kWaves][kRowsPerWave][NCH];
+    __shared__ gpsiq_qchan_t qs[NCH];
+
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    const gpsiq_qchan_t *q_blk = desc + (size_t) (block0 + blk) * nchan;
+    const int nq = nchan < NCH ? nchan : NCH;
+    for (int i = tid; i < NCH * 12; i += kRowsThreads)
+        reinterpret_cast<uint32_t *>(qs)[i] = i < nq * 12 ? reinterpret_cast<const uint32_t *>(q_blk)[i] : 0u;
+    __syncthreads();
+    for (int e = tid; e < NCH * 512; e += kRowsThreads) {
+        const int c = e >> 9, k = e & 511;
+        uint32_t v = 0u;
+        if (qs[c].prn != 0) {
+            const double g = qs[c].gain;
+            const int ts = (int) ((double) dev_sin512(tab->quarter_wave, k) * g);
+            const int tc = (int) ((double) dev_sin512(tab->quarter_wave, k + 128) * g);
+            v = ((uint32_t) tc & 0xffffu) | ((uint32_t) ts << 16);
+        }
+        lut[c][k] = v;
+    }
+    for (int e = tid; e < NCH * kPrnExtWords; e += kRowsThreads) {
+        const int c = e / kPrnExtWords, w = e % kPrnExtWords;
+        ext[c][w] = qs[c].prn ? tab->prn_ext[qs[c].prn - 1][w] : 0u;
+    }
+    __syncthreads();
+    uint8_t *blk_dst = dst + (size_t) blk * block_stride;
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_wave = (uint32_t) tile * kRowsTile + (uint32_t) wave * (kRowsPerWave * 64);
+
+    // ---- windows: lane (c, g) prepares a run of consecutive rows of channel c ------
+    {
+        constexpr int kGroups = 64 / NCH;                   // lanes per channel
+        constexpr int kRun = kRowsPerWave / kGroups;        // rows per lane
+        static_assert(kRowsPerWave % kGroups == 0, "rows per wave must split over the lane groups");
+        const int c = lane % NCH, g = lane / NCH;
+        if (g < kGroups) {
+            const gpsiq_qchan_t &q = qs[c];
+            const bool on = q.prn != 0;
+            const uint32_t n_row = n_wave + (uint32_t) (g * kRun) * 64u;
+            const unsigned __int128 T = (unsigned __int128) q.code_frac +
+                                        (unsigned __int128) q.code_step * (unsigned __int128) n_row;
+            uint64_t A = (uint64_t) q.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+            uint64_t fr = (uint64_t) T & kCodeFracMask;
+            uint32_t k = (uint32_t) (A % GPSIQ_CA_SEQ_LEN);
+            const uint64_t ic = q.icode + A / GPSIQ_CA_SEQ_LEN;
+            uint32_t bit = (uint32_t) (ic / 20), icur = (uint32_t) (ic % 20);
+            uint32_t a5 = (uint32_t) A;
+            const uint64_t row_step = q.code_step * 64u;
+            const uint32_t d_int = (uint32_t) (row_step >> GPSIQ_CODE_FRAC_BITS);
+            const uint64_t d_fr = row_step & kCodeFracMask;
+            const uint32_t nav = q.nav_bits;
+#pragma unroll 4
+            for (int r = 0; r < kRun; ++r) {
+                const uint32_t lo = ext[c][k >> 5], hi = ext[c][(k >> 5) + 1];
+                uint32_t S = __builtin_amdgcn_alignbit(hi, lo, k & 31u);
+                const uint32_t to_wrap = GPSIQ_CA_SEQ_LEN - k;
+                const uint32_t next_mask = to_wrap < 32u ? (0xffffffffu << to_wrap) : 0u;
+                const uint32_t bit_next = icur == 19u ? bit + 1u : bit;
+                const uint32_t d0 = 0u - ((nav >> (bit & 31u)) & 1u);
+                const uint32_t d1 = 0u - ((nav >> (bit_next & 31u)) & 1u);
+                S ^= (d0 & ~next_mask) ^ (d1 & next_mask);
+                win[wave][g * kRun + r][c] = on ? __builtin_rotateleft32(S, a5 & 31u) : 0u;
+                fr += d_fr;
+                const uint32_t adv = d_int + (uint32_t) (fr >> GPSIQ_CODE_FRAC_BITS);
+                fr &= kCodeFracMask;
+                a5 += adv;
+                k += adv;
+                if (k >= GPSIQ_CA_SEQ_LEN) {
+                    k -= GPSIQ_CA_SEQ_LEN;
+                    if (++icur == 20u) { icur = 0u; ++bit; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane NCO state of every channel --------------------------------------
+    const uint32_t n0 = n_wave + (uint32_t) lane;
+    uint64_t P[NCH], Q[NCH], dP[NCH], dQ[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        // descriptor fields through scalar loads (uniform address, read-only global):
+        // the row steps must live in SGPRs, 4 per channel, or they cost 64 VGPRs
+        const bool have = c < nchan;
+        const uint64_t p0 = have ? q_blk[c].carr_phase : 0u, ps = have ? (uint64_t) q_blk[c].carr_step : 0u;
+        const uint64_t f0 = have ? q_blk[c].code_frac : 0u, cs = have ? q_blk[c].code_step : 0u;
+        const uint64_t c0 = have ? (uint64_t) q_blk[c].chip0 : 0u;
+        P[c] = p0 + ps * (uint64_t) n0;
+        Q[c] = (c0 << GPSIQ_CODE_FRAC_BITS) + f0 + cs * (uint64_t) n0;
+        dP[c] = ps * 64u;
+        dQ[c] = cs * 64u;
+    }
+
+    const unsigned char *lut_b = reinterpret_cast<const unsigned char *>(&lut[0][0]);
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        const uint32_t n = n0 + (uint32_t) r * 64u;
+        if (n_wave + (uint32_t) r * 64u >= (uint32_t) nsamp) break;     // wave-uniform
+        const uint32_t *w_row = win[wave][r];
+        s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t w = w_row[c];
+            const uint32_t b = (uint32_t) (Q[c] >> 56);
+            const uint32_t m = (uint32_t) __builtin_amdgcn_sbfe((int) w, b, 1u);
+            const uint32_t sgn = m | 0x00010001u;
+            const uint32_t a = (uint32_t) (P[c] >> 48) & 0x7fcu;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+            if (c & 1) acc1 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc1;
+            else       acc0 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc0;
+            P[c] += dP[c];
+            Q[c] += dQ[c];
+        }
+        if (n < (uint32_t) nsamp)
+            store_sample<FMT>(blk_dst, n, __builtin_bit_cast(uint32_t, acc0 + acc1));
+    }
+}
+
+// ---------------------------------------------------------------------------
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream)
+                          const DeviceTables *tab, hipStream_t stream, int max_active)
 {
     if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
     uint8_t *d = static_cast<uint8_t *>(dst);
-    if (variant == kRows) {
+    if (variant == kRowsX) {
+        const int tiles = (nsamp + kRowsTile - 1) / kRowsTile;
+        dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
+#define GPSIQ_LAUNCH_X(F, N) hipLaunchKernelGGL((synth_rowsx<F, N>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles)
+        const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : 16;
+        if (sample_size == GPSIQ_SC16) {
+            if (slots == 4) GPSIQ_LAUNCH_X(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_X(GPSIQ_SC16, 8); else GPSIQ_LAUNCH_X(GPSIQ_SC16, 16);
+        } else {
+            if (slots == 4) GPSIQ_LAUNCH_X(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_X(GPSIQ_SC08, 8); else GPSIQ_LAUNCH_X(GPSIQ_SC08, 16);
+        }
+#undef GPSIQ_LAUNCH_X
+    } else if (variant == kRows) {
         const int tiles = (nsamp + kRowsTile - 1) / kRowsTile;
         dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
         if (sample_size == GPSIQ_SC16)

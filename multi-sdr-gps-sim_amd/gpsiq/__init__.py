@@ -21,6 +21,28 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or make -C multi-sdr-gps-sim_amd/csrc); gpsiq has no non-HIP path")
 
+
+
+def _preload_shared_hip_runtime():
+    """PyTorch wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7) and load it by
+    file name, so a process that loaded /opt/rocm's copy first ends up with two HIP/HSA
+    runtimes and the second one to initialise sees no device.  When torch is installed,
+    load ITS runtime first (without importing torch) so libgpsiq.so binds to the same one."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+_preload_shared_hip_runtime()
 _lib = C.CDLL(LIB_PATH)
 
 
@@ -161,15 +183,15 @@ class Context:
 
     def launch(self, block0, nblocks, nsamp, sample_size, device_ptr, block_stride, stream=None, variant=0):
         _check(_launch(self._h, int(block0), int(nblocks), int(nsamp), int(sample_size), _vp(device_ptr),
-                       int(block_stride), _vp(stream) if stream else None, int(variant)))
+                       int(block_stride), _vp(stream or 0), int(variant)))
 
     def synchronize(self, stream=None):
-        _check(_synchronize(self._h, _vp(stream) if stream else None))
+        _check(_synchronize(self._h, _vp(stream or 0)))
 
     def time_launches(self, block0, nblocks, nsamp, sample_size, device_ptr, block_stride, iters,
                       stream=None, variant=0):
         ms = C.c_float(0.0)
         _check(_time_launches(self._h, int(block0), int(nblocks), int(nsamp), int(sample_size), _vp(device_ptr),
-                              int(block_stride), _vp(stream) if stream else None, int(variant), int(iters),
+                              int(block_stride), _vp(stream or 0), int(variant), int(iters),
                               C.byref(ms)))
         return ms.value

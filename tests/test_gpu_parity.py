@@ -12,7 +12,7 @@ from test_golden import CASES, load_case
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["generic", "rows"]
+VARIANTS = ["generic", "rows", "rowsx"]
 
 
 @pytest.fixture(scope="module")
@@ -222,12 +222,15 @@ def test_baseline_size_properties(ctx, oracle):
     a = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
     b_ = torch.empty(nb * stride, dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    ctx.launch(0, nb, ns, SC16, a.data_ptr(), stride, stream=s, variant=gpsiq.variants()["rows"])
+    ctx.launch(0, nb, ns, SC16, a.data_ptr(), stride, stream=s, variant=gpsiq.variants()["rowsx"])
     ctx.launch(0, nb, ns, SC16, b_.data_ptr(), stride, stream=s, variant=gpsiq.variants()["generic"])
     torch.cuda.synchronize()
     assert torch.equal(a, b_)
+    ctx.launch(0, nb, ns, SC16, b_.data_ptr(), stride, stream=s, variant=gpsiq.variants()["rows"])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b_)
     c = torch.empty(nb * 2 * ns, dtype=torch.uint8, device="cuda")
-    ctx.launch(0, nb, ns, SC08, c.data_ptr(), 2 * ns, stream=s, variant=gpsiq.variants()["rows"])
+    ctx.launch(0, nb, ns, SC08, c.data_ptr(), 2 * ns, stream=s, variant=gpsiq.variants()["rowsx"])
     torch.cuda.synchronize()
     assert torch.equal((a.view(torch.int16) >> 4).to(torch.int8), c.view(torch.int8))
     rng = np.random.default_rng(5)
@@ -239,9 +242,19 @@ def test_baseline_size_properties(ctx, oracle):
 
 
 def test_bad_arguments_are_errors(ctx):
+    import torch
     d = synth_blocks(1, 2, seed=81)
+    q, _ = gpsiq.quantize_blocks(d, 2.6e6, 100)
+    ctx.set_descriptors(q)
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     with pytest.raises(gpsiq.GpsiqError):
-        ctx.launch(0, 5, 100, SC16, 1 << 20, 400)        # nothing resident yet / out of range
+        ctx.launch(0, 5, 100, SC16, buf.data_ptr(), 400)      # only 1 block resident
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.launch(0, 1, 100, SC16, buf.data_ptr(), 396)      # stride smaller than a block
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.launch(0, 1, 100, SC16, 0, 400)                   # null destination
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.launch(0, 1, 100, SC16, buf.data_ptr(), 400, variant=99)
     bad = d.copy()
     bad["prn"][0, 0] = 40
     with pytest.raises(gpsiq.GpsiqError):
