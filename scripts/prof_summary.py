@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (rocpd sqlite) outputs under gpurun_out/prof into profiles/<tag>_*.txt."""
+import glob
+import os
+import sqlite3
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+os.makedirs("profiles", exist_ok=True)
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+lines = []
+for db in sorted(glob.glob(os.path.join(src, "kt*", "*.db"))):
+    lines.append(f"== rocprofv3 --kernel-trace --stats ({db}) ==")
+    lines.append(f"{'kernel':<70} {'calls':>6} {'total_ns':>14} {'avg_ns':>14} {'pct':>7}")
+    for name, calls, tot, avg, pct in q(db, "select name,total_calls,total_duration,average,percentage from top_kernels"):
+        lines.append(f"{name[:70]:<70} {calls:>6} {tot:>14.0f} {avg:>14.1f} {pct:>7.2f}")
+    lines.append("per dispatch: kernel, grid, wg, vgpr, sgpr, lds, duration_ns")
+    for r in q(db, "select name,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,duration from kernels order by start"):
+        lines.append("  " + " ".join(str(x)[:60] for x in r))
+open(f"profiles/{tag}_kernel_trace_stats.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+
+lines = []
+for db in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
+    lines.append(f"== rocprofv3 --pmc ({db}) ==")
+    rows = q(db, "select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(duration) "
+                 "from counters_collection group by kernel_name, counter_name order by kernel_name, counter_name")
+    lines.append(f"{'kernel':<50} {'counter':<24} {'n':>3} {'avg':>18} {'min':>18} {'max':>18} {'avg_dur_ns':>12}")
+    for k, c, n, a, mn, mx, d in rows:
+        lines.append(f"{k[:50]:<50} {c:<24} {n:>3} {a:>18.1f} {mn:>18.1f} {mx:>18.1f} {d:>12.0f}")
+open(f"profiles/{tag}_pmc_counters.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
