@@ -101,11 +101,12 @@ def main():
     # one global timeline of world*nblocks blocks; this rank's shard is [rank*nblocks, ...)
     # Descriptors: distinct code/Doppler state per block for a short pattern, tiled over
     # the timeline (host generation cost only), then quantised with the exact carrier prefix.
+    from gpsiq.shard import max_over_ranks, shard_descriptors
     pattern = synth_blocks(min(64, nblocks), nchan, seed=args.seed)
     reps = -(-nblocks * world // len(pattern))
     desc_all = np.concatenate([pattern] * reps)[: nblocks * world]
-    q_all, _ = gpsiq.quantize_blocks(desc_all, fs, nsamp)
-    q = q_all[rank * nblocks:(rank + 1) * nblocks]
+    q, (b0, b1) = shard_descriptors(desc_all, fs, nsamp, rank, world)
+    assert b1 - b0 == nblocks
 
     ctx = gpsiq.Context(local_rank)
     ctx.set_descriptors(q)
@@ -135,11 +136,7 @@ def main():
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([t_local], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-    else:
-        t_max = t_local
+    t_max = max_over_ranks(t_local, dist, device="cuda")
     launch_ms = e0.elapsed_time(e1) / args.steps       # HIP events on the launch stream
 
     if args.sweep and rank == 0:

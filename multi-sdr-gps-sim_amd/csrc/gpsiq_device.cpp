@@ -69,7 +69,7 @@ static int ensure_out(gpsiq_ctx *c, size_t bytes)
 static int pick_variant(const gpsiq_ctx *c, int variant)
 {
     if (variant == kAuto)
-        return c->max_code_step <= kRowsMaxCodeStep ? kRowsX : kGeneric;
+        return c->max_code_step <= kRowsMaxCodeStep ? kTile : kGeneric;
     return variant;
 }
 
@@ -85,7 +85,7 @@ static int check_launch(const gpsiq_ctx *c, int block0, int nblocks, int nsamp, 
     if (stride < (size_t) 2 * (size_t) nsamp * (size_t) sample_size || (stride & 3))
         return fail(GPSIQ_E_ARG, "block stride %zu too small or not a multiple of 4", stride);
     if (variant < 0 || variant >= kNumVariants) return fail(GPSIQ_E_ARG, "unknown variant %d", variant);
-    if ((variant == kRows || variant == kRowsX) && c->max_code_step > kRowsMaxCodeStep)
+    if (variant >= kRows && c->max_code_step > kRowsMaxCodeStep)
         return fail(GPSIQ_E_RANGE, "row kernel needs f_code/fs <= 31/63 chip per sample");
     return GPSIQ_OK;
 }
@@ -230,6 +230,8 @@ const char *gpsiq_variant_name(int v)
     case kGeneric: return "generic";
     case kRows: return "rows";
     case kRowsX: return "rowsx";
+    case kTile: return "tile";
+    case kTile32: return "tile32";
     default: return "?";
     }
 }

@@ -378,13 +378,181 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
 }
 
 // ---------------------------------------------------------------------------
+// Tile kernel ("tile"): the row kernel in channel-inner order with the per-tile overhead
+// trimmed, because the path is VALU-issue bound (profiles/r01_pmc_counters.txt: 9.7 VALU
+// instructions per (channel,row) against 7 in the core):
+//   * ROWS rows per wave (64 by default -> 32768-sample tiles): LUT build, NCO start
+//     products and the window set-up are amortised over twice the rows;
+//   * LUT build: thread k owns LUT entry k of every channel, so sin/cos of k are formed
+//     once and each entry costs two f64 multiplies and two truncations;
+//   * window set-up in 32-bit chip arithmetic (a block never advances 2^32 chips);
+//   * a wave whose rows all lie inside the block runs a check-free row loop.
+template <int FMT, int NCH, int ROWS>
+__global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
+    const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
+    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block)
+{
+    constexpr int kTileSamples = kWaves * ROWS * 64;
+    __shared__ uint32_t lut[NCH][512];
+    __shared__ uint32_t ext[NCH][kPrnExtWords];
+    __shared__ uint32_t win[kWaves][ROWS][NCH];
+    __shared__ gpsiq_qchan_t qs[NCH];
+
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    const gpsiq_qchan_t *q_blk = desc + (size_t) (block0 + blk) * nchan;
+    const int nq = nchan < NCH ? nchan : NCH;
+    for (int i = tid; i < NCH * 12; i += kRowsThreads)
+        reinterpret_cast<uint32_t *>(qs)[i] = i < nq * 12 ? reinterpret_cast<const uint32_t *>(q_blk)[i] : 0u;
+    __syncthreads();
+    {
+        // entry k = tid of every channel; unused slots have gain 0.0 -> entry 0
+        const double sk = (double) dev_sin512(tab->quarter_wave, tid);
+        const double ck = (double) dev_sin512(tab->quarter_wave, tid + 128);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const double g = qs[c].gain;
+            const int ts = (int) (sk * g), tc = (int) (ck * g);   // gps.c:2781-2782
+            lut[c][tid] = ((uint32_t) tc & 0xffffu) | ((uint32_t) ts << 16);
+        }
+    }
+    for (int e = tid; e < NCH * kPrnExtWords; e += kRowsThreads) {
+        const int c = e / kPrnExtWords, w = e % kPrnExtWords;
+        ext[c][w] = qs[c].prn ? tab->prn_ext[qs[c].prn - 1][w] : 0u;
+    }
+    __syncthreads();
+    uint8_t *blk_dst = dst + (size_t) blk * block_stride;
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_wave = (uint32_t) tile * kTileSamples + (uint32_t) wave * (ROWS * 64);
+    if (n_wave >= (uint32_t) nsamp) return;             // whole wave past the block end
+
+    // ---- windows: lane (c, g) prepares a run of consecutive rows of channel c ------
+    {
+        constexpr int kPad = NCH <= 4 ? 4 : NCH <= 8 ? 8 : 16;   // lanes per row group
+        constexpr int kGroups = 64 / kPad;
+        constexpr int kRun = ROWS / kGroups;
+        static_assert(ROWS % kGroups == 0, "rows per wave must split over the lane groups");
+        const int c_raw = lane % kPad, g = lane / kPad;
+        const int c = c_raw < NCH ? c_raw : 0;               // surplus lanes recompute channel 0
+        const gpsiq_qchan_t &q = qs[c];
+        const uint32_t on = (q.prn != 0 && c_raw < NCH) ? 0xffffffffu : 0u;
+        const uint32_t n_row = n_wave + (uint32_t) (g * kRun) * 64u;
+        const unsigned __int128 T = (unsigned __int128) q.code_frac +
+                                    (unsigned __int128) q.code_step * (unsigned __int128) n_row;
+        const uint32_t A = (uint32_t) q.chip0 + (uint32_t) (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+        uint64_t fr = (uint64_t) T & kCodeFracMask;
+        uint32_t k = A % GPSIQ_CA_SEQ_LEN;                       // chip inside the period
+        const uint32_t ic = q.icode + A / GPSIQ_CA_SEQ_LEN;
+        uint32_t icur = ic % 20u;
+        uint32_t navw = q.nav_bits >> ((ic / 20u) & 31u);        // bit 0 = current nav bit
+        uint32_t rot = A;                                        // only A mod 32 matters
+        const uint64_t row_step = q.code_step * 64u;
+        const uint32_t d_int = (uint32_t) (row_step >> GPSIQ_CODE_FRAC_BITS);
+        const uint64_t d_fr = row_step & kCodeFracMask;
+        uint32_t *wdst = &win[wave][g * kRun][c];
+#pragma unroll 4
+        for (int r = 0; r < kRun; ++r) {
+            const uint32_t lo = ext[c][k >> 5], hi = ext[c][(k >> 5) + 1];
+            uint32_t S = __builtin_amdgcn_alignbit(hi, lo, k);   // 32 chips from chip k (shift uses k & 31)
+            const uint32_t d0 = 0u - (navw & 1u);
+            // window positions >= 1023-k are the next period; its nav bit differs only
+            // when this is the 20th period of the bit
+            const uint32_t to_wrap = GPSIQ_CA_SEQ_LEN - k;
+            uint32_t flip = 0u;
+            if (icur == 19u && to_wrap < 32u)
+                flip = ((navw ^ (navw >> 1)) & 1u) ? (0xffffffffu << to_wrap) : 0u;
+            S ^= d0 ^ flip;
+            if (c_raw < NCH) wdst[r * NCH] = __builtin_rotateleft32(S, rot & 31u) & on;
+            fr += d_fr;
+            const uint32_t adv = d_int + (uint32_t) (fr >> GPSIQ_CODE_FRAC_BITS);
+            fr &= kCodeFracMask;
+            rot += adv;
+            k += adv;
+            if (k >= GPSIQ_CA_SEQ_LEN) {
+                k -= GPSIQ_CA_SEQ_LEN;
+                if (++icur == 20u) { icur = 0u; navw >>= 1; }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- per-lane NCO state of every channel (steps in SGPRs via scalar loads) -----
+    const uint32_t n0 = n_wave + (uint32_t) lane;
+    uint64_t P[NCH], Q[NCH], dP[NCH], dQ[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool have = c < nchan;
+        const uint64_t p0 = have ? q_blk[c].carr_phase : 0u, ps = have ? (uint64_t) q_blk[c].carr_step : 0u;
+        const uint64_t f0 = have ? q_blk[c].code_frac : 0u, cs = have ? q_blk[c].code_step : 0u;
+        const uint64_t c0 = have ? (uint64_t) q_blk[c].chip0 : 0u;
+        P[c] = p0 + ps * (uint64_t) n0;
+        Q[c] = (c0 << GPSIQ_CODE_FRAC_BITS) + f0 + cs * (uint64_t) n0;
+        dP[c] = ps * 64u;
+        dQ[c] = cs * 64u;
+    }
+
+    const unsigned char *lut_b = reinterpret_cast<const unsigned char *>(&lut[0][0]);
+    const uint32_t *w_row = &win[wave][0][0];
+    const bool full = n_wave + (uint32_t) (ROWS * 64) <= (uint32_t) nsamp;   // wave-uniform
+    const int rows = full ? ROWS : (int) (((uint32_t) nsamp - n_wave + 63u) >> 6);
+
+    auto row_body = [&](int r, bool check) {
+        s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t w = w_row[r * NCH + c];
+            const uint32_t b = (uint32_t) (Q[c] >> 56);
+            const uint32_t m = (uint32_t) __builtin_amdgcn_sbfe((int) w, b, 1u);
+            const uint32_t sgn = m | 0x00010001u;
+            const uint32_t a = (uint32_t) (P[c] >> 48) & 0x7fcu;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+            if (c & 1) acc1 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc1;
+            else       acc0 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc0;
+            P[c] += dP[c];
+            Q[c] += dQ[c];
+        }
+        const uint32_t n = n0 + (uint32_t) r * 64u;
+        if (!check || n < (uint32_t) nsamp)
+            store_sample<FMT>(blk_dst, n, __builtin_bit_cast(uint32_t, acc0 + acc1));
+    };
+
+    if (full) {
+#pragma unroll 1
+        for (int r = 0; r < ROWS; ++r) row_body(r, false);
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < rows; ++r) row_body(r, true);
+    }
+}
+
+// ---------------------------------------------------------------------------
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
                           const DeviceTables *tab, hipStream_t stream, int max_active)
 {
     if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
     uint8_t *d = static_cast<uint8_t *>(dst);
-    if (variant == kRowsX) {
+    if (variant == kTile || variant == kTile32) {
+        const int rows = variant == kTile ? 64 : 32;
+        const int tile_samples = kWaves * rows * 64;
+        const int tiles = (nsamp + tile_samples - 1) / tile_samples;
+        dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
+#define GPSIQ_LAUNCH_T(F, N, R) hipLaunchKernelGGL((synth_tile<F, N, R>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles)
+#define GPSIQ_LAUNCH_TR(F, N) do { if (rows == 64) GPSIQ_LAUNCH_T(F, N, 64); else GPSIQ_LAUNCH_T(F, N, 32); } while (0)
+        const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
+        if (sample_size == GPSIQ_SC16) {
+            if (slots == 4) GPSIQ_LAUNCH_TR(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_TR(GPSIQ_SC16, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_TR(GPSIQ_SC16, 12); else GPSIQ_LAUNCH_TR(GPSIQ_SC16, 16);
+        } else {
+            if (slots == 4) GPSIQ_LAUNCH_TR(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_TR(GPSIQ_SC08, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_TR(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_TR(GPSIQ_SC08, 16);
+        }
+#undef GPSIQ_LAUNCH_TR
+#undef GPSIQ_LAUNCH_T
+    } else if (variant == kRowsX) {
         const int tiles = (nsamp + kRowsTile - 1) / kRowsTile;
         dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
 #define GPSIQ_LAUNCH_X(F, N) hipLaunchKernelGGL((synth_rowsx<F, N>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles)

@@ -1,0 +1,167 @@
+"""Host half of libgpsiq (no GPU): tables, quantiser, fifo hand-off rules — against the
+oracle and the committed reference captures."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import gpsiq
+from gpsiq.abi import CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE, SINK_PLUTOSDR
+from gpsiq.scenario import synth_blocks
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_tables_equal_oracle_and_golden(oracle):
+    cos, sin = gpsiq.carrier_table()
+    s, c = oracle.tables()
+    assert (cos == c).all() and (sin == s).all()
+    z = np.load(os.path.join(GOLD, "tables.npz"))
+    assert (sin == z["sin512"]).all() and (cos == z["cos512"]).all()
+    for prn in range(1, 33):
+        ca = gpsiq.prn_code(prn)
+        assert (ca == oracle.codegen(prn)).all()
+        assert (np.packbits(ca, bitorder="little") == z["prn_packed"][prn - 1]).all()
+    for bad in (0, 33, -1):
+        with pytest.raises(gpsiq.GpsiqError):
+            gpsiq.prn_code(bad)
+
+
+@pytest.mark.parametrize("fs", [2.6e6, 3e6, 1e7, 2.5e7, 1.5e6])
+def test_quantiser_equals_oracle(oracle, fs):
+    d = synth_blocks(6, 16, seed=int(fs) % 1000)
+    d["prn"][2:4, 3] = 0
+    d["prn"][4:, 3] = 17
+    ns = int(fs) // 10
+    q, carry = gpsiq.quantize_blocks(d, fs, ns)
+    assert q.tobytes() == oracle.quantize_blocks(d, fs, ns).tobytes()
+    # exact carry: block k+1 starts where block k ended, modulo 2^59
+    for b in range(1, 6):
+        for c in range(16):
+            if d[b, c]["prn"] > 0 and d[b, c]["prn"] == d[b - 1, c]["prn"]:
+                want = (int(q[b - 1, c]["carr_phase"]) + int(q[b - 1, c]["carr_step"]) * ns) % (1 << 59)
+                assert int(q[b, c]["carr_phase"]) == want
+
+
+def test_quantiser_definition():
+    """The rules of include/gpsiq.h spelled out with Python integers/Fractions."""
+    from fractions import Fraction
+    d = synth_blocks(1, 5, seed=9)[0]
+    fs, ns = 2.6e6, 260000
+    q, carry = gpsiq.quantize(d, fs, ns)
+    delt = 1.0 / fs
+    for c in range(5):
+        assert int(q[c]["carr_step"]) == round(Fraction(float(d[c]["f_carr"]) * delt) * 2 ** 59)
+        assert int(q[c]["code_step"]) == round(Fraction(float(d[c]["f_code"]) * delt) * 2 ** 56)
+        assert int(q[c]["carr_phase"]) == int(Fraction(float(d[c]["carr_phase"])) * 2 ** 59)
+        chip0 = int(d[c]["code_phase"])
+        assert int(q[c]["chip0"]) == chip0
+        assert int(q[c]["code_frac"]) == int((Fraction(float(d[c]["code_phase"])) - chip0) * 2 ** 56)
+        bits = []
+        w, b = int(d[c]["iword"]), int(d[c]["ibit"])
+        for _ in range(8):
+            bits.append((int(d[c]["dwrd"][w]) >> (29 - b)) & 1)
+            b += 1
+            if b == 30:
+                b, w = 0, w + 1
+        nb = (int(d[c]["icode"]) + (chip0 + ((int(q[c]["code_frac"]) + (ns - 1) * int(q[c]["code_step"])) >> 56)) // 1023) // 20 + 1
+        assert int(q[c]["nav_bits"]) == sum(bit << i for i, bit in enumerate(bits[:nb]))
+        assert int(carry[c]) == (int(q[c]["carr_phase"]) + ns * int(q[c]["carr_step"])) % (1 << 59)
+
+
+@pytest.mark.parametrize("field,value", [("prn", 33), ("code_phase", 1023.0), ("code_phase", -0.5), ("carr_phase", 1.0),
+                                         ("carr_phase", -0.1), ("iword", 60), ("ibit", 30), ("icode", 20),
+                                         ("f_carr", 2.0e6), ("f_code", 6.0e6), ("f_code", 0.0), ("f_carr", float("nan"))])
+def test_quantiser_rejects_out_of_range(field, value):
+    d = synth_blocks(1, 3, seed=2)[0]
+    d[field][1] = value
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.quantize(d, 2.6e6, 1000)
+
+
+def test_quantiser_rejects_running_off_the_word_buffer():
+    d = synth_blocks(1, 1, seed=3)[0]
+    d["iword"], d["ibit"], d["icode"] = 59, 29, 19      # the block needs dwrd[60]
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.quantize(d, 2.6e6, 260000)
+    with pytest.raises(gpsiq.GpsiqError):                # more than 32 nav bits in one block
+        gpsiq.quantize(synth_blocks(1, 1, seed=4)[0], 2.6e6, 2600000)
+
+
+# ---- fifo hand-off (gps.c:2839-2865) --------------------------------------------
+class IqBuf(C.Structure):
+    pass
+
+
+IqBuf._fields_ = [("data8", C.c_void_p), ("data16", C.c_void_p), ("totalLength", C.c_uint),
+                  ("validLength", C.c_uint), ("next", C.POINTER(IqBuf))]
+ACQ = C.CFUNCTYPE(C.c_void_p, C.c_void_p)
+ENQ = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(IqBuf))
+
+
+class Chunker(C.Structure):
+    _fields_ = [("acquire", ACQ), ("enqueue", ENQ), ("user", C.c_void_p), ("cur", C.POINTER(IqBuf)),
+                ("sink_kind", C.c_int), ("sample_size", C.c_int)]
+
+
+def run_chunker(sink, ss, blocks, buf_len):
+    lib = C.CDLL(gpsiq.LIB_PATH)
+    dt = np.int8 if ss == SC08 else np.int16
+    pool, enq = [], []
+
+    def acquire(_):
+        arr = np.zeros(buf_len, dtype=dt)
+        b = IqBuf()
+        if ss == SC08:
+            b.data8 = arr.ctypes.data
+        else:
+            b.data16 = arr.ctypes.data
+        b.totalLength, b.validLength = buf_len, 0
+        pool.append((b, arr))
+        return C.addressof(b)
+
+    def enqueue(_, p):
+        for b, arr in pool:
+            if C.addressof(b) == C.addressof(p.contents):
+                enq.append(arr[: b.validLength].copy())
+                return
+        raise AssertionError("unknown buffer")
+
+    ck = Chunker()
+    a, e = ACQ(acquire), ENQ(enqueue)
+    lib.gpsiq_chunker_init.argtypes = [C.c_void_p, C.c_int, C.c_int, ACQ, ENQ, C.c_void_p]
+    lib.gpsiq_chunker_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    assert lib.gpsiq_chunker_init(C.byref(ck), sink, ss, a, e, None) == 0
+    total = 0
+    for blk in blocks:
+        n = lib.gpsiq_chunker_push(C.byref(ck), blk.ctypes.data, blk.size)
+        assert n >= 0, gpsiq._last_error()
+        total += n
+    assert total == len(enq)
+    return enq
+
+
+@pytest.mark.parametrize("sink", [SINK_IQFILE, SINK_HACKRF, SINK_PLUTOSDR])
+@pytest.mark.parametrize("ss", [SC08, SC16])
+def test_chunker_follows_reference_rules(oracle, sink, ss):
+    rng = np.random.default_rng(1)
+    nelem, nb = 600000, 3
+    dt = np.int8 if ss == SC08 else np.int16
+    blocks = [rng.integers(-100, 100, size=nelem).astype(dt) for _ in range(nb)]
+    buf_len = 262144 if sink == SINK_HACKRF else nelem          # sdr_hackrf.c:215 / sdr_iqfile.c:59
+    enq = run_chunker(sink, ss, blocks, buf_len)
+    plan = oracle.chunk_plan(sink, nelem, nb)
+    assert [len(x) for x in enq] == list(plan)
+    flat = np.concatenate(blocks)
+    assert np.array_equal(np.concatenate(enq), flat[: plan.sum()])
+
+
+def test_chunker_matches_reference_capture():
+    z = np.load(os.path.join(GOLD, "hackrf_chunks.npz"))
+    rng = np.random.default_rng(2)
+    nb, nelem = z["desc"].shape[0], 2 * int(z["nsamp"])
+    blocks = [rng.integers(-100, 100, size=nelem).astype(np.int8) for _ in range(nb)]
+    enq = run_chunker(SINK_HACKRF, SC08, blocks, 262144)
+    assert [len(x) for x in enq] == list(z["chunk_len"])
