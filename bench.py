@@ -151,6 +151,19 @@ def main():
             except gpsiq.GpsiqError as e:
                 print(f"[sweep] variant {name}: {e}", file=sys.stderr)
 
+    if args.sweep and rank == 0:
+        # the drop-in path with HOST destination buffers (gpsiq_generate_batch: quantise,
+        # H2D descriptors, kernel, D2H samples): PCIe-bound, reported separately, never `value`
+        nb_h = min(256, nblocks)
+        pinned = torch.empty(nb_h * blk_bytes, dtype=torch.uint8).pin_memory()
+        ctx.generate_batch(desc_all[:nb_h], nsamp, fs, ss, host_ptr=pinned.data_ptr())
+        t1 = time.perf_counter()
+        ctx.generate_batch(desc_all[:nb_h], nsamp, fs, ss, host_ptr=pinned.data_ptr())
+        dt = time.perf_counter() - t1
+        print(f"[host-dst] gpsiq_generate_batch -> pinned host memory: {nb_h} blocks in {dt * 1e3:.1f} ms = "
+              f"{nb_h * nsamp / dt / 1e6:.0f} Msamples/s, {nb_h * blk_bytes / dt / 1e9:.1f} GB/s over PCIe", file=sys.stderr)
+        ctx.set_descriptors(q)
+
     if rank == 0:
         samples_step = nblocks * nsamp * world
         value = samples_step * args.steps / t_max / 1e6
@@ -177,6 +190,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+            # informational: the limiter actually hit.  The row-kernel core is
+            # 5 four-cycle + 2 two-cycle VALU instructions per (channel, 64-sample row) per SIMD
+            # (profiles/r01_ubench_valu_encodings.txt) = 26.5 issue cycles; peak = every SIMD of
+            # 256 CUs issuing only that core at the 2.4 GHz maximum clock.
+            "issue_roofline": {"bound": "valu-issue", "unit": "Gchannel-samples/s",
+                               "achieved": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / 1e9, 1),
+                               "peak": round(256 * 4 * 64 * 2.4e9 / 26.5 / 1e9, 1),
+                               "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / 26.5), 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc_all, fs, nsamp, ss, min(args.cpu_blocks, nblocks))

@@ -69,7 +69,7 @@ static int ensure_out(gpsiq_ctx *c, size_t bytes)
 static int pick_variant(const gpsiq_ctx *c, int variant)
 {
     if (variant == kAuto)
-        return c->max_code_step <= kRowsMaxCodeStep ? kTile : kGeneric;
+        return c->max_code_step <= kRowsMaxCodeStep ? kSeg : kGeneric;
     return variant;
 }
 
@@ -231,7 +231,7 @@ const char *gpsiq_variant_name(int v)
     case kRows: return "rows";
     case kRowsX: return "rowsx";
     case kTile: return "tile";
-    case kTile32: return "tile32";
+    case kSeg: return "seg";
     default: return "?";
     }
 }

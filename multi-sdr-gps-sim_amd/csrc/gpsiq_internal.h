@@ -22,7 +22,7 @@ enum Variant {
     kRows = 2,      // 64-sample rows per wave, incremental NCOs, LDS-staged windows
     kRowsX = 3,     // same rows, channel-inner loop order with all NCO state in registers
     kTile = 4,      // rowsx with trimmed per-tile overhead, 64 rows per wave (32768-sample tiles)
-    kTile32 = 5,    // the same with 32 rows per wave (16384-sample tiles, more workgroups)
+    kSeg = 5,       // tile kernel, each wave running several consecutive 64-row chunks
     kNumVariants
 };
 

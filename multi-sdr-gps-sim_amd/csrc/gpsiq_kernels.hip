@@ -378,21 +378,24 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
 }
 
 // ---------------------------------------------------------------------------
-// Tile kernel ("tile"): the row kernel in channel-inner order with the per-tile overhead
-// trimmed, because the path is VALU-issue bound (profiles/r01_pmc_counters.txt: 9.7 VALU
-// instructions per (channel,row) against 7 in the core):
-//   * ROWS rows per wave (64 by default -> 32768-sample tiles): LUT build, NCO start
-//     products and the window set-up are amortised over twice the rows;
+// Tile kernel ("tile"/"seg"): the row kernel in channel-inner order with the per-tile
+// overhead trimmed, because the path is VALU-issue bound (profiles/r01_pmc_counters.txt:
+// 9.7 VALU instructions per (channel,row) against 7 in the core):
+//   * a wave owns `chunks` consecutive chunks of ROWS rows (a contiguous run of samples):
+//     the per-lane NCO words and the window-builder state simply continue from chunk to
+//     chunk, so the start products, the mod-1023 / mod-20 set-up and the LUT build are
+//     paid once per workgroup, not once per 64 rows ("seg": chunks > 1, one workgroup
+//     per block at 2.6 Msps; "tile": chunks = 1 for small launches);
 //   * LUT build: thread k owns LUT entry k of every channel, so sin/cos of k are formed
 //     once and each entry costs two f64 multiplies and two truncations;
 //   * window set-up in 32-bit chip arithmetic (a block never advances 2^32 chips);
-//   * a wave whose rows all lie inside the block runs a check-free row loop.
+//   * a chunk whose rows all lie inside the block runs a check-free row loop.
 template <int FMT, int NCH, int ROWS>
 __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
-    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block)
+    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block,
+    int chunks)
 {
-    constexpr int kTileSamples = kWaves * ROWS * 64;
     __shared__ uint32_t lut[NCH][512];
     __shared__ uint32_t ext[NCH][kPrnExtWords];
     __shared__ uint32_t win[kWaves][ROWS][NCH];
@@ -424,60 +427,38 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     uint8_t *blk_dst = dst + (size_t) blk * block_stride;
 
     const int wave = tid >> 6, lane = tid & 63;
-    const uint32_t n_wave = (uint32_t) tile * kTileSamples + (uint32_t) wave * (ROWS * 64);
+    const uint32_t wave_samples = (uint32_t) chunks * (ROWS * 64);
+    const uint32_t n_wave = ((uint32_t) tile * kWaves + (uint32_t) wave) * wave_samples;
     if (n_wave >= (uint32_t) nsamp) return;             // whole wave past the block end
 
-    // ---- windows: lane (c, g) prepares a run of consecutive rows of channel c ------
+    // ---- window builder: lane (c, g) prepares rows g, g+G, g+2G, ... of channel c ----
+    constexpr int kPad = NCH <= 4 ? 4 : NCH <= 8 ? 8 : 16;   // lanes per row group
+    constexpr int kGroups = 64 / kPad;
+    constexpr int kRun = ROWS / kGroups;
+    static_assert(ROWS % kGroups == 0, "rows per chunk must split over the lane groups");
+    const int c_raw = lane % kPad, wg = lane / kPad;
+    const int wc = c_raw < NCH ? c_raw : 0;                  // surplus lanes shadow channel 0
+    const bool w_store = c_raw < NCH;
+    uint32_t w_on, w_k, w_icur, w_navw, w_rot, w_dint;
+    uint64_t w_fr, w_dfr;
     {
-        constexpr int kPad = NCH <= 4 ? 4 : NCH <= 8 ? 8 : 16;   // lanes per row group
-        constexpr int kGroups = 64 / kPad;
-        constexpr int kRun = ROWS / kGroups;
-        static_assert(ROWS % kGroups == 0, "rows per wave must split over the lane groups");
-        const int c_raw = lane % kPad, g = lane / kPad;
-        const int c = c_raw < NCH ? c_raw : 0;               // surplus lanes recompute channel 0
-        const gpsiq_qchan_t &q = qs[c];
-        const uint32_t on = (q.prn != 0 && c_raw < NCH) ? 0xffffffffu : 0u;
-        const uint32_t n_row = n_wave + (uint32_t) (g * kRun) * 64u;
+        const gpsiq_qchan_t &q = qs[wc];
+        w_on = q.prn != 0 ? 0xffffffffu : 0u;
+        const uint32_t n_row = n_wave + (uint32_t) wg * 64u;
         const unsigned __int128 T = (unsigned __int128) q.code_frac +
                                     (unsigned __int128) q.code_step * (unsigned __int128) n_row;
         const uint32_t A = (uint32_t) q.chip0 + (uint32_t) (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
-        uint64_t fr = (uint64_t) T & kCodeFracMask;
-        uint32_t k = A % GPSIQ_CA_SEQ_LEN;                       // chip inside the period
+        w_fr = (uint64_t) T & kCodeFracMask;
+        w_k = A % GPSIQ_CA_SEQ_LEN;                              // chip inside the period
         const uint32_t ic = q.icode + A / GPSIQ_CA_SEQ_LEN;
-        uint32_t icur = ic % 20u;
-        uint32_t navw = q.nav_bits >> ((ic / 20u) & 31u);        // bit 0 = current nav bit
-        uint32_t rot = A;                                        // only A mod 32 matters
-        const uint64_t row_step = q.code_step * 64u;
-        const uint32_t d_int = (uint32_t) (row_step >> GPSIQ_CODE_FRAC_BITS);
-        const uint64_t d_fr = row_step & kCodeFracMask;
-        uint32_t *wdst = &win[wave][g * kRun][c];
-#pragma unroll 4
-        for (int r = 0; r < kRun; ++r) {
-            const uint32_t lo = ext[c][k >> 5], hi = ext[c][(k >> 5) + 1];
-            uint32_t S = __builtin_amdgcn_alignbit(hi, lo, k);   // 32 chips from chip k (shift uses k & 31)
-            const uint32_t d0 = 0u - (navw & 1u);
-            // window positions >= 1023-k are the next period; its nav bit differs only
-            // when this is the 20th period of the bit
-            const uint32_t to_wrap = GPSIQ_CA_SEQ_LEN - k;
-            uint32_t flip = 0u;
-            if (icur == 19u && to_wrap < 32u)
-                flip = ((navw ^ (navw >> 1)) & 1u) ? (0xffffffffu << to_wrap) : 0u;
-            S ^= d0 ^ flip;
-            if (c_raw < NCH) wdst[r * NCH] = __builtin_rotateleft32(S, rot & 31u) & on;
-            fr += d_fr;
-            const uint32_t adv = d_int + (uint32_t) (fr >> GPSIQ_CODE_FRAC_BITS);
-            fr &= kCodeFracMask;
-            rot += adv;
-            k += adv;
-            if (k >= GPSIQ_CA_SEQ_LEN) {
-                k -= GPSIQ_CA_SEQ_LEN;
-                if (++icur == 20u) { icur = 0u; navw >>= 1; }
-            }
-        }
+        w_icur = ic % 20u;
+        w_navw = q.nav_bits >> ((ic / 20u) & 31u);               // bit 0 = current nav bit
+        w_rot = A;                                               // only A mod 32 matters
+        // chips per builder step: 64*kGroups samples (<= 1024 * 0.5 chips: one period wrap at most)
+        const unsigned __int128 step = (unsigned __int128) q.code_step * (unsigned) (64 * kGroups);
+        w_dint = (uint32_t) (uint64_t) (step >> GPSIQ_CODE_FRAC_BITS);
+        w_dfr = (uint64_t) step & kCodeFracMask;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // ---- per-lane NCO state of every channel (steps in SGPRs via scalar loads) -----
     const uint32_t n0 = n_wave + (uint32_t) lane;
@@ -496,10 +477,9 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
 
     const unsigned char *lut_b = reinterpret_cast<const unsigned char *>(&lut[0][0]);
     const uint32_t *w_row = &win[wave][0][0];
-    const bool full = n_wave + (uint32_t) (ROWS * 64) <= (uint32_t) nsamp;   // wave-uniform
-    const int rows = full ? ROWS : (int) (((uint32_t) nsamp - n_wave + 63u) >> 6);
+    uint32_t *w_dst = &win[wave][wg][wc];
 
-    auto row_body = [&](int r, bool check) {
+    auto row_body = [&](int r, uint32_t n_chunk, bool check) {
         s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -514,17 +494,54 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
             P[c] += dP[c];
             Q[c] += dQ[c];
         }
-        const uint32_t n = n0 + (uint32_t) r * 64u;
+        const uint32_t n = n_chunk + (uint32_t) lane + (uint32_t) r * 64u;
         if (!check || n < (uint32_t) nsamp)
             store_sample<FMT>(blk_dst, n, __builtin_bit_cast(uint32_t, acc0 + acc1));
     };
 
-    if (full) {
+    for (int ch = 0; ch < chunks; ++ch) {
+        const uint32_t n_chunk = n_wave + (uint32_t) ch * (ROWS * 64);
+        if (n_chunk >= (uint32_t) nsamp) break;          // wave-uniform
+        // windows of this chunk (the builder state carries over from the previous chunk)
+#pragma unroll 4
+        for (int i = 0; i < kRun; ++i) {
+            const uint32_t lo = ext[wc][w_k >> 5], hi = ext[wc][(w_k >> 5) + 1];
+            uint32_t S = __builtin_amdgcn_alignbit(hi, lo, w_k);   // 32 chips from chip k (shift uses k & 31)
+            const uint32_t d0 = 0u - (w_navw & 1u);
+            // window positions >= 1023-k are the next period; its nav bit differs only
+            // when this is the 20th period of the bit
+            const uint32_t to_wrap = GPSIQ_CA_SEQ_LEN - w_k;
+            uint32_t flip = 0u;
+            if (w_icur == 19u && to_wrap < 32u)
+                flip = ((w_navw ^ (w_navw >> 1)) & 1u) ? (0xffffffffu << to_wrap) : 0u;
+            S ^= d0 ^ flip;
+            if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_rotateleft32(S, w_rot & 31u) & w_on;
+            w_fr += w_dfr;
+            const uint32_t adv = w_dint + (uint32_t) (w_fr >> GPSIQ_CODE_FRAC_BITS);
+            w_fr &= kCodeFracMask;
+            w_rot += adv;
+            w_k += adv;
+            if (w_k >= GPSIQ_CA_SEQ_LEN) {
+                w_k -= GPSIQ_CA_SEQ_LEN;
+                if (++w_icur == 20u) { w_icur = 0u; w_navw >>= 1; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        if (n_chunk + (uint32_t) (ROWS * 64) <= (uint32_t) nsamp) {
 #pragma unroll 1
-        for (int r = 0; r < ROWS; ++r) row_body(r, false);
-    } else {
+            for (int r = 0; r < ROWS; ++r) row_body(r, n_chunk, false);
+        } else {
+            const int rows = (int) (((uint32_t) nsamp - n_chunk + 63u) >> 6);
 #pragma unroll 1
-        for (int r = 0; r < rows; ++r) row_body(r, true);
+            for (int r = 0; r < rows; ++r) row_body(r, n_chunk, true);
+        }
+        // the next chunk overwrites this wave's windows: all lanes must be done reading
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 
@@ -535,22 +552,32 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
 {
     if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
     uint8_t *d = static_cast<uint8_t *>(dst);
-    if (variant == kTile || variant == kTile32) {
-        const int rows = variant == kTile ? 64 : 32;
-        const int tile_samples = kWaves * rows * 64;
-        const int tiles = (nsamp + tile_samples - 1) / tile_samples;
+    if (variant == kTile || variant == kSeg) {
+        constexpr int rows = 64;
+        const int rows_total = (nsamp + 63) / 64;
+        // seg: up to 8 chunks per wave (one workgroup covers 262144 samples = a 2.6 Msps block),
+        // fewer when that would leave CUs without work
+        int chunks = 1;
+        if (variant == kSeg) {
+            // more chunks per wave amortise the per-workgroup set-up, but the grid must stay
+            // many rounds deep (512 resident workgroups) or the tail round eats the gain
+            for (int cand = 4; cand > 1; cand >>= 1) {
+                const long wgs = (long) nblocks * ((rows_total + kWaves * rows * cand - 1) / (kWaves * rows * cand));
+                if (wgs >= 8192) { chunks = cand; break; }
+            }
+        }
+        const int wg_rows = kWaves * rows * chunks;
+        const int tiles = (rows_total + wg_rows - 1) / wg_rows;
         dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
-#define GPSIQ_LAUNCH_T(F, N, R) hipLaunchKernelGGL((synth_tile<F, N, R>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles)
-#define GPSIQ_LAUNCH_TR(F, N) do { if (rows == 64) GPSIQ_LAUNCH_T(F, N, 64); else GPSIQ_LAUNCH_T(F, N, 32); } while (0)
+#define GPSIQ_LAUNCH_T(F, N) hipLaunchKernelGGL((synth_tile<F, N, rows>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, chunks)
         const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
         if (sample_size == GPSIQ_SC16) {
-            if (slots == 4) GPSIQ_LAUNCH_TR(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_TR(GPSIQ_SC16, 8);
-            else if (slots == 12) GPSIQ_LAUNCH_TR(GPSIQ_SC16, 12); else GPSIQ_LAUNCH_TR(GPSIQ_SC16, 16);
+            if (slots == 4) GPSIQ_LAUNCH_T(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_T(GPSIQ_SC16, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_T(GPSIQ_SC16, 12); else GPSIQ_LAUNCH_T(GPSIQ_SC16, 16);
         } else {
-            if (slots == 4) GPSIQ_LAUNCH_TR(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_TR(GPSIQ_SC08, 8);
-            else if (slots == 12) GPSIQ_LAUNCH_TR(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_TR(GPSIQ_SC08, 16);
+            if (slots == 4) GPSIQ_LAUNCH_T(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_T(GPSIQ_SC08, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_T(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_T(GPSIQ_SC08, 16);
         }
-#undef GPSIQ_LAUNCH_TR
 #undef GPSIQ_LAUNCH_T
     } else if (variant == kRowsX) {
         const int tiles = (nsamp + kRowsTile - 1) / kRowsTile;

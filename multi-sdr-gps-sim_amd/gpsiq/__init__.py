@@ -165,9 +165,12 @@ class Context:
         _check(_generate_block(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _p(out), _p(carr)))
         return out, carr
 
-    def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None):
+    def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None, host_ptr=None):
         desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
         nb, nc = desc.shape
+        if host_ptr is not None:      # caller-owned host buffer (e.g. pinned), nb*2*nsamp elements
+            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(host_ptr), 0))
+            return None
         if device_ptr is not None:
             _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(device_ptr), 1))
             return None

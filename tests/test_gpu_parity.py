@@ -12,7 +12,7 @@ from test_golden import CASES, load_case
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["generic", "rows", "rowsx", "tile", "tile32"]
+VARIANTS = ["generic", "rows", "rowsx", "tile", "seg"]
 
 
 @pytest.fixture(scope="module")
