@@ -150,6 +150,11 @@ int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, 
                          int nsamp, double fs, int sample_size,
                          void *dst, int dst_is_device);
 
+/* Page-locked host memory for fifo buffers (hipHostMalloc): a device-to-host copy into it
+ * is a single DMA.  NULL on failure.  Usable as the allocator of host/fifo.c. */
+void *gpsiq_host_alloc(size_t bytes);
+void  gpsiq_host_free(void *p);
+
 /* ---- resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
 /* Copy nblocks*nchan quantised descriptors ([nblocks][nchan]) to the device. */
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);

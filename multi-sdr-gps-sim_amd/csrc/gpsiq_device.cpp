@@ -133,6 +133,21 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     delete c;
 }
 
+void *gpsiq_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void) fail(GPSIQ_E_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void gpsiq_host_free(void *p)
+{
+    if (p) (void) hipHostFree(p);
+}
+
 int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan)
 {
     if (!c || !q) return fail(GPSIQ_E_ARG, "null argument");

@@ -73,6 +73,8 @@ _set_descriptors = _sig("gpsiq_set_descriptors", _i, _vp, _vp, _i, _i)
 _launch = _sig("gpsiq_launch", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i)
 _synchronize = _sig("gpsiq_synchronize", _i, _vp, _vp)
 _time_launches = _sig("gpsiq_time_launches", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i, _i, C.POINTER(C.c_float))
+_host_alloc = _sig("gpsiq_host_alloc", _vp, _sz)
+_host_free = _sig("gpsiq_host_free", None, _vp)
 _num_variants = _sig("gpsiq_num_variants", _i)
 _variant_name = _sig("gpsiq_variant_name", C.c_char_p, _i)
 

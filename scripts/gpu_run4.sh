@@ -1,0 +1,9 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ) > gpurun_out/pytest_gpu.log 2>&1
+tail -5 gpurun_out/pytest_gpu.log
+( timeout 300 python __graft_entry__.py smoke ) > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log
+rm -rf gpurun_out/prof
+bash scripts/gpu_prof.sh > gpurun_out/prof.log 2>&1
+( timeout 600 python bench.py ) > gpurun_out/bench_default.log 2>&1; tail -2 gpurun_out/bench_default.log

@@ -40,3 +40,22 @@ for db in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
         lines.append(f"{k[:50]:<50} {c:<24} {n:>3} {a:>18.1f} {mn:>18.1f} {mx:>18.1f} {d:>12.0f}")
 open(f"profiles/{tag}_pmc_counters.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+
+# HBM traffic per launch for bench.py's roofline.traffic (MI355X_MICROARCH.md section HBM:
+# WRITE_SIZE and FETCH_SIZE in KiB from separate passes; FETCH_SIZE doubled on gfx950).
+import json
+w = f = None
+for db in sorted(glob.glob(os.path.join(src, "pmc_write", "*.db"))):
+    r = q(db, "select avg(value) from counters_collection where counter_name='WRITE_SIZE' and kernel_name like '%synth_%'")
+    w = r[0][0]
+for db in sorted(glob.glob(os.path.join(src, "pmc_fetch", "*.db"))):
+    r = q(db, "select avg(value) from counters_collection where counter_name='FETCH_SIZE' and kernel_name like '%synth_%'")
+    f = r[0][0]
+if w is not None and f is not None:
+    key = os.environ.get("PMC_KEY", "2600000_16_1_4130")
+    path = "profiles/pmc_traffic.json"
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[key] = int(w * 1024 + 2 * f * 1024)
+    d[key + "_detail"] = {"WRITE_SIZE_KiB": w, "FETCH_SIZE_KiB_raw": f, "fetch_correction": "x2 (gfx950)", "source": f"profiles/{tag}_pmc_counters.txt"}
+    json.dump(d, open(path, "w"), indent=1)
+    print("traffic bytes/launch:", d[key])

@@ -1,0 +1,85 @@
+"""The C host side (multi-sdr-gps-sim_amd/host): the fifo.h-compatible FIFO under stress
+(and under ThreadSanitizer when the toolchain has it), and — on the GPU box — the
+gpsiq_play program, which is the reference's generator-thread / fifo / sink-thread structure
+with libgpsiq in place of the sample loop."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpsiq.abi import CHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE
+from gpsiq.scenario import synth_blocks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host_built():
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    return HOST
+
+
+def test_fifo_is_drop_free_and_ordered(host_built):
+    r = subprocess.run([os.path.join(host_built, "fifo_selftest"), "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_fifo_under_thread_sanitizer(tmp_path):
+    exe = str(tmp_path / "fifo_tsan")
+    b = subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-D_GNU_SOURCE", "-pthread", "-fsanitize=thread", "-o", exe,
+                        os.path.join(HOST, "fifo_selftest.c"), os.path.join(HOST, "fifo.c")], capture_output=True, text=True)
+    if b.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime here: " + b.stderr[-200:])
+    r = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-2000:]
+
+
+def test_fifo_header_matches_reference_api():
+    """Same nine entry points and the same struct fields as the reference's fifo.h:19-63."""
+    txt = open(os.path.join(HOST, "fifo.h")).read()
+    for fn in ("fifo_create", "fifo_destroy", "fifo_wait_next", "fifo_wait_full", "fifo_halt", "fifo_acquire",
+               "fifo_enqueue", "fifo_dequeue", "fifo_release"):
+        assert fn + "(" in txt
+    for field in ("signed char  *data8", "signed short *data16", "unsigned int  totalLength", "unsigned int  validLength",
+                  "struct iq_buf *next"):
+        assert field in txt
+    ref = "/root/reference/fifo.h"
+    if os.path.exists(ref):      # compile a translation unit that includes BOTH declarations
+        # identical prototypes may be repeated in C; conflicting ones are an error
+        code = '#include "%s"\n' % os.path.join(HOST, "fifo.h") + "\n".join(
+            l for l in open(ref).read().splitlines() if l.strip().startswith(("bool fifo_", "void fifo_", "struct iq_buf *fifo_"))
+            and "()" not in l) + "\nint main(void){return 0;}\n"
+        r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-x", "c", "-"], input=code, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def write_descriptors(path, desc, fs, nsamp, ss):
+    nb, nc = desc.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8sIIIId", b"GPSIQD1\0", nb, nc, ss, nsamp, fs))
+        f.write(np.ascontiguousarray(desc, dtype=CHAN_DTYPE).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sink,name,ss", [(SINK_IQFILE, "iqfile", SC08), (SINK_HACKRF, "hackrf", SC08), (SINK_IQFILE, "pluto", SC16)])
+def test_gpsiq_play_end_to_end(host_built, oracle, tmp_path, sink, name, ss):
+    """C generator thread -> pinned fifo -> C sink thread -> file == the oracle's blocks in
+    the reference's enqueue order (HackRF: 262144-element chunks, trailing partial chunk kept
+    back exactly as gps.c:2847-2856 does)."""
+    fs, ns, nb, nc = 2.6e6, 260000, 5, 12
+    d = synth_blocks(nb, nc, seed=91)
+    d["prn"][3:, 2] = 0
+    dpath, opath = str(tmp_path / "desc.bin"), str(tmp_path / "out.bin")
+    write_descriptors(dpath, d, fs, ns, ss)
+    r = subprocess.run([os.path.join(host_built, "gpsiq_play"), dpath, opath, name], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(opath, dtype=np.int8 if ss == SC08 else np.int16)
+    q = oracle.quantize_blocks(d, fs, ns)
+    want = np.concatenate([oracle.block_fixed(q[b], ns, ss, seq=True) for b in range(nb)])
+    plan = oracle.chunk_plan(sink, 2 * ns, nb)
+    assert len(got) == plan.sum()
+    assert np.array_equal(got, want[: plan.sum()])
