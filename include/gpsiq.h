@@ -16,6 +16,7 @@
  *   gps.c:272-309    codegen() C/A sequence             -> gpsiq_prn_code()   (table built in-library)
  *   gps.c:145-213    sinTable512 / cosTable512          -> gpsiq_carrier_table() (table built in-library)
  *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
+ *   gps.c:2731-2765  per-block host refresh (next row)  -> gpsiq_refresh_batch()
  *
  * NCO definition ("identical fixed-point NCO word widths", BASELINE.json north_star).
  * The reference advances both NCOs with sequential double additions (gps.h:17
@@ -173,6 +174,49 @@ int gpsiq_time_launches(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, in
                         int iters, float *ms_per_launch);
 int         gpsiq_num_variants(void);
 const char *gpsiq_variant_name(int variant);
+
+/* ---- per-block host refresh, batched ----------- */
+/* What the reference does on the host just before every pass of the sample loop
+ * (gps.c:2731-2765: computeRange -> computeCodePhase -> gain), for many 0.1 s blocks at
+ * once.  Plain double-precision C on the host, same operation order as the reference, so
+ * with the same libm the descriptors are identical; blocks are independent (each range
+ * depends only on time and position; the Doppler of block k is the range difference to
+ * block k-1), so the batch is spread over host threads.  Nav words are inputs
+ * (the 30 s nav-message refresh, gps.c:2878-2885, stays with the caller). */
+typedef struct gpsiq_ephem {       /* the ephem_t fields satpos()/computeRange() read (gps.h:155-196) */
+    double toe_sec, toc_sec;       /* toe.sec, toc.sec */
+    double m0, n, ecc, sqrta, sq1e2, A, aop, omg0, omgkdot, inc0, idot;
+    double cuc, cus, cic, cis, crc, crs;
+    double af0, af1, af2, tgd;
+} gpsiq_ephem_t;
+
+typedef struct gpsiq_iono {        /* ionoutc_t fields ionosphericDelay() reads (gps.h:198-206) */
+    int32_t enable, vflg;
+    double  alpha[4], beta[4];
+} gpsiq_iono_t;
+
+typedef struct gpsiq_track {       /* per-channel host state that persists between blocks */
+    int32_t  prn;                  /* 1..32, <= 0 unused */
+    int32_t  g0_week;  double g0_sec;      /* chan.g0: start of the nav-word buffer (gps.c:2045) */
+    int32_t  rho0_week; double rho0_sec;   /* chan.rho0.g  */
+    double   rho0_range;                   /* chan.rho0.range: pseudorange of the previous block (gps.c:2039) */
+    double   carr_phase;                   /* initial carrier phase (gps.c:2208-2214) */
+    uint32_t dwrd[GPSIQ_N_DWRD];
+} gpsiq_track_t;
+
+/* Initialise trk[i].rho0 and carr_phase at receiver time (week, sec) and position xyz the
+ * way allocateChannel() does (gps.c:2199-2214).  prn, g0 and dwrd must be filled by the caller. */
+int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                     const double xyz[3], gpsiq_track_t *trk, int nchan);
+
+/* Blocks k = 0..nblocks-1 at receiver times t_k = incGpsTime^(k+1)(week, sec) (the reference
+ * advances grx by 0.1 s before the first block, gps.c:2692, and after every block, gps.c:2932)
+ * and positions xyz[k] (ECEF metres).  out is [nblocks][nchan]; trk is updated to the state
+ * after the last block.  gain_x2 != 0 applies the Pluto factor (gps.c:2759-2763).
+ * nthreads <= 0: one per online CPU. */
+int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                        const double *xyz, int nblocks, int nchan, int gain_x2,
+                        gpsiq_track_t *trk, gpsiq_chan_t *out, int nthreads);
 
 /* ---- hand-off to fifo.h buffers (gps.c:2847-2865) -------------------------- */
 /* Element-exact restatement of the chunking rules, independent of the FIFO

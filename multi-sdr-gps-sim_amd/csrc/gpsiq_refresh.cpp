@@ -1,0 +1,371 @@
+// gpsiq_refresh.cpp — the per-block host refresh of the reference, batched.
+//
+// SURVEY.md section 8f rank 1.  Before every pass of the sample loop the reference computes,
+// per visible satellite, the pseudorange at the new receiver time and position
+// (computeRange, gps.c:1972-2026 -> satpos gps.c:508-611, xyz2llh gps.c:361-406, ltcmat
+// gps.c:449-469, ecef2neu gps.c:476-482, neu2azel gps.c:488-499, ionosphericDelay
+// gps.c:1893-1964), turns the range difference to the previous block into Doppler and code
+// phase (computeCodePhase, gps.c:2033-2064) and derives the signal gain (gps.c:2749-2763).
+// At >100 000x real time that loop (10 Hz, tens of microseconds per block on one core) is
+// what limits a time-sharded run, so here it runs for a whole batch of blocks, spread over
+// host threads.  Every formula keeps the reference's operand order (and this file is built
+// with -ffp-contract=off), so with the same libm the descriptors are bit-identical to the
+// reference's; tests/test_refresh.py checks that against the reference's own lines.
+#include "gpsiq_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <pthread.h>
+#include <unistd.h>
+#include <vector>
+
+namespace {
+
+// constants as the reference defines them (gps.h:61-65, 93-112)
+constexpr double kPi = 3.1415926535898;
+constexpr double kR2D = 57.2957795131;
+constexpr double kC = 2.99792458e8;
+constexpr double kLambdaL1 = 0.190293672798365;
+constexpr double kOmegaEarth = 7.2921151467e-5;
+constexpr double kWgs84A = 6378137.0;
+constexpr double kWgs84E = 0.0818191908426;
+constexpr double kSecWeek = 604800.0, kSecHalfWeek = 302400.0, kSecDay = 86400.0;
+constexpr double kCodeFreq = 1.023e6;
+constexpr double kCarrToCode = 1.0 / 1540.0;
+
+// receiver antenna attenuation in dB per 5 degrees of boresight angle (gps.c:216-221)
+const double kAntPatDb[37] = {
+    0.00, 0.00, 0.22, 0.44, 0.67, 1.11, 1.56, 2.00, 2.44, 2.89, 3.56, 4.22,
+    4.89, 5.56, 6.22, 6.89, 7.56, 8.22, 8.89, 9.78, 10.67, 11.56, 12.44, 13.33,
+    14.44, 15.56, 16.67, 17.78, 18.89, 20.00, 21.33, 22.67, 24.00, 25.56, 27.33, 29.33,
+    31.56};
+
+struct GpsTime { int week; double sec; };
+
+// gps.c:1105-1124
+GpsTime advance(GpsTime g, double dt)
+{
+    g.sec = g.sec + dt;
+    g.sec = std::round(g.sec * 1000.0) / 1000.0;
+    while (g.sec >= kSecWeek) { g.sec -= kSecWeek; g.week++; }
+    while (g.sec < 0.0) { g.sec += kSecWeek; g.week--; }
+    return g;
+}
+
+// The reference is built with gcc, which fuses sin(x) and cos(x) of one argument into a
+// single glibc sincos() call, and sincos() is not always bit-identical to separate sin()/cos()
+// (6 ranges in 4800 differ by one ulp).  Calling sincos() explicitly makes the result
+// independent of which compiler builds this file.
+inline void sin_cos(double x, double *s, double *c) { ::sincos(x, s, c); }
+
+inline double norm3(const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }   // gps.c:255-257
+
+// Receiver geometry of one block: geodetic position and the ECEF->NEU rotation
+// (gps.c:361-406, gps.c:449-469).  The reference recomputes it per satellite; the inputs
+// are the same, so once per block gives the same numbers.
+struct Site { double llh[3]; double t[3][3]; };
+
+Site site_from_ecef(const double *xyz)
+{
+    Site s;
+    const double a = kWgs84A, e = kWgs84E, eps = 1.0e-3, e2 = e * e;
+    if (norm3(xyz) < eps) {
+        s.llh[0] = 0.0; s.llh[1] = 0.0; s.llh[2] = -a;
+    } else {
+        const double x = xyz[0], y = xyz[1], z = xyz[2];
+        const double rho2 = x * x + y * y;
+        double dz = e2 * z, zdz, nh, n;
+        for (;;) {
+            zdz = z + dz;
+            nh = std::sqrt(rho2 + zdz * zdz);
+            const double slat = zdz / nh;
+            n = a / std::sqrt(1.0 - e2 * slat * slat);
+            const double dz_new = n * e2 * slat;
+            if (std::fabs(dz - dz_new) < eps) break;
+            dz = dz_new;
+        }
+        s.llh[0] = std::atan2(zdz, std::sqrt(rho2));
+        s.llh[1] = std::atan2(y, x);
+        s.llh[2] = nh - n;
+    }
+    double slat, clat, slon, clon;
+    sin_cos(s.llh[0], &slat, &clat);
+    sin_cos(s.llh[1], &slon, &clon);
+    s.t[0][0] = -slat * clon; s.t[0][1] = -slat * slon; s.t[0][2] = clat;
+    s.t[1][0] = -slon;        s.t[1][1] = clon;         s.t[1][2] = 0.0;
+    s.t[2][0] = clat * clon;  s.t[2][1] = clat * slon;  s.t[2][2] = slat;
+    return s;
+}
+
+struct SvState { double pos[3], vel[3], clk[2]; };
+
+// Broadcast-ephemeris orbit, velocity and clock (gps.c:508-611).
+SvState sv_state(const gpsiq_ephem_t &e, double sec)
+{
+    SvState s;
+    double tk = sec - e.toe_sec;
+    if (tk > kSecHalfWeek) tk -= kSecWeek;
+    else if (tk < -kSecHalfWeek) tk += kSecWeek;
+
+    const double mk = e.m0 + e.n * tk;
+    double ek = mk, ekold = ek + 1.0, one_m_ecos = 0;
+    while (std::fabs(ek - ekold) > 1.0E-14) {          // Kepler, Newton steps
+        ekold = ek;
+        double so, co;
+        sin_cos(ekold, &so, &co);
+        one_m_ecos = 1.0 - e.ecc * co;
+        ek = ek + (mk - ekold + e.ecc * so) / one_m_ecos;
+    }
+    double sek, cek;
+    sin_cos(ek, &sek, &cek);
+    const double ekdot = e.n / one_m_ecos;
+    const double relativistic = -4.442807633E-10 * e.ecc * e.sqrta * sek;
+
+    const double pk = std::atan2(e.sq1e2 * sek, cek - e.ecc) + e.aop;
+    const double pkdot = e.sq1e2 * ekdot / one_m_ecos;
+    double s2pk, c2pk;
+    sin_cos(2.0 * pk, &s2pk, &c2pk);
+
+    const double uk = pk + e.cus * s2pk + e.cuc * c2pk;
+    double suk, cuk;
+    sin_cos(uk, &suk, &cuk);
+    const double ukdot = pkdot * (1.0 + 2.0 * (e.cus * c2pk - e.cuc * s2pk));
+
+    const double rk = e.A * one_m_ecos + e.crc * c2pk + e.crs * s2pk;
+    const double rkdot = e.A * e.ecc * sek * ekdot + 2.0 * pkdot * (e.crs * c2pk - e.crc * s2pk);
+
+    const double ik = e.inc0 + e.idot * tk + e.cic * c2pk + e.cis * s2pk;
+    double sik, cik;
+    sin_cos(ik, &sik, &cik);
+    const double ikdot = e.idot + 2.0 * pkdot * (e.cis * c2pk - e.cic * s2pk);
+
+    const double xpk = rk * cuk, ypk = rk * suk;
+    const double xpkdot = rkdot * cuk - ypk * ukdot;
+    const double ypkdot = rkdot * suk + xpk * ukdot;
+
+    const double ok = e.omg0 + tk * e.omgkdot - kOmegaEarth * e.toe_sec;
+    double sok, cok;
+    sin_cos(ok, &sok, &cok);
+
+    s.pos[0] = xpk * cok - ypk * cik * sok;
+    s.pos[1] = xpk * sok + ypk * cik * cok;
+    s.pos[2] = ypk * sik;
+
+    const double tmp = ypkdot * cik - ypk * sik * ikdot;
+    s.vel[0] = -e.omgkdot * s.pos[1] + xpkdot * cok - tmp * sok;
+    s.vel[1] = e.omgkdot * s.pos[0] + xpkdot * sok + tmp * cok;
+    s.vel[2] = ypk * cik * ikdot + ypkdot * sik;
+
+    tk = sec - e.toc_sec;
+    if (tk > kSecHalfWeek) tk -= kSecWeek;
+    else if (tk < -kSecHalfWeek) tk += kSecWeek;
+    s.clk[0] = e.af0 + tk * (e.af1 + tk * e.af2) + relativistic - e.tgd;
+    s.clk[1] = e.af1 + 2.0 * tk * e.af2;
+    return s;
+}
+
+// Klobuchar model (gps.c:1893-1964).
+double iono_delay(const gpsiq_iono_t &io, double sec, const double *llh, const double *azel)
+{
+    if (!io.enable) return 0.0;
+    const double E = azel[1] / kPi, phi_u = llh[0] / kPi, lam_u = llh[1] / kPi;
+    const double F = 1.0 + 16.0 * std::pow((0.53 - E), 3.0);
+    if (!io.vflg) return F * 5.0e-9 * kC;
+
+    const double psi = 0.0137 / (E + 0.11) - 0.022;
+    double saz, caz;
+    sin_cos(azel[0], &saz, &caz);
+    double phi_i = phi_u + psi * caz;
+    if (phi_i > 0.416) phi_i = 0.416;
+    else if (phi_i < -0.416) phi_i = -0.416;
+    const double lam_i = lam_u + psi * saz / std::cos(phi_i * kPi);
+    const double phi_m = phi_i + 0.064 * std::cos((lam_i - 1.617) * kPi);
+    const double phi_m2 = phi_m * phi_m, phi_m3 = phi_m2 * phi_m;
+    double amp = io.alpha[0] + io.alpha[1] * phi_m + io.alpha[2] * phi_m2 + io.alpha[3] * phi_m3;
+    if (amp < 0.0) amp = 0.0;
+    double per = io.beta[0] + io.beta[1] * phi_m + io.beta[2] * phi_m2 + io.beta[3] * phi_m3;
+    if (per < 72000.0) per = 72000.0;
+    double t = kSecDay / 2.0 * lam_i + sec;
+    while (t >= kSecDay) t -= kSecDay;
+    while (t < 0) t += kSecDay;
+    const double X = 2.0 * kPi * (t - 50400.0) / per;
+    if (std::fabs(X) < 1.57) {
+        const double X2 = X * X, X4 = X2 * X2;
+        return F * (5.0e-9 + amp * (1.0 - X2 / 2.0 + X4 / 24.0)) * kC;
+    }
+    return F * 5.0e-9 * kC;
+}
+
+struct Range { double prange, d, az, el; };
+
+// Light-time and Earth-rotation corrected pseudorange, azimuth/elevation (gps.c:1972-2026).
+Range range_to(const gpsiq_ephem_t &e, const gpsiq_iono_t &io, double sec, const double *xyz, const Site &site)
+{
+    SvState s = sv_state(e, sec);
+    double los[3] = {s.pos[0] - xyz[0], s.pos[1] - xyz[1], s.pos[2] - xyz[2]};
+    const double tau = norm3(los) / kC;
+    s.pos[0] -= s.vel[0] * tau;
+    s.pos[1] -= s.vel[1] * tau;
+    s.pos[2] -= s.vel[2] * tau;
+    const double xrot = s.pos[0] + s.pos[1] * kOmegaEarth * tau;
+    const double yrot = s.pos[1] - s.pos[0] * kOmegaEarth * tau;
+    s.pos[0] = xrot;
+    s.pos[1] = yrot;
+    los[0] = s.pos[0] - xyz[0]; los[1] = s.pos[1] - xyz[1]; los[2] = s.pos[2] - xyz[2];
+    Range r;
+    r.d = norm3(los);
+    r.prange = r.d - kC * s.clk[0];
+    double neu[3];
+    for (int k = 0; k < 3; ++k)
+        neu[k] = site.t[k][0] * los[0] + site.t[k][1] * los[1] + site.t[k][2] * los[2];   // gps.c:476-482
+    double azel[2];
+    azel[0] = std::atan2(neu[1], neu[0]);                                                  // gps.c:488-499
+    if (azel[0] < 0.0) azel[0] += (2.0 * kPi);
+    azel[1] = std::atan2(neu[2], std::sqrt(neu[0] * neu[0] + neu[1] * neu[1]));
+    r.az = azel[0];
+    r.el = azel[1];
+    r.prange += iono_delay(io, sec, site.llh, azel);
+    return r;
+}
+
+struct Job {
+    const gpsiq_ephem_t *eph; const gpsiq_iono_t *iono; const double *xyz; const GpsTime *t;
+    int nchan, gain_x2; const gpsiq_track_t *trk; const double *ant_pat;
+    Range *rng;            // [nblocks + 1][nchan], row 0 = the state before the batch
+    gpsiq_chan_t *out;
+    int b0, b1, pass;
+};
+
+void *worker(void *p)
+{
+    const Job &j = *static_cast<const Job *>(p);
+    for (int b = j.b0; b < j.b1; ++b) {
+        if (j.pass == 0) {                                   // ranges: independent per block
+            const Site site = site_from_ecef(j.xyz + 3 * (size_t) b);
+            for (int c = 0; c < j.nchan; ++c)
+                if (j.trk[c].prn > 0)
+                    j.rng[(size_t) (b + 1) * j.nchan + c] = range_to(j.eph[c], *j.iono, j.t[b + 1].sec, j.xyz + 3 * (size_t) b, site);
+        } else {                                             // code phase, Doppler, gain
+            for (int c = 0; c < j.nchan; ++c) {
+                gpsiq_chan_t &o = j.out[(size_t) b * j.nchan + c];
+                std::memset(&o, 0, sizeof o);
+                o.prn = j.trk[c].prn > 0 ? j.trk[c].prn : 0;
+                if (o.prn == 0) continue;
+                const Range &r0 = j.rng[(size_t) b * j.nchan + c], &r1 = j.rng[(size_t) (b + 1) * j.nchan + c];
+                // time of the previous range (chan.rho0.g): the carried-in one for the first block
+                const GpsTime t0 = b == 0 ? GpsTime{j.trk[c].rho0_week, j.trk[c].rho0_sec} : j.t[b];
+                // gps.c:2033-2064
+                const double rhorate = (r1.prange - r0.prange) / 0.1;
+                o.f_carr = -rhorate / kLambdaL1;
+                o.f_code = kCodeFreq + o.f_carr * kCarrToCode;
+                double dtg = t0.sec - j.trk[c].g0_sec;
+                dtg += (double) (t0.week - j.trk[c].g0_week) * kSecWeek;
+                const double ms = ((dtg + 6.0) - r0.prange / kC) * 1000.0;
+                int ims = (int) ms;
+                o.code_phase = (ms - (double) ims) * GPSIQ_CA_SEQ_LEN;
+                o.iword = ims / 600; ims -= o.iword * 600;
+                o.ibit = ims / 20;   ims -= o.ibit * 20;
+                o.icode = ims;
+                o.carr_phase = j.trk[c].carr_phase;
+                // gps.c:2749-2763
+                const double path_loss = 20200000.0 / r1.d;
+                const int ibs = (int) ((90.0 - r1.el * kR2D) / 5.0);
+                double g = path_loss * j.ant_pat[ibs < 0 ? 0 : ibs > 36 ? 36 : ibs];
+                if (j.gain_x2) g *= 2;
+                o.gain = g;
+                std::memcpy(o.dwrd, j.trk[c].dwrd, sizeof o.dwrd);
+            }
+        }
+    }
+    return nullptr;
+}
+
+void run_parallel(Job proto, int nblocks, int nthreads)
+{
+    if (nthreads > nblocks) nthreads = nblocks;
+    if (nthreads <= 1) { proto.b0 = 0; proto.b1 = nblocks; worker(&proto); return; }
+    std::vector<Job> jobs((size_t) nthreads, proto);
+    std::vector<pthread_t> th((size_t) nthreads);
+    for (int i = 0; i < nthreads; ++i) {
+        jobs[(size_t) i].b0 = (int) ((long) nblocks * i / nthreads);
+        jobs[(size_t) i].b1 = (int) ((long) nblocks * (i + 1) / nthreads);
+        if (pthread_create(&th[(size_t) i], nullptr, worker, &jobs[(size_t) i]) != 0) {
+            worker(&jobs[(size_t) i]);               // could not spawn: do it here
+            th[(size_t) i] = pthread_t();
+            jobs[(size_t) i].pass = -1;
+        }
+    }
+    for (int i = 0; i < nthreads; ++i)
+        if (jobs[(size_t) i].pass != -1) pthread_join(th[(size_t) i], nullptr);
+}
+
+}  // namespace
+
+using namespace gpsiq;
+
+extern "C" {
+
+int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                     const double xyz[3], gpsiq_track_t *trk, int nchan)
+{
+    if (!eph || !iono || !xyz || !trk) return fail(GPSIQ_E_ARG, "null argument");
+    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "nchan %d outside 1..%d", nchan, GPSIQ_MAX_CHAN);
+    const Site site = site_from_ecef(xyz);
+    const double origin[3] = {0.0, 0.0, 0.0};
+    const Site site0 = site_from_ecef(origin);
+    for (int c = 0; c < nchan; ++c) {
+        if (trk[c].prn <= 0) continue;
+        if (trk[c].prn > 32) return fail(GPSIQ_E_ARG, "prn %d out of range", trk[c].prn);
+        const Range r = range_to(eph[c], *iono, sec, xyz, site);            // gps.c:2199-2200
+        trk[c].rho0_range = r.prange;
+        trk[c].rho0_week = week;
+        trk[c].rho0_sec = sec;
+        const double r_ref = range_to(eph[c], *iono, sec, origin, site0).prange;   // gps.c:2206-2207
+        const double phase_ini = (2.0 * r_ref - r.prange) / kLambdaL1;      // gps.c:2209
+        trk[c].carr_phase = phase_ini - std::floor(phase_ini);              // gps.c:2211
+    }
+    return GPSIQ_OK;
+}
+
+int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                        const double *xyz, int nblocks, int nchan, int gain_x2,
+                        gpsiq_track_t *trk, gpsiq_chan_t *out, int nthreads)
+{
+    if (!eph || !iono || !xyz || !trk || !out) return fail(GPSIQ_E_ARG, "null argument");
+    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN || nblocks < 0) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nblocks == 0) return GPSIQ_OK;
+    if (nthreads <= 0) {
+        long n = sysconf(_SC_NPROCESSORS_ONLN);
+        nthreads = n > 0 ? (int) n : 1;
+    }
+    double ant_pat[37];
+    for (int i = 0; i < 37; ++i) ant_pat[i] = std::pow(10.0, -kAntPatDb[i] / 20.0);    // gps.c:2688-2689
+
+    // receiver time of every block: grx is advanced before the first block (gps.c:2692)
+    // and after each one (gps.c:2932); t[0] is the time of the carried-in range
+    std::vector<GpsTime> t((size_t) nblocks + 1);
+    GpsTime g = {week, sec};
+    for (int b = 1; b <= nblocks; ++b) { g = advance(g, 0.1); t[(size_t) b] = g; }
+    std::vector<Range> rng((size_t) (nblocks + 1) * (size_t) nchan);
+    for (int c = 0; c < nchan; ++c) {
+        if (trk[c].prn > 32) return fail(GPSIQ_E_ARG, "prn %d out of range", trk[c].prn);
+        rng[(size_t) c].prange = trk[c].rho0_range;
+        rng[(size_t) c].d = rng[(size_t) c].az = rng[(size_t) c].el = 0.0;
+    }
+    t[0] = GpsTime{week, sec};
+
+    Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0, 0, 0};
+    run_parallel(job, nblocks, nthreads);
+    job.pass = 1;
+    run_parallel(job, nblocks, nthreads);
+
+    for (int c = 0; c < nchan; ++c) {                      // chan.rho0 = rho1 (gps.c:2063)
+        if (trk[c].prn <= 0) continue;
+        trk[c].rho0_range = rng[(size_t) nblocks * nchan + c].prange;
+        trk[c].rho0_week = t[(size_t) nblocks].week;
+        trk[c].rho0_sec = t[(size_t) nblocks].sec;
+    }
+    return GPSIQ_OK;
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,  # noqa: F401
-                  SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype)
+                  SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype, EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
@@ -75,6 +75,8 @@ _synchronize = _sig("gpsiq_synchronize", _i, _vp, _vp)
 _time_launches = _sig("gpsiq_time_launches", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i, _i, C.POINTER(C.c_float))
 _host_alloc = _sig("gpsiq_host_alloc", _vp, _sz)
 _host_free = _sig("gpsiq_host_free", None, _vp)
+_track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
+_refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _num_variants = _sig("gpsiq_num_variants", _i)
 _variant_name = _sig("gpsiq_variant_name", C.c_char_p, _i)
 
@@ -137,6 +139,28 @@ def quantize_blocks(desc, fs, nsamp, carry0=None):
                         cin[c] = np.uint64(int(np.floor(np.ldexp(float(desc[b, c]["carr_phase"]), 59))))
         q[b], carry = quantize(desc[b], fs, nsamp, cin)
     return q, carry
+
+
+def track_init(eph, iono, week, sec, xyz, trk):
+    """allocateChannel()'s range / carrier-phase initialisation (reference gps.c:2199-2214); trk is updated in place."""
+    eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+    iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    assert trk.dtype == TRACK_DTYPE and trk.flags.c_contiguous
+    _check(_track_init(_p(eph), _p(iono), int(week), float(sec), _p(xyz), _p(trk), len(trk)))
+    return trk
+
+
+def refresh_batch(eph, iono, week, sec, xyz, trk, gain_x2=False, nthreads=0):
+    """The per-block host refresh (reference gps.c:2731-2765) for len(xyz) blocks -> gpsiq_chan_t[nblocks][nchan]."""
+    eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+    iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    assert trk.dtype == TRACK_DTYPE and trk.flags.c_contiguous
+    out = np.zeros((len(xyz), len(trk)), dtype=CHAN_DTYPE)
+    _check(_refresh_batch(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), len(trk), int(bool(gain_x2)),
+                          _p(trk), _p(out), int(nthreads)))
+    return out
 
 
 class Context:

@@ -28,3 +28,15 @@ assert QCHAN_DTYPE.itemsize == 48
 
 def elem_dtype(sample_size):
     return np.int8 if sample_size == SC08 else np.int16
+
+
+# gpsiq_ephem_t / gpsiq_iono_t / gpsiq_track_t (host refresh, include/gpsiq.h)
+EPHEM_FIELDS = ["toe_sec", "toc_sec", "m0", "n", "ecc", "sqrta", "sq1e2", "A", "aop", "omg0", "omgkdot", "inc0", "idot",
+                "cuc", "cus", "cic", "cis", "crc", "crs", "af0", "af1", "af2", "tgd"]
+EPHEM_DTYPE = np.dtype([(f, "<f8") for f in EPHEM_FIELDS], align=True)
+assert EPHEM_DTYPE.itemsize == 23 * 8
+IONO_DTYPE = np.dtype([("enable", "<i4"), ("vflg", "<i4"), ("alpha", "<f8", (4,)), ("beta", "<f8", (4,))], align=True)
+assert IONO_DTYPE.itemsize == 72
+TRACK_DTYPE = np.dtype([("prn", "<i4"), ("g0_week", "<i4"), ("g0_sec", "<f8"), ("rho0_week", "<i4"), ("rho0_sec", "<f8"),
+                        ("rho0_range", "<f8"), ("carr_phase", "<f8"), ("dwrd", "<u4", (N_DWRD,))], align=True)
+assert TRACK_DTYPE.itemsize == 288

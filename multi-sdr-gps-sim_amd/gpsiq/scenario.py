@@ -56,3 +56,108 @@ def synth_blocks(nblocks, nchan, seed=20250215, doppler_hz=5000.0, prn0=1, drift
             e["dwrd"] = dwrd
             f_carr += (rng.uniform() * 2.0 - 1.0) * drift_hz
     return d
+
+
+# ---- scenarios for the host refresh (gpsiq_refresh_batch) -------------------------------
+GM_EARTH = 3.986005e14          # reference gps.h:89-90
+OMEGA_EARTH = 7.2921151467e-5
+WGS84_A, WGS84_E = 6378137.0, 0.0818191908426
+
+
+def llh_to_ecef(lat_deg, lon_deg, h):
+    lat, lon = np.radians(lat_deg), np.radians(lon_deg)
+    n = WGS84_A / np.sqrt(1.0 - (WGS84_E * np.sin(lat)) ** 2)
+    return np.array([(n + h) * np.cos(lat) * np.cos(lon), (n + h) * np.cos(lat) * np.sin(lon),
+                     ((1.0 - WGS84_E ** 2) * n + h) * np.sin(lat)])
+
+
+def _elevation_deg(e, sec, xyz):
+    """Plain Kepler orbit -> elevation; only used to pick visible satellites."""
+    tk = sec - e["toe_sec"]
+    mk = e["m0"] + e["n"] * tk
+    ek = mk
+    for _ in range(12):
+        ek = ek + (mk - ek + e["ecc"] * np.sin(ek)) / (1.0 - e["ecc"] * np.cos(ek))
+    pk = np.arctan2(e["sq1e2"] * np.sin(ek), np.cos(ek) - e["ecc"]) + e["aop"]
+    rk = e["A"] * (1.0 - e["ecc"] * np.cos(ek))
+    ok = e["omg0"] + tk * e["omgkdot"] - OMEGA_EARTH * e["toe_sec"]
+    xp, yp = rk * np.cos(pk), rk * np.sin(pk)
+    pos = np.array([xp * np.cos(ok) - yp * np.cos(e["inc0"]) * np.sin(ok),
+                    xp * np.sin(ok) + yp * np.cos(e["inc0"]) * np.cos(ok), yp * np.sin(e["inc0"])])
+    los = pos - xyz
+    up = xyz / np.linalg.norm(xyz)
+    return float(np.degrees(np.arcsin(np.dot(los, up) / np.linalg.norm(los))))
+
+
+def synth_constellation(nsat, xyz, sec, seed=1, min_elev_deg=8.0):
+    """nsat broadcast-ephemeris sets (EPHEM_DTYPE) of GPS-like orbits that are all above
+    min_elev_deg at receiver position xyz and time-of-week sec, with the working variables
+    the reference derives when it reads RINEX (A, n, sq1e2, omgkdot: gps.c:1456-1461)."""
+    from .abi import EPHEM_DTYPE
+    rng = SplitMix64(seed)
+    out = np.zeros(nsat, dtype=EPHEM_DTYPE)
+    k = 0
+    toe = float(int(sec / 7200.0) * 7200)
+    while k < nsat:
+        e = np.zeros((), dtype=EPHEM_DTYPE)
+        e["sqrta"] = 5153.6 + (rng.uniform() - 0.5)
+        e["A"] = e["sqrta"] * e["sqrta"]
+        e["ecc"] = 0.001 + 0.019 * rng.uniform()
+        e["sq1e2"] = np.sqrt(1.0 - e["ecc"] * e["ecc"])
+        e["n"] = np.sqrt(GM_EARTH / (e["A"] * e["A"] * e["A"])) + (3.0 + 2.0 * rng.uniform()) * 1e-9
+        e["inc0"] = np.radians(55.0 + 2.0 * (rng.uniform() - 0.5))
+        e["idot"] = (rng.uniform() - 0.5) * 6e-10
+        e["omg0"] = 2.0 * np.pi * rng.uniform() - np.pi
+        e["omgkdot"] = -(7.5 + rng.uniform()) * 1e-9 - OMEGA_EARTH
+        e["aop"] = 2.0 * np.pi * rng.uniform() - np.pi
+        e["m0"] = 2.0 * np.pi * rng.uniform() - np.pi
+        for f, a in (("cuc", 3e-6), ("cus", 8e-6), ("cic", 2e-7), ("cis", 2e-7), ("crc", 300.0), ("crs", 80.0)):
+            e[f] = (rng.uniform() - 0.5) * 2.0 * a
+        e["af0"] = (rng.uniform() - 0.5) * 4e-4
+        e["af1"] = (rng.uniform() - 0.5) * 2e-11
+        e["af2"] = 0.0
+        e["tgd"] = -(0.5 + rng.uniform()) * 1e-8
+        e["toe_sec"] = toe
+        e["toc_sec"] = toe
+        if _elevation_deg(e, sec, xyz) > min_elev_deg:
+            out[k] = e
+            k += 1
+    return out
+
+
+def synth_iono(kind="klobuchar"):
+    from .abi import IONO_DTYPE
+    io = np.zeros((), dtype=IONO_DTYPE)
+    if kind == "off":
+        return io
+    io["enable"] = 1
+    if kind == "klobuchar":
+        io["vflg"] = 1
+        io["alpha"] = [0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06]
+        io["beta"] = [0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07]
+    return io
+
+
+def synth_tracks(nsat, week, sec, seed=1, prn0=1):
+    """Per-channel host state before gpsiq_track_init: prn, nav-word buffer (random 30-bit
+    words) and its start time g0 (the start of the 30 s frame that contains sec)."""
+    from .abi import TRACK_DTYPE
+    rng = SplitMix64(seed + 77)
+    t = np.zeros(nsat, dtype=TRACK_DTYPE)
+    for c in range(nsat):
+        t[c]["prn"] = (prn0 - 1 + c) % 32 + 1
+        t[c]["g0_week"] = week
+        t[c]["g0_sec"] = float(int(sec / 30.0) * 30)
+        t[c]["dwrd"] = [rng.next() & 0x3FFFFFFF for _ in range(N_DWRD)]
+    return t
+
+
+def circle_track(centre_xyz, nblocks, radius_m=100.0, period_s=60.0, dt=0.1):
+    """Receiver positions for nblocks+1 epochs on a horizontal circle around centre_xyz."""
+    up = centre_xyz / np.linalg.norm(centre_xyz)
+    east = np.cross([0.0, 0.0, 1.0], up)
+    east /= np.linalg.norm(east)
+    north = np.cross(up, east)
+    t = np.arange(nblocks + 1) * dt
+    ang = 2.0 * np.pi * t / period_s
+    return centre_xyz[None, :] + radius_m * (np.cos(ang)[:, None] * north[None, :] + np.sin(ang)[:, None] * east[None, :])

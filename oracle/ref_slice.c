@@ -37,8 +37,15 @@ static int ref_nchan = 12;
 #define MAX_CHAN ref_nchan
 
 #include "ref_tables.inc"            /* gps.c:145-213  sinTable512, cosTable512 */
+#include "ref_antpat.inc"            /* gps.c:216-221  ant_pat_db[] */
+#include "ref_vec.inc"               /* gps.c:243-266  subVect, normVect, dotProd */
 #include "ref_codegen.inc"           /* gps.c:272-309  codegen() */
+#include "ref_geo.inc"               /* gps.c:361-499  xyz2llh, llh2xyz, ltcmat, ecef2neu, neu2azel */
+#include "ref_satpos.inc"            /* gps.c:508-611  satpos() */
 #include "ref_subgpstime.inc"        /* gps.c:1096-1103 subGpsTime() */
+#include "ref_incgpstime.inc"        /* gps.c:1105-1124 incGpsTime() */
+#include "ref_iono.inc"              /* gps.c:1893-1964 ionosphericDelay() */
+#include "ref_range.inc"             /* gps.c:1972-2026 computeRange() */
 #include "ref_computecodephase.inc"  /* gps.c:2033-2064 computeCodePhase() */
 
 /* ---- capturing fifo (the tap SURVEY.md section 0 fact 6 asks for) --------- */
@@ -194,4 +201,120 @@ int ref_run_blocks(const gpsiq_chan_t *desc, int nblocks, int nchan, int fs,
     for (int b = 0; b < 2; b++) { free(cap.buf[b].data16); free(cap.buf[b].data8); }
     free(iq_buff);
     return rc;
+}
+
+/* ---- host refresh: the reference's own lines around the loop ---- */
+static void load_eph(ephem_t *e, const gpsiq_ephem_t *in)
+{
+    memset(e, 0, sizeof *e);
+    e->vflg = 1;
+    e->toe.sec = in->toe_sec; e->toc.sec = in->toc_sec;
+    e->m0 = in->m0; e->n = in->n; e->ecc = in->ecc; e->sqrta = in->sqrta; e->sq1e2 = in->sq1e2;
+    e->A = in->A; e->aop = in->aop; e->omg0 = in->omg0; e->omgkdot = in->omgkdot;
+    e->inc0 = in->inc0; e->idot = in->idot;
+    e->cuc = in->cuc; e->cus = in->cus; e->cic = in->cic; e->cis = in->cis; e->crc = in->crc; e->crs = in->crs;
+    e->af0 = in->af0; e->af1 = in->af1; e->af2 = in->af2; e->tgd = in->tgd;
+}
+
+static void load_iono(ionoutc_t *io, const gpsiq_iono_t *in)
+{
+    memset(io, 0, sizeof *io);
+    io->enable = in->enable; io->vflg = in->vflg;
+    io->alpha0 = in->alpha[0]; io->alpha1 = in->alpha[1]; io->alpha2 = in->alpha[2]; io->alpha3 = in->alpha[3];
+    io->beta0 = in->beta[0]; io->beta1 = in->beta[1]; io->beta2 = in->beta[2]; io->beta3 = in->beta[3];
+}
+
+/* satpos() + computeRange() for one satellite: pos[3], vel[3], clk[2], then
+ * range, rate, d, az, el, iono_delay. */
+int ref_compute_range(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in, int week, double sec,
+                      const double *xyz, double *out14)
+{
+    ephem_t e; ionoutc_t io; gpstime_t g = { week, sec }; range_t rho;
+    double p[3] = { xyz[0], xyz[1], xyz[2] };
+    load_eph(&e, eph_in); load_iono(&io, iono_in);
+    satpos(e, g, out14, out14 + 3, out14 + 6);
+    computeRange(&rho, e, &io, g, p);
+    out14[8] = rho.range; out14[9] = rho.rate; out14[10] = rho.d;
+    out14[11] = rho.azel[0]; out14[12] = rho.azel[1]; out14[13] = rho.iono_delay;
+    return 0;
+}
+
+int ref_inc_gps_time(int *week, double *sec, double dt)
+{
+    gpstime_t g = { *week, *sec };
+    g = incGpsTime(g, dt);
+    *week = g.week; *sec = g.sec;
+    return 0;
+}
+
+/*
+ * The host side of gps_thread_ep() from channel allocation to the state at gps.c:2766, for
+ * nblocks blocks: rho0 / carr_phase initialised as allocateChannel() does (gps.c:2199-2214,
+ * restated below with the reference's computeRange), antenna pattern gps.c:2688-2689 and
+ * the per-block refresh gps.c:2731-2765 included verbatim, grx advanced by incGpsTime as
+ * gps.c:2692 / gps.c:2932 do.  xyz is [nblocks+1][3]: xyz[0] the allocation position,
+ * xyz[k+1] the position of block k.  out is [nblocks][nchan].
+ */
+int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in, int week, double sec,
+                       const double *xyz_in, int nblocks, int nchan, int sdr_type,
+                       const gpsiq_track_t *trk_in, gpsiq_chan_t *out, double *carr_init)
+{
+    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return -1;
+    ref_nchan = nchan;
+    static simulator_t sim;
+    simulator_t *simulator = &sim;
+    static channel_t chan[GPSIQ_MAX_CHAN];
+    static ephem_t eph[1][MAX_SAT];
+    ionoutc_t ionoutc;
+    double gain[GPSIQ_MAX_CHAN], ant_pat[37], path_loss, ant_gain;
+    int i, sv, ibs, ieph = 0, iumd;
+    gpstime_t grx = { week, sec };
+    double (*xyz)[3] = (double (*)[3]) xyz_in;
+
+    memset(&sim, 0, sizeof sim);
+    sim.sdr_type = (sdr_type_t) sdr_type;
+    memset(chan, 0, sizeof chan);
+    memset(eph, 0, sizeof eph);
+    load_iono(&ionoutc, iono_in);
+
+    for (i = 0; i < nchan; i++) {                       /* allocateChannel(), gps.c:2183-2214 */
+        if (trk_in[i].prn <= 0) continue;
+        range_t rho;
+        double ref[3] = { 0.0 }, r_ref, r_xyz, phase_ini;
+        chan[i].prn = trk_in[i].prn;
+        sv = chan[i].prn - 1;
+        load_eph(&eph[0][sv], &eph_in[i]);
+        codegen(chan[i].ca, chan[i].prn);
+        for (int k = 0; k < N_DWRD; k++) chan[i].dwrd[k] = trk_in[i].dwrd[k];
+        chan[i].g0.week = trk_in[i].g0_week; chan[i].g0.sec = trk_in[i].g0_sec;
+        computeRange(&rho, eph[0][sv], &ionoutc, grx, xyz[0]);      /* gps.c:2199 */
+        chan[i].rho0 = rho;
+        r_xyz = rho.range;
+        computeRange(&rho, eph[0][sv], &ionoutc, grx, ref);         /* gps.c:2206 */
+        r_ref = rho.range;
+        phase_ini = (2.0 * r_ref - r_xyz) / LAMBDA_L1;              /* gps.c:2209 */
+        chan[i].carr_phase = phase_ini - floor(phase_ini);          /* gps.c:2211 */
+        if (carr_init) carr_init[i] = chan[i].carr_phase;
+    }
+
+#include "ref_antinit.inc"           /* gps.c:2688-2689 ant_pat[] */
+
+    grx = incGpsTime(grx, 0.1);                                     /* gps.c:2692 */
+    for (iumd = 1; iumd <= nblocks; iumd++) {
+#include "ref_refresh.inc"           /* gps.c:2731-2765 */
+        for (i = 0; i < nchan; i++) {
+            gpsiq_chan_t *o = &out[(size_t) (iumd - 1) * nchan + i];
+            memset(o, 0, sizeof *o);
+            o->prn = chan[i].prn;
+            if (chan[i].prn <= 0) continue;
+            o->iword = chan[i].iword; o->ibit = chan[i].ibit; o->icode = chan[i].icode;
+            o->f_carr = chan[i].f_carr; o->f_code = chan[i].f_code;
+            o->carr_phase = chan[i].carr_phase; o->code_phase = chan[i].code_phase;
+            o->gain = gain[i];
+            for (int k = 0; k < N_DWRD; k++) o->dwrd[k] = (uint32_t) chan[i].dwrd[k];
+        }
+        grx = incGpsTime(grx, 0.1);                                 /* gps.c:2932 */
+    }
+    (void) path_loss; (void) ant_gain; (void) ibs; (void) ieph;
+    return 0;
 }

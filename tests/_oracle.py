@@ -14,7 +14,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 import sys
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
-from gpsiq.abi import CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, elem_dtype  # noqa: E402
+from gpsiq.abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, elem_dtype,  # noqa: E402
+                       EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE)
 
 
 def build():
@@ -149,6 +150,39 @@ class Ref:
         if rc:
             raise RuntimeError(rc)
         return out[: n_out.value], chunks[: n_chunks.value].astype(np.int64), carr
+
+    def compute_range(self, eph, iono, week, sec, xyz):
+        """satpos + computeRange: dict(pos, vel, clk, range, rate, d, az, el, iono)"""
+        eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+        iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        o = np.zeros(14)
+        self.lib.ref_compute_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        assert self.lib.ref_compute_range(_ptr(eph), _ptr(iono), int(week), float(sec), _ptr(xyz), _ptr(o)) == 0
+        return dict(pos=o[0:3], vel=o[3:6], clk=o[6:8], range=o[8], rate=o[9], d=o[10], az=o[11], el=o[12], iono=o[13])
+
+    def inc_gps_time(self, week, sec, dt):
+        w, s = C.c_int(week), C.c_double(sec)
+        self.lib.ref_inc_gps_time.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        self.lib.ref_inc_gps_time(C.byref(w), C.byref(s), dt)
+        return w.value, s.value
+
+    def refresh_blocks(self, eph, iono, week, sec, xyz, trk, sdr_type=1):
+        """xyz [nblocks+1][3] (xyz[0] = allocation position) -> (descriptors [nblocks][nchan], carr_init[nchan])"""
+        eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+        iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        trk = np.ascontiguousarray(trk, dtype=TRACK_DTYPE)
+        nb, nc = len(xyz) - 1, len(trk)
+        out = np.zeros((nb, nc), dtype=CHAN_DTYPE)
+        carr = np.zeros(nc)
+        self.lib.ref_refresh_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = self.lib.ref_refresh_blocks(_ptr(eph), _ptr(iono), int(week), float(sec), _ptr(xyz), nb, nc, sdr_type,
+                                         _ptr(trk), _ptr(out), _ptr(carr))
+        if rc:
+            raise RuntimeError(rc)
+        return out, carr
 
     def compute_code_phase(self, rho0_range, rho0_g, g0, rho1_range, dt, dwrd, prn):
         out = np.zeros(1, dtype=CHAN_DTYPE)

@@ -97,7 +97,32 @@ def main():
                         fs=3000000, nsamp=300000, sample_size=SC08, chunk_len=chunks,
                         sha256=np.array([hashlib.sha256(out.tobytes()).hexdigest()]), n_elems=len(out))
     print("hackrf_chunks:", chunks, len(out))
+    make_refresh_golden()
+
+
+
+
+def make_refresh_golden():
+    """Capture of the reference's host refresh (computeRange/computeCodePhase/gain lines,
+    gps.c:2731-2765) on a moving receiver, for tests/test_refresh.py on boxes without the
+    reference."""
+    from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks
+    r = _oracle.load_ref()
+    tokyo = llh_to_ecef(35.681298, 139.766247, 10.0)
+    week, sec, nb, nc = 2190, 270000.0, 400, 16
+    eph = synth_constellation(nc, tokyo, sec, seed=21)
+    trk = synth_tracks(nc, week, sec, seed=21)
+    iono = synth_iono()
+    xyz = circle_track(tokyo, nb, radius_m=300.0, period_s=45.0)
+    desc, carr = r.refresh_blocks(eph, iono, week, sec, xyz, trk)
+    np.savez_compressed(os.path.join(HERE, "refresh_circle.npz"), eph=eph.view(np.uint8), iono=np.ascontiguousarray(iono).reshape(1).view(np.uint8),
+                        trk=trk.view(np.uint8), xyz=xyz, week=week, sec=sec, desc=desc.view(np.uint8).reshape(nb, nc, -1),
+                        carr_init=carr)
+    print("refresh_circle:", desc.shape, "f_carr range", desc["f_carr"].min(), desc["f_carr"].max())
 
 
 if __name__ == "__main__":
-    main()
+    if "--refresh-only" in sys.argv:
+        make_refresh_golden()
+    else:
+        main()

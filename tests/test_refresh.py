@@ -1,0 +1,144 @@
+"""The batched host refresh (gpsiq_refresh_batch) against the
+reference's own computeRange / computeCodePhase / gain lines (oracle/_ref) and against
+committed captures of them.  Bit-exact: same operand order, same libm."""
+import os
+
+import numpy as np
+import pytest
+
+import gpsiq
+from gpsiq.abi import CHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, SC16, TRACK_DTYPE
+from gpsiq.scenario import (circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOKYO = llh_to_ecef(35.681298, 139.766247, 10.0)        # BASELINE configs 1/2: static lat/lon/h
+WEEK, SEC = 2190, 259200.0 + 3.0 * 3600                 # a Wednesday 03:00 GPS time
+
+FIELDS = ["prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd"]
+
+
+def product_refresh(eph, iono, xyz, trk0, sec=SEC, gain_x2=False, nthreads=0):
+    trk = trk0.copy()
+    gpsiq.track_init(eph, iono, WEEK, sec, xyz[0], trk)
+    carr = trk["carr_phase"].copy()
+    out = gpsiq.refresh_batch(eph, iono, WEEK, sec, xyz[1:], trk, gain_x2=gain_x2, nthreads=nthreads)
+    return out, carr, trk
+
+
+def assert_same(got, want):
+    for f in FIELDS:
+        a, b = got[f], want[f]
+        assert a.tobytes() == b.tobytes(), (f, np.argwhere(a != b)[:5], a[a != b][:3], b[a != b][:3])
+
+
+@pytest.mark.parametrize("iono_kind", ["klobuchar", "flat", "off"])
+def test_range_model_matches_reference(ref, iono_kind):
+    iono = synth_iono(iono_kind)
+    eph = synth_constellation(16, TOKYO, SEC, seed=3)
+    trk = synth_tracks(16, WEEK, SEC)
+    for dt in (0.0, 12.3, 1799.9, 7300.0):
+        t2 = trk.copy()
+        gpsiq.track_init(eph, iono, WEEK, SEC + dt, TOKYO, t2)
+        for c in range(16):
+            r = ref.compute_range(eph[c], iono, WEEK, SEC + dt, TOKYO)
+            assert r["range"] == t2[c]["rho0_range"], (c, dt)
+            if dt == 0.0:
+                assert r["el"] > 0.0
+
+
+@pytest.mark.parametrize("case", ["static", "circle", "fast_circle", "pluto", "iono_off"])
+def test_refresh_batch_is_bit_exact_vs_reference(ref, case):
+    nb, nc = 450, 16                                   # 45 s: crosses the 30 s frame boundary in iword
+    iono = synth_iono("off" if case == "iono_off" else "klobuchar")
+    eph = synth_constellation(nc, TOKYO, SEC, seed=5)
+    trk = synth_tracks(nc, WEEK, SEC)
+    if case == "static":
+        xyz = np.repeat(TOKYO[None, :], nb + 1, axis=0)
+    elif case == "fast_circle":
+        xyz = circle_track(TOKYO, nb, radius_m=2000.0, period_s=20.0)
+    else:
+        xyz = circle_track(TOKYO, nb)
+    want, carr_want = ref.refresh_blocks(eph, iono, WEEK, SEC, xyz, trk, sdr_type=3 if case == "pluto" else 1)
+    got, carr, trk_end = product_refresh(eph, iono, xyz, trk, gain_x2=(case == "pluto"))
+    assert_same(got, want)
+    assert carr.tobytes() == carr_want.tobytes()
+    assert (np.abs(got["f_carr"]) < 12000.0).all() and (got["gain"] > 0.05).all()
+    # continuing a second batch from the carried track state == one long batch
+    more = circle_track(TOKYO, nb + 50)[nb:] if case != "static" else np.repeat(TOKYO[None, :], 51, axis=0)
+    if case in ("static", "circle"):
+        full_xyz = np.concatenate([xyz, more[1:]])
+        want2, _ = ref.refresh_blocks(eph, iono, WEEK, SEC, full_xyz, trk)
+        w, s = WEEK, SEC
+        for _ in range(nb):
+            w, s = ref.inc_gps_time(w, s, 0.1)
+        got2 = gpsiq.refresh_batch(eph, iono, w, s, more[1:], trk_end)
+        assert_same(got2, want2[nb:])
+
+
+def test_reference_circle_csv_when_present(ref):
+    """BASELINE config 4's motion file (reference circle.csv, 3000 rows of t,x,y,z ECEF)."""
+    path = "/root/reference/circle.csv"
+    if not os.path.exists(path):
+        pytest.skip("reference motion file not on this box")
+    xyz = np.loadtxt(path, delimiter=",")[:601, 1:4]
+    eph = synth_constellation(12, xyz[0], SEC, seed=9)
+    trk = synth_tracks(12, WEEK, SEC)
+    iono = synth_iono()
+    want, carr_want = ref.refresh_blocks(eph, iono, WEEK, SEC, xyz, trk)
+    got, carr, _ = product_refresh(eph, iono, xyz, trk)
+    assert_same(got, want)
+    assert carr.tobytes() == carr_want.tobytes()
+
+
+def test_threads_do_not_change_results():
+    eph = synth_constellation(9, TOKYO, SEC, seed=6)
+    trk = synth_tracks(9, WEEK, SEC)
+    xyz = circle_track(TOKYO, 1000)
+    a, _, _ = product_refresh(eph, synth_iono(), xyz, trk, nthreads=1)
+    b, _, _ = product_refresh(eph, synth_iono(), xyz, trk, nthreads=7)
+    c, _, _ = product_refresh(eph, synth_iono(), xyz, trk, nthreads=0)
+    assert a.tobytes() == b.tobytes() == c.tobytes()
+
+
+def test_week_rollover_and_unused_slots(ref):
+    sec = 604800.0 - 1.25                              # the batch crosses the end of the GPS week
+    eph = synth_constellation(5, TOKYO, sec, seed=8)
+    trk = synth_tracks(5, WEEK, sec)
+    trk["prn"][2] = 0
+    xyz = np.repeat(TOKYO[None, :], 41, axis=0)
+    want, _ = ref.refresh_blocks(eph, synth_iono(), WEEK, sec, xyz, trk)
+    got, _, trk_end = product_refresh(eph, synth_iono(), xyz, trk, sec=sec)
+    assert_same(got, want)
+    assert trk_end["rho0_week"][0] == WEEK + 1 and got["prn"][:, 2].max() == 0
+
+
+def test_golden_refresh_capture():
+    """Committed capture of the reference's refresh (runs without /root/reference)."""
+    z = np.load(os.path.join(GOLD, "refresh_circle.npz"))
+    eph = np.ascontiguousarray(z["eph"]).view(EPHEM_DTYPE).reshape(-1)
+    iono = np.ascontiguousarray(z["iono"]).view(IONO_DTYPE).reshape(())
+    trk = np.ascontiguousarray(z["trk"]).view(TRACK_DTYPE).reshape(-1)
+    want = np.ascontiguousarray(z["desc"]).view(CHAN_DTYPE).reshape(z["desc"].shape[0], z["desc"].shape[1])
+    got, carr, _ = product_refresh(eph, iono, z["xyz"], trk, sec=float(z["sec"]))
+    assert_same(got, want)
+    assert carr.tobytes() == z["carr_init"].tobytes()
+
+
+@pytest.mark.gpu
+def test_scenario_to_samples_end_to_end(oracle):
+    """ephemeris -> refresh (host C) -> quantise -> HIP synthesis, dynamic receiver, int16 2.6 Msps
+    (BASELINE config 4 shape): equals the oracle on the same descriptors, and the Doppler the
+    refresh produced is what the circle implies."""
+    fs, ns, nb, nc = 2.6e6, 260000, 20, 16
+    eph = synth_constellation(nc, TOKYO, SEC, seed=12)
+    trk = synth_tracks(nc, WEEK, SEC)
+    xyz = circle_track(TOKYO, nb, radius_m=500.0, period_s=30.0)
+    desc, carr, _ = product_refresh(eph, synth_iono(), xyz, trk)
+    desc["carr_phase"] = carr[None, :]
+    ctx = gpsiq.Context(0)
+    out = ctx.generate_batch(desc, ns, fs, SC16)
+    q = oracle.quantize_blocks(desc, fs, ns)
+    for b in (0, 1, nb // 2, nb - 1):
+        assert np.array_equal(out[b], oracle.block_fixed(q[b], ns, SC16, seq=True))
+    assert np.ptp(desc["f_carr"], axis=0).max() > 50.0      # 105 m/s circle: hundreds of Hz of Doppler swing
+    ctx.close()
