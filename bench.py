@@ -164,6 +164,22 @@ def main():
               f"{nb_h * nsamp / dt / 1e6:.0f} Msamples/s, {nb_h * blk_bytes / dt / 1e9:.1f} GB/s over PCIe", file=sys.stderr)
         ctx.set_descriptors(q)
 
+    if args.sweep and rank == 0:
+        # the host refresh that feeds the kernel (gpsiq_refresh_batch, reference gps.c:2731-2765):
+        # blocks per second on this host, 1 thread and all threads
+        from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks
+        pos = llh_to_ecef(35.681298, 139.766247, 10.0)
+        eph = synth_constellation(nchan, pos, 270000.0, seed=3)
+        xyz = circle_track(pos, 200000)
+        for nt in (1, 0):
+            trk = synth_tracks(nchan, 2190, 270000.0)
+            gpsiq.track_init(eph, synth_iono(), 2190, 270000.0, xyz[0], trk)
+            t1 = time.perf_counter()
+            gpsiq.refresh_batch(eph, synth_iono(), 2190, 270000.0, xyz[1:], trk, nthreads=nt)
+            dt = time.perf_counter() - t1
+            print(f"[refresh] gpsiq_refresh_batch {nchan} ch, {len(xyz) - 1} blocks, threads={'all' if nt == 0 else nt}: "
+                  f"{(len(xyz) - 1) / dt / 1e3:.1f} kblocks/s = {(len(xyz) - 1) * 0.1 / dt:.0f}x real time", file=sys.stderr)
+
     if rank == 0:
         samples_step = nblocks * nsamp * world
         value = samples_step * args.steps / t_max / 1e6

@@ -335,8 +335,11 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
     if (nchan < 1 || nchan > GPSIQ_MAX_CHAN || nblocks < 0) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     if (nblocks == 0) return GPSIQ_OK;
     if (nthreads <= 0) {
+        // one thread per online CPU, but never less than ~1000 blocks (a few ms of work) each
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         nthreads = n > 0 ? (int) n : 1;
+        const int useful = nblocks / 1024 + 1;
+        if (nthreads > useful) nthreads = useful;
     }
     double ant_pat[37];
     for (int i = 0; i < 37; ++i) ant_pat[i] = std::pow(10.0, -kAntPatDb[i] / 20.0);    // gps.c:2688-2689

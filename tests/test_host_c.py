@@ -35,6 +35,8 @@ def test_fifo_under_thread_sanitizer(tmp_path):
     if b.returncode != 0:
         pytest.skip("no ThreadSanitizer runtime here: " + b.stderr[-200:])
     r = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=600)
+    if "FATAL: ThreadSanitizer" in r.stderr or "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot run in this container: " + r.stderr.strip()[-160:])
     assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-2000:]
 
 
