@@ -218,6 +218,51 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
                         const double *xyz, int nblocks, int nchan, int gain_x2,
                         gpsiq_track_t *trk, gpsiq_chan_t *out, int nthreads);
 
+/* ---- navigation message words ------------------- */
+/* The 60-word rolling buffer dwrd[] the sample loop reads its data bits from
+ * (gps.c:2811) is built by the reference from the broadcast ephemeris: eph2sbf()
+ * (gps.c:617-884) packs 3 + 2*25 subframe pages, generateNavMsg() (gps.c:2066-2140) inserts
+ * week number and TOW count, chains the (32,26) parity of computeChecksum() (gps.c:1008-1072)
+ * from word to word and rolls the buffer by one 30 s frame.  Bit-exact restatements: */
+#define GPSIQ_N_SBF_PAGE 53   /* gps.h:55: subframes 1-3 + 25 pages of subframes 4 and 5 */
+#define GPSIQ_N_DWRD_SBF 10
+
+typedef struct gpsiq_nav_eph {    /* the ephem_t fields eph2sbf() packs (gps.h:155-196) */
+    int32_t toe_week, iode, iodc, reserved;
+    double  toe_sec, toc_sec;
+    double  deltan, cuc, cus, cic, cis, crc, crs, ecc, sqrta, m0, omg0, inc0, aop, omgdot, idot;
+    double  af0, af1, af2, tgd;
+} gpsiq_nav_eph_t;
+
+typedef struct gpsiq_nav_utc {    /* ionoutc_t (gps.h:198-206) */
+    int32_t vflg, dtls, tot, wnt;
+    double  alpha[4], beta[4], A0, A1;
+} gpsiq_nav_utc_t;
+
+typedef struct gpsiq_nav_alm_sv { /* almanac_prn_t fields eph2sbf() reads (almanac.h:21-41) */
+    uint32_t svid, valid;
+    int32_t  toa_week, reserved;
+    double   toa_sec, e, delta_i, omegadot, sqrta, omega0, aop, m0, af0, af1;
+} gpsiq_nav_alm_sv_t;
+
+typedef struct gpsiq_nav_state {  /* per channel: chan.dwrd, chan.ipage, chan.g0 */
+    uint32_t dwrd[GPSIQ_N_DWRD];
+    int32_t  ipage, g0_week;
+    double   g0_sec;
+} gpsiq_nav_state_t;
+
+/* computeChecksum(): source bits 31..30 = D29*,D30* of the previous word, bits 29..6 = d1..d24.
+ * nib != 0 solves d23,d24 so that D29 = D30 = 0 (words 2 and 10). */
+uint32_t gpsiq_nav_parity(uint32_t source, int nib);
+/* eph2sbf().  alm = 32 entries or NULL (--disable-almanac: every page-25/almanac slot empty). */
+int gpsiq_nav_subframes(const gpsiq_nav_eph_t *eph, const gpsiq_nav_utc_t *utc,
+                        const gpsiq_nav_alm_sv_t *alm,
+                        uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF]);
+/* generateNavMsg(g = (week, sec), chan, init).  init != 0 at channel allocation (gps.c:2196),
+ * 0 at every 30 s refresh (gps.c:2880-2885).  st->ipage selects the subframe 4/5 page and is advanced. */
+int gpsiq_nav_message(const uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], int week, double sec,
+                      int init, gpsiq_nav_state_t *st);
+
 /* ---- hand-off to fifo.h buffers (gps.c:2847-2865) -------------------------- */
 /* Element-exact restatement of the chunking rules, independent of the FIFO
  * implementation: the caller supplies acquire/enqueue callbacks with the fifo.h

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,  # noqa: F401
-                  SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype, EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE)
+                  SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype, EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE,
+                  NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE, NAV_STATE_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
@@ -77,6 +78,9 @@ _host_alloc = _sig("gpsiq_host_alloc", _vp, _sz)
 _host_free = _sig("gpsiq_host_free", None, _vp)
 _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
+_nav_parity = _sig("gpsiq_nav_parity", C.c_uint32, C.c_uint32, _i)
+_nav_subframes = _sig("gpsiq_nav_subframes", _i, _vp, _vp, _vp, _vp)
+_nav_message = _sig("gpsiq_nav_message", _i, _vp, _i, _d, _i, _vp)
 _num_variants = _sig("gpsiq_num_variants", _i)
 _variant_name = _sig("gpsiq_variant_name", C.c_char_p, _i)
 
@@ -161,6 +165,29 @@ def refresh_batch(eph, iono, week, sec, xyz, trk, gain_x2=False, nthreads=0):
     _check(_refresh_batch(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), len(trk), int(bool(gain_x2)),
                           _p(trk), _p(out), int(nthreads)))
     return out
+
+
+def nav_parity(source, nib=False):
+    return int(_nav_parity(int(source) & 0xFFFFFFFF, int(bool(nib))))
+
+
+def nav_subframes(eph, utc, alm=None):
+    """eph2sbf(): -> uint32[53][10]"""
+    eph = np.ascontiguousarray(eph, dtype=NAV_EPH_DTYPE)
+    utc = np.ascontiguousarray(utc, dtype=NAV_UTC_DTYPE)
+    sbf = np.zeros((53, 10), dtype=np.uint32)
+    a = None if alm is None else np.ascontiguousarray(alm, dtype=NAV_ALM_DTYPE)
+    assert a is None or len(a) == 32
+    _check(_nav_subframes(_p(eph), _p(utc), None if a is None else _p(a), _p(sbf)))
+    return sbf
+
+
+def nav_message(sbf, week, sec, init, state):
+    """generateNavMsg(): state (NAV_STATE_DTYPE scalar array of shape (1,)) is updated in place."""
+    sbf = np.ascontiguousarray(sbf, dtype=np.uint32)
+    assert sbf.shape == (53, 10) and state.dtype == NAV_STATE_DTYPE and state.size == 1
+    _check(_nav_message(_p(sbf), int(week), float(sec), int(bool(init)), _p(state)))
+    return state
 
 
 class Context:

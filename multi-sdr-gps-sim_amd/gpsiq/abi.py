@@ -40,3 +40,18 @@ assert IONO_DTYPE.itemsize == 72
 TRACK_DTYPE = np.dtype([("prn", "<i4"), ("g0_week", "<i4"), ("g0_sec", "<f8"), ("rho0_week", "<i4"), ("rho0_sec", "<f8"),
                         ("rho0_range", "<f8"), ("carr_phase", "<f8"), ("dwrd", "<u4", (N_DWRD,))], align=True)
 assert TRACK_DTYPE.itemsize == 288
+
+# navigation message structs (include/gpsiq.h)
+NAV_EPH_DTYPE = np.dtype([("toe_week", "<i4"), ("iode", "<i4"), ("iodc", "<i4"), ("reserved", "<i4"),
+                          ("toe_sec", "<f8"), ("toc_sec", "<f8")] +
+                         [(f, "<f8") for f in ["deltan", "cuc", "cus", "cic", "cis", "crc", "crs", "ecc", "sqrta", "m0", "omg0",
+                                                "inc0", "aop", "omgdot", "idot", "af0", "af1", "af2", "tgd"]], align=True)
+assert NAV_EPH_DTYPE.itemsize == 184
+NAV_UTC_DTYPE = np.dtype([("vflg", "<i4"), ("dtls", "<i4"), ("tot", "<i4"), ("wnt", "<i4"),
+                          ("alpha", "<f8", (4,)), ("beta", "<f8", (4,)), ("A0", "<f8"), ("A1", "<f8")], align=True)
+assert NAV_UTC_DTYPE.itemsize == 96
+NAV_ALM_DTYPE = np.dtype([("svid", "<u4"), ("valid", "<u4"), ("toa_week", "<i4"), ("reserved", "<i4"), ("toa_sec", "<f8")] +
+                         [(f, "<f8") for f in ["e", "delta_i", "omegadot", "sqrta", "omega0", "aop", "m0", "af0", "af1"]], align=True)
+assert NAV_ALM_DTYPE.itemsize == 96
+NAV_STATE_DTYPE = np.dtype([("dwrd", "<u4", (N_DWRD,)), ("ipage", "<i4"), ("g0_week", "<i4"), ("g0_sec", "<f8")], align=True)
+assert NAV_STATE_DTYPE.itemsize == 256

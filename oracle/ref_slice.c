@@ -26,6 +26,8 @@
 
 #include "sdr.h"     /* -> gps-sim.h -> gps.h ; NUM_IQ_SAMPLES, IQ_BUFFER_SIZE, HACKRF_TRANSFER_BUFFER_SIZE */
 #include "fifo.h"    /* struct iq_buf, fifo_acquire, fifo_enqueue */
+#include "gui.h"     /* status_color_t, gui_status_wprintw() (called by validate_parityN) */
+#include "almanac.h" /* almanac_gps_t (eph2sbf argument) */
 
 #include "../include/gpsiq.h"   /* gpsiq_chan_t: the descriptor layout the tests pass in */
 
@@ -47,6 +49,10 @@ static int ref_nchan = 12;
 #include "ref_iono.inc"              /* gps.c:1893-1964 ionosphericDelay() */
 #include "ref_range.inc"             /* gps.c:1972-2026 computeRange() */
 #include "ref_computecodephase.inc"  /* gps.c:2033-2064 computeCodePhase() */
+#include "ref_sbfid.inc"             /* gps.c:224-234  sbf4_svId[], sbf5_svId[] */
+#include "ref_eph2sbf.inc"           /* gps.c:617-884  eph2sbf() */
+#include "ref_parity.inc"            /* gps.c:890-1072 countBits, decode_wordN, validate_parityN, computeChecksum */
+#include "ref_navmsg.inc"            /* gps.c:2066-2140 generateNavMsg() */
 
 /* ---- capturing fifo (the tap SURVEY.md section 0 fact 6 asks for) --------- */
 static struct {
@@ -316,5 +322,74 @@ int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in,
         grx = incGpsTime(grx, 0.1);                                 /* gps.c:2932 */
     }
     (void) path_loss; (void) ant_gain; (void) ibs; (void) ieph;
+    return 0;
+}
+
+/* ---- navigation message --------------------------------------- */
+/* validate_parityN() reports a word whose parity fails its two independent checkers
+ * (gps.c:926-1001, 907-924) through the TUI; here the report is counted. */
+static int parity_complaints;
+void gui_status_wprintw(status_color_t clr, const char *fmt, ...) { (void) clr; (void) fmt; parity_complaints++; }
+int ref_parity_complaints(void) { return parity_complaints; }
+
+unsigned ref_nav_parity(unsigned source, int nib) { return (unsigned) computeChecksum(source, nib); }
+
+static void load_nav_eph(ephem_t *e, const gpsiq_nav_eph_t *in)
+{
+    memset(e, 0, sizeof *e);
+    e->vflg = 1;
+    e->toe.week = in->toe_week; e->toe.sec = in->toe_sec; e->toc.week = in->toe_week; e->toc.sec = in->toc_sec;
+    e->iode = in->iode; e->iodc = in->iodc;
+    e->deltan = in->deltan; e->cuc = in->cuc; e->cus = in->cus; e->cic = in->cic; e->cis = in->cis;
+    e->crc = in->crc; e->crs = in->crs; e->ecc = in->ecc; e->sqrta = in->sqrta; e->m0 = in->m0;
+    e->omg0 = in->omg0; e->inc0 = in->inc0; e->aop = in->aop; e->omgdot = in->omgdot; e->idot = in->idot;
+    e->af0 = in->af0; e->af1 = in->af1; e->af2 = in->af2; e->tgd = in->tgd;
+}
+
+int ref_nav_subframes(const gpsiq_nav_eph_t *eph_in, const gpsiq_nav_utc_t *utc, const gpsiq_nav_alm_sv_t *alm_in,
+                      uint32_t *out /* [53][10] */)
+{
+    static ephem_t e; static ionoutc_t io; static almanac_gps_t alm;
+    static unsigned long sbf[N_SBF_PAGE][N_DWRD_SBF];
+    load_nav_eph(&e, eph_in);
+    memset(&io, 0, sizeof io);
+    io.enable = 1; io.vflg = utc->vflg;
+    io.alpha0 = utc->alpha[0]; io.alpha1 = utc->alpha[1]; io.alpha2 = utc->alpha[2]; io.alpha3 = utc->alpha[3];
+    io.beta0 = utc->beta[0]; io.beta1 = utc->beta[1]; io.beta2 = utc->beta[2]; io.beta3 = utc->beta[3];
+    io.A0 = utc->A0; io.A1 = utc->A1; io.dtls = utc->dtls; io.tot = utc->tot; io.wnt = utc->wnt;
+    memset(&alm, 0, sizeof alm);
+    for (int sv = 0; alm_in && sv < MAX_SAT; sv++) {
+        almanac_prn_t *a = &alm.sv[sv];
+        a->svid = (unsigned short) alm_in[sv].svid; a->valid = alm_in[sv].valid;
+        a->toa.week = alm_in[sv].toa_week; a->toa.sec = alm_in[sv].toa_sec;
+        a->e = alm_in[sv].e; a->delta_i = alm_in[sv].delta_i; a->omegadot = alm_in[sv].omegadot;
+        a->sqrta = alm_in[sv].sqrta; a->omega0 = alm_in[sv].omega0; a->aop = alm_in[sv].aop;
+        a->m0 = alm_in[sv].m0; a->af0 = alm_in[sv].af0; a->af1 = alm_in[sv].af1;
+    }
+    memset(sbf, 0, sizeof sbf);
+    eph2sbf(e, io, &alm, sbf);
+    for (int p = 0; p < N_SBF_PAGE; p++)
+        for (int w = 0; w < N_DWRD_SBF; w++) {
+            if (sbf[p][w] >> 32) return -2;          /* every word must fit 32 bits */
+            out[p * N_DWRD_SBF + w] = (uint32_t) sbf[p][w];
+        }
+    return 0;
+}
+
+int ref_nav_message(const uint32_t *sbf_in /* [53][10] */, int week, double sec, int init, gpsiq_nav_state_t *st)
+{
+    static channel_t ch;
+    gpstime_t g = { week, sec };
+    memset(&ch, 0, sizeof ch);
+    for (int p = 0; p < N_SBF_PAGE; p++)
+        for (int w = 0; w < N_DWRD_SBF; w++) ch.sbf[p][w] = sbf_in[p * N_DWRD_SBF + w];
+    for (int k = 0; k < N_DWRD; k++) ch.dwrd[k] = st->dwrd[k];
+    ch.ipage = st->ipage;
+    generateNavMsg(g, &ch, init);
+    for (int k = 0; k < N_DWRD; k++) {
+        if (ch.dwrd[k] >> 32) return -2;
+        st->dwrd[k] = (uint32_t) ch.dwrd[k];
+    }
+    st->ipage = ch.ipage; st->g0_week = ch.g0.week; st->g0_sec = ch.g0.sec;
     return 0;
 }

@@ -15,7 +15,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 import sys
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
 from gpsiq.abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, elem_dtype,  # noqa: E402
-                       EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE)
+                       EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE, NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE,
+                       NAV_STATE_DTYPE)
 
 
 def build():
@@ -183,6 +184,32 @@ class Ref:
         if rc:
             raise RuntimeError(rc)
         return out, carr
+
+    def nav_parity(self, source, nib=False):
+        self.lib.ref_nav_parity.restype = C.c_uint
+        return int(self.lib.ref_nav_parity(C.c_uint(int(source) & 0xFFFFFFFF), int(bool(nib))))
+
+    def parity_complaints(self):
+        return int(self.lib.ref_parity_complaints())
+
+    def nav_subframes(self, eph, utc, alm=None):
+        eph = np.ascontiguousarray(eph, dtype=NAV_EPH_DTYPE)
+        utc = np.ascontiguousarray(utc, dtype=NAV_UTC_DTYPE)
+        a = None if alm is None else np.ascontiguousarray(alm, dtype=NAV_ALM_DTYPE)
+        sbf = np.zeros((53, 10), dtype=np.uint32)
+        self.lib.ref_nav_subframes.argtypes = [C.c_void_p] * 4
+        rc = self.lib.ref_nav_subframes(_ptr(eph), _ptr(utc), None if a is None else _ptr(a), _ptr(sbf))
+        if rc:
+            raise RuntimeError(rc)
+        return sbf
+
+    def nav_message(self, sbf, week, sec, init, state):
+        sbf = np.ascontiguousarray(sbf, dtype=np.uint32)
+        self.lib.ref_nav_message.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        rc = self.lib.ref_nav_message(_ptr(sbf), int(week), float(sec), int(bool(init)), _ptr(state))
+        if rc:
+            raise RuntimeError(rc)
+        return state
 
     def compute_code_phase(self, rho0_range, rho0_g, g0, rho1_range, dt, dwrd, prn):
         out = np.zeros(1, dtype=CHAN_DTYPE)

@@ -121,8 +121,35 @@ def make_refresh_golden():
     print("refresh_circle:", desc.shape, "f_carr range", desc["f_carr"].min(), desc["f_carr"].max())
 
 
+def make_nav_golden():
+    """Capture of the reference's eph2sbf / generateNavMsg (gps.c:617-884, 2066-2140)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_nav import rand_alm, rand_eph, rand_utc
+    from gpsiq.abi import NAV_STATE_DTYPE
+    r = _oracle.load_ref()
+    rng = np.random.default_rng(2025)
+    e, u, alm = rand_eph(rng), rand_utc(rng), rand_alm(rng)
+    sbf = r.nav_subframes(e, u, alm)
+    week, sec = 2190, 270013.7
+    st = np.zeros(1, dtype=NAV_STATE_DTYPE)
+    seq = []
+    r.nav_message(sbf, week, sec, True, st)
+    seq.append(st[0]["dwrd"].copy())
+    for k in range(1, 30):
+        r.nav_message(sbf, week, sec + 30.0 * k, False, st)
+        seq.append(st[0]["dwrd"].copy())
+    assert r.parity_complaints() == 0
+    np.savez_compressed(os.path.join(HERE, "nav_words.npz"), eph=np.ascontiguousarray(e).reshape(1).view(np.uint8),
+                        utc=np.ascontiguousarray(u).reshape(1).view(np.uint8), alm=alm.view(np.uint8), sbf=sbf,
+                        week=week, sec=sec, dwrd_seq=np.stack(seq))
+    print("nav_words:", sbf.shape, len(seq), "frames")
+
+
 if __name__ == "__main__":
     if "--refresh-only" in sys.argv:
         make_refresh_golden()
+    elif "--nav-only" in sys.argv:
+        make_nav_golden()
     else:
         main()
+        make_nav_golden()
