@@ -263,6 +263,31 @@ int gpsiq_nav_subframes(const gpsiq_nav_eph_t *eph, const gpsiq_nav_utc_t *utc,
 int gpsiq_nav_message(const uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], int week, double sec,
                       int init, gpsiq_nav_state_t *st);
 
+/* ---- RINEX navigation files ---------------------- */
+/* readRinex2() (gps.c:1131-1505) / readRinex3() (gps.c:1512-1891): fixed-column parse of a
+ * GPS broadcast-ephemeris file (plain or gzip), records grouped into sets whenever the time
+ * of clock advances by more than an hour, at most GPSIQ_EPHEM_SETS sets of 32 satellites. */
+#define GPSIQ_EPHEM_SETS 13   /* gps.h:108 EPHEM_ARRAY_SIZE */
+#define GPSIQ_MAX_SAT    32   /* gps.h:33 */
+
+typedef struct gpsiq_rinex_eph {  /* one ephem_t (gps.h:155-196), in the groupings the other entry points take */
+    int32_t vflg, sva, svh, code, flag;       /* validity, URA index, health (MSB set as the reference does), L2 code, L2P flag */
+    int32_t t_y, t_m, t_d, t_hh, t_mm;        /* calendar time of clock */
+    double  t_sec, fit;
+    int32_t toc_week, reserved;
+    gpsiq_ephem_t   orbit;                    /* what gpsiq_refresh_batch() takes (incl. working variables A, n, sq1e2, omgkdot) */
+    gpsiq_nav_eph_t nav;                      /* what gpsiq_nav_subframes() takes */
+} gpsiq_rinex_eph_t;
+
+/* version: 2 or 3.  eph is [GPSIQ_EPHEM_SETS][GPSIQ_MAX_SAT]; utc receives the header's
+ * ionosphere/UTC parameters (vflg set when all four header records were present, gps.c:1257-1259).
+ * Returns the number of ephemeris sets (>= 0), or the reference's error codes: -1 cannot open,
+ * -2 wrong RINEX version for this reader, -3 not a GPS navigation file. */
+int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsiq_nav_utc_t *utc);
+/* The set gps_thread_ep() would use for a start time (gps.c:2588-2608): first set with a
+ * satellite whose toc is within one hour of (week, sec); -1 if none. */
+int gpsiq_rinex_select(const gpsiq_rinex_eph_t *eph, int nsets, int week, double sec);
+
 /* ---- hand-off to fifo.h buffers (gps.c:2847-2865) -------------------------- */
 /* Element-exact restatement of the chunking rules, independent of the FIFO
  * implementation: the caller supplies acquire/enqueue callbacks with the fifo.h

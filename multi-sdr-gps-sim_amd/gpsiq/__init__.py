@@ -12,7 +12,7 @@ import numpy as np
 
 from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,  # noqa: F401
                   SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype, EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE,
-                  NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE, NAV_STATE_DTYPE)
+                  NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE, NAV_STATE_DTYPE, RINEX_EPH_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
@@ -81,6 +81,8 @@ _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, 
 _nav_parity = _sig("gpsiq_nav_parity", C.c_uint32, C.c_uint32, _i)
 _nav_subframes = _sig("gpsiq_nav_subframes", _i, _vp, _vp, _vp, _vp)
 _nav_message = _sig("gpsiq_nav_message", _i, _vp, _i, _d, _i, _vp)
+_rinex_read = _sig("gpsiq_rinex_read", _i, C.c_char_p, _i, _vp, _vp)
+_rinex_select = _sig("gpsiq_rinex_select", _i, _vp, _i, _i, _d)
 _num_variants = _sig("gpsiq_num_variants", _i)
 _variant_name = _sig("gpsiq_variant_name", C.c_char_p, _i)
 
@@ -188,6 +190,20 @@ def nav_message(sbf, week, sec, init, state):
     assert sbf.shape == (53, 10) and state.dtype == NAV_STATE_DTYPE and state.size == 1
     _check(_nav_message(_p(sbf), int(week), float(sec), int(bool(init)), _p(state)))
     return state
+
+
+def rinex_read(path, version=2):
+    """readRinex2/readRinex3 -> (eph[13][32] RINEX_EPH_DTYPE, utc NAV_UTC_DTYPE, nsets).  nsets < 0:
+    the reference's error codes (-1 open, -2 version, -3 file type)."""
+    eph = np.zeros((13, 32), dtype=RINEX_EPH_DTYPE)
+    utc = np.zeros(1, dtype=NAV_UTC_DTYPE)
+    n = _rinex_read(os.fsencode(path), int(version), _p(eph), _p(utc))
+    return eph, utc[0], n
+
+
+def rinex_select(eph, nsets, week, sec):
+    eph = np.ascontiguousarray(eph, dtype=RINEX_EPH_DTYPE)
+    return int(_rinex_select(_p(eph), int(nsets), int(week), float(sec)))
 
 
 class Context:

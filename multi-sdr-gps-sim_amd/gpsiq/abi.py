@@ -55,3 +55,10 @@ NAV_ALM_DTYPE = np.dtype([("svid", "<u4"), ("valid", "<u4"), ("toa_week", "<i4")
 assert NAV_ALM_DTYPE.itemsize == 96
 NAV_STATE_DTYPE = np.dtype([("dwrd", "<u4", (N_DWRD,)), ("ipage", "<i4"), ("g0_week", "<i4"), ("g0_sec", "<f8")], align=True)
 assert NAV_STATE_DTYPE.itemsize == 256
+
+RINEX_EPH_DTYPE = np.dtype([("vflg", "<i4"), ("sva", "<i4"), ("svh", "<i4"), ("code", "<i4"), ("flag", "<i4"),
+                            ("t_y", "<i4"), ("t_m", "<i4"), ("t_d", "<i4"), ("t_hh", "<i4"), ("t_mm", "<i4"),
+                            ("t_sec", "<f8"), ("fit", "<f8"), ("toc_week", "<i4"), ("reserved", "<i4"),
+                            ("orbit", EPHEM_DTYPE), ("nav", NAV_EPH_DTYPE)], align=True)
+assert RINEX_EPH_DTYPE.itemsize == 432
+EPHEM_SETS, MAX_SAT = 13, 32

@@ -161,3 +161,95 @@ def circle_track(centre_xyz, nblocks, radius_m=100.0, period_s=60.0, dt=0.1):
     t = np.arange(nblocks + 1) * dt
     ang = 2.0 * np.pi * t / period_s
     return centre_xyz[None, :] + radius_m * (np.cos(ang)[:, None] * north[None, :] + np.sin(ang)[:, None] * east[None, :])
+
+
+# ---- synthetic RINEX navigation files (the reference ships none) ---------------------------
+def _d19(x):
+    return ("%19.12E" % x).replace("E", "D")
+
+
+def _d12(x):
+    return ("%12.4E" % x).replace("E", "D")
+
+
+def gps_to_calendar(week, sec):
+    import datetime
+    t = datetime.datetime(1980, 1, 6) + datetime.timedelta(weeks=int(week), seconds=float(sec))
+    return t.year, t.month, t.day, t.hour, t.minute, t.second
+
+
+def write_rinex_nav(path, records, utc=None, version=2, gzip_it=False, extra_comment=True):
+    """records: list of dicts with keys prn, week, toc_sec + the broadcast parameters
+    (af0 af1 af2 iode crs deltan m0 cuc ecc cus sqrta toe_sec cic omg0 cis inc0 crc aop omgdot idot
+    code toe_week flag sva svh tgd iodc tx fit), written in file order.  utc: dict with alpha[4],
+    beta[4], A0, A1, tot, wnt, dtls or None (then the header carries no iono/UTC records).
+    Column layout per the RINEX 2.10 / 3.0x navigation message file definition."""
+    v3 = version == 3
+    L = []
+
+    def hdr(body, label):
+        L.append("%-60s%s" % (body, label))
+
+    if v3:
+        hdr("     3.02           N: GNSS NAV DATA    G: GPS", "RINEX VERSION / TYPE")
+    else:
+        hdr("     2.10           N: GPS NAV DATA", "RINEX VERSION / TYPE")
+    hdr("gpsiq scenario      synthetic           20250215 000000 UTC", "PGM / RUN BY / DATE")
+    if extra_comment:
+        hdr("synthetic constellation for parity tests", "COMMENT")
+    if utc is not None:
+        if v3:
+            hdr("GPSA " + "".join(_d12(a) for a in utc["alpha"]), "IONOSPHERIC CORR")
+            hdr("GPSB " + "".join(_d12(b) for b in utc["beta"]), "IONOSPHERIC CORR")
+            hdr("GPUT " + ("%17.10E" % utc["A0"]).replace("E", "D") + ("%16.9E" % utc["A1"]).replace("E", "D")
+                + "%7d%5d" % (utc["tot"], utc["wnt"]), "TIME SYSTEM CORR")
+        else:
+            hdr("  " + "".join(_d12(a) for a in utc["alpha"]), "ION ALPHA")
+            hdr("  " + "".join(_d12(b) for b in utc["beta"]), "ION BETA")
+            hdr("   " + _d19(utc["A0"]) + _d19(utc["A1"]) + "%9d%9d" % (utc["tot"], utc["wnt"]), "DELTA-UTC: A0,A1,T,W")
+        hdr("%6d" % utc["dtls"], "LEAP SECONDS")
+    hdr("", "END OF HEADER")
+    pad = "    " if v3 else "   "
+    for r in records:
+        y, mo, d, hh, mi, ss = gps_to_calendar(r["week"], r["toc_sec"])
+        if v3:
+            head = "G%02d %04d %02d %02d %02d %02d %02d" % (r["prn"], y, mo, d, hh, mi, ss)
+        else:
+            head = "%2d %02d %2d %2d %2d %2d%5.1f" % (r["prn"], y % 100, mo, d, hh, mi, float(ss))
+        L.append(head + _d19(r["af0"]) + _d19(r["af1"]) + _d19(r["af2"]))
+        for keys in (("iode", "crs", "deltan", "m0"), ("cuc", "ecc", "cus", "sqrta"), ("toe_sec", "cic", "omg0", "cis"),
+                     ("inc0", "crc", "aop", "omgdot"), ("idot", "code", "toe_week", "flag"), ("sva", "svh", "tgd", "iodc"),
+                     ("tx", "fit")):
+            L.append(pad + "".join(_d19(float(r[k])) for k in keys))
+    data = ("\n".join(L) + "\n").encode("ascii")
+    if gzip_it:
+        import gzip
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+    return path
+
+
+def synth_rinex_records(nsat, xyz, week, sec, seed=1, sets=2):
+    """Broadcast records for nsat satellites visible at (week, sec), repeated for `sets`
+    consecutive two-hour issues (so the reader has to group them into hourly sets)."""
+    eph = synth_constellation(nsat, xyz, sec, seed=seed)
+    rng = SplitMix64(seed + 5)
+    recs = []
+    for k in range(sets):
+        toc = float(int(sec / 7200.0) * 7200 + 7200 * k)
+        for c in range(nsat):
+            e = eph[c]
+            # keep the orbit continuous across issues: advance the mean anomaly to the new toe
+            m0 = float(e["m0"] + e["n"] * (toc - e["toe_sec"]))
+            r = dict(prn=c + 1, week=week, toc_sec=toc, af0=float(e["af0"]), af1=float(e["af1"]), af2=0.0,
+                     iode=(17 + c + k) % 256, crs=float(e["crs"]), deltan=float(e["n"] - np.sqrt(GM_EARTH / e["A"] ** 3)),
+                     m0=m0, cuc=float(e["cuc"]), ecc=float(e["ecc"]), cus=float(e["cus"]), sqrta=float(e["sqrta"]),
+                     toe_sec=toc, cic=float(e["cic"]), omg0=float(e["omg0"]), cis=float(e["cis"]), inc0=float(e["inc0"]),
+                     crc=float(e["crc"]), aop=float(e["aop"]), omgdot=float(e["omgkdot"] + OMEGA_EARTH), idot=float(e["idot"]),
+                     code=1, toe_week=week, flag=0, sva=int(rng.below(4)), svh=0 if c != 3 else 5, tgd=float(e["tgd"]),
+                     iodc=(17 + c + k) % 256 + 256, tx=toc - 18.0, fit=4.0)
+            recs.append(r)
+    return recs

@@ -38,14 +38,20 @@ static int ref_nchan = 12;
 #undef MAX_CHAN
 #define MAX_CHAN ref_nchan
 
+#include <zlib.h>
+#include "ref_rinexdate.inc"         /* gps.c:138      rinex_date[] */
 #include "ref_tables.inc"            /* gps.c:145-213  sinTable512, cosTable512 */
 #include "ref_antpat.inc"            /* gps.c:216-221  ant_pat_db[] */
 #include "ref_vec.inc"               /* gps.c:243-266  subVect, normVect, dotProd */
 #include "ref_codegen.inc"           /* gps.c:272-309  codegen() */
+#include "ref_date2gps.inc"          /* gps.c:315-337  date2gps() */
 #include "ref_geo.inc"               /* gps.c:361-499  xyz2llh, llh2xyz, ltcmat, ecef2neu, neu2azel */
 #include "ref_satpos.inc"            /* gps.c:508-611  satpos() */
 #include "ref_subgpstime.inc"        /* gps.c:1096-1103 subGpsTime() */
+#include "ref_expd.inc"              /* gps.c:1079-1094 replaceExpDesignator() */
 #include "ref_incgpstime.inc"        /* gps.c:1105-1124 incGpsTime() */
+#include "ref_rinex2.inc"            /* gps.c:1131-1505 readRinex2() */
+#include "ref_rinex3.inc"            /* gps.c:1512-1891 readRinex3() */
 #include "ref_iono.inc"              /* gps.c:1893-1964 ionosphericDelay() */
 #include "ref_range.inc"             /* gps.c:1972-2026 computeRange() */
 #include "ref_computecodephase.inc"  /* gps.c:2033-2064 computeCodePhase() */
@@ -392,4 +398,42 @@ int ref_nav_message(const uint32_t *sbf_in /* [53][10] */, int week, double sec,
     }
     st->ipage = ch.ipage; st->g0_week = ch.g0.week; st->g0_sec = ch.g0.sec;
     return 0;
+}
+
+/* ---- RINEX readers --------------------------------------------- */
+int ref_read_rinex(int version, const char *path, gpsiq_rinex_eph_t *out /* [13][32] */, gpsiq_nav_utc_t *utc,
+                   char *date21)
+{
+    static ephem_t eph[EPHEM_ARRAY_SIZE][MAX_SAT];
+    ionoutc_t io;
+    memset(eph, 0, sizeof eph);
+    memset(&io, 0, sizeof io);
+    ref_nchan = MAX_SAT;   /* MAX_CHAN is not used by the readers; keep the macro harmless */
+    int n = version == 3 ? readRinex3(eph, &io, path) : readRinex2(eph, &io, path);
+    memset(out, 0, sizeof *out * EPHEM_ARRAY_SIZE * 32);
+    for (int i = 0; i < EPHEM_ARRAY_SIZE; i++)
+        for (int sv = 0; sv < 32; sv++) {
+            const ephem_t *e = &eph[i][sv];
+            gpsiq_rinex_eph_t *o = &out[i * 32 + sv];
+            if (!e->vflg) continue;
+            o->vflg = 1; o->sva = e->sva; o->svh = e->svh; o->code = e->code; o->flag = e->flag;
+            o->t_y = e->t.y; o->t_m = e->t.m; o->t_d = e->t.d; o->t_hh = e->t.hh; o->t_mm = e->t.mm; o->t_sec = e->t.sec;
+            o->fit = e->fit; o->toc_week = e->toc.week;
+            gpsiq_ephem_t *b = &o->orbit; gpsiq_nav_eph_t *v = &o->nav;
+            b->toe_sec = v->toe_sec = e->toe.sec; b->toc_sec = v->toc_sec = e->toc.sec;
+            v->toe_week = e->toe.week; v->iode = e->iode; v->iodc = e->iodc;
+            b->m0 = v->m0 = e->m0; b->n = e->n; b->ecc = v->ecc = e->ecc; b->sqrta = v->sqrta = e->sqrta;
+            b->sq1e2 = e->sq1e2; b->A = e->A; b->aop = v->aop = e->aop; b->omg0 = v->omg0 = e->omg0;
+            b->omgkdot = e->omgkdot; v->omgdot = e->omgdot; b->inc0 = v->inc0 = e->inc0; b->idot = v->idot = e->idot;
+            b->cuc = v->cuc = e->cuc; b->cus = v->cus = e->cus; b->cic = v->cic = e->cic; b->cis = v->cis = e->cis;
+            b->crc = v->crc = e->crc; b->crs = v->crs = e->crs; v->deltan = e->deltan;
+            b->af0 = v->af0 = e->af0; b->af1 = v->af1 = e->af1; b->af2 = v->af2 = e->af2; b->tgd = v->tgd = e->tgd;
+        }
+    memset(utc, 0, sizeof *utc);
+    utc->vflg = io.vflg; utc->dtls = io.dtls; utc->tot = io.tot; utc->wnt = io.wnt;
+    utc->alpha[0] = io.alpha0; utc->alpha[1] = io.alpha1; utc->alpha[2] = io.alpha2; utc->alpha[3] = io.alpha3;
+    utc->beta[0] = io.beta0; utc->beta[1] = io.beta1; utc->beta[2] = io.beta2; utc->beta[3] = io.beta3;
+    utc->A0 = io.A0; utc->A1 = io.A1;
+    if (date21) memcpy(date21, rinex_date, 21);
+    return n;
 }

@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
 from gpsiq.abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, elem_dtype,  # noqa: E402
                        EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE, NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE,
-                       NAV_STATE_DTYPE)
+                       NAV_STATE_DTYPE, RINEX_EPH_DTYPE)
 
 
 def build():
@@ -210,6 +210,14 @@ class Ref:
         if rc:
             raise RuntimeError(rc)
         return state
+
+    def read_rinex(self, path, version=2):
+        eph = np.zeros((13, 32), dtype=RINEX_EPH_DTYPE)
+        utc = np.zeros(1, dtype=NAV_UTC_DTYPE)
+        date = C.create_string_buffer(21)
+        self.lib.ref_read_rinex.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_char_p]
+        n = self.lib.ref_read_rinex(int(version), os.fsencode(path), _ptr(eph), _ptr(utc), date)
+        return eph, utc[0], n
 
     def compute_code_phase(self, rho0_range, rho0_g, g0, rho1_range, dt, dwrd, prn):
         out = np.zeros(1, dtype=CHAN_DTYPE)

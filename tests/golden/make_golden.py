@@ -145,11 +145,28 @@ def make_nav_golden():
     print("nav_words:", sbf.shape, len(seq), "frames")
 
 
+def make_rinex_golden():
+    """A synthetic RINEX 2 file (input data) and what the reference's readRinex2 makes of it."""
+    from gpsiq.scenario import llh_to_ecef, synth_rinex_records, write_rinex_nav
+    r = _oracle.load_ref()
+    tokyo = llh_to_ecef(35.681298, 139.766247, 10.0)
+    utc = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
+               A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=2190, dtls=18)
+    recs = synth_rinex_records(10, tokyo, 2190, 270000.0, seed=77, sets=2)
+    path = write_rinex_nav(os.path.join(HERE, "synth_static.21n"), recs, utc, 2)
+    eph, u, n = r.read_rinex(path, 2)
+    np.savez_compressed(os.path.join(HERE, "rinex_parsed.npz"), eph=eph.view(np.uint8), utc=np.asarray(u).reshape(1).view(np.uint8), nsets=n)
+    print("rinex:", n, "sets,", int(eph["vflg"].sum()), "records")
+
+
 if __name__ == "__main__":
-    if "--refresh-only" in sys.argv:
+    if "--rinex-only" in sys.argv:
+        make_rinex_golden()
+    elif "--refresh-only" in sys.argv:
         make_refresh_golden()
     elif "--nav-only" in sys.argv:
         make_nav_golden()
     else:
         main()
         make_nav_golden()
+        make_rinex_golden()
