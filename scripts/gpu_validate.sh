@@ -5,4 +5,5 @@ mkdir -p gpurun_out
 tail -4 gpurun_out/pytest_gpu.log
 ( timeout 900 python -m pytest tests -m "not gpu" -x -q 2>&1 | tail -5 ) > gpurun_out/pytest_cpu_on_gpubox.log 2>&1
 tail -3 gpurun_out/pytest_cpu_on_gpubox.log
+( timeout 300 python __graft_entry__.py smoke ) > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 ( timeout 600 python bench.py --sweep --no-cpu-baseline --steps 10 ) > gpurun_out/bench1.log 2>&1; grep -E "refresh|host-dst|sweep" gpurun_out/bench1.log
