@@ -16,7 +16,10 @@
  *   gps.c:272-309    codegen() C/A sequence             -> gpsiq_prn_code()   (table built in-library)
  *   gps.c:145-213    sinTable512 / cosTable512          -> gpsiq_carrier_table() (table built in-library)
  *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
- *   gps.c:2731-2765  per-block host refresh (next row)  -> gpsiq_refresh_batch()
+ *   gps.c:2731-2765  per-block host refresh              -> gpsiq_refresh_batch(), gpsiq_track_init()
+ *   gps.c:617-884, 1008-1072, 2066-2140  nav words     -> gpsiq_nav_subframes/_message/_parity()
+ *   gps.c:1131-1891  readRinex2 / readRinex3             -> gpsiq_rinex_read(), gpsiq_rinex_select()
+ *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
  *
  * NCO definition ("identical fixed-point NCO word widths", BASELINE.json north_star).
  * The reference advances both NCOs with sequential double additions (gps.h:17
