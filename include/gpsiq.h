@@ -146,13 +146,15 @@ int gpsiq_generate_block(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
 
 /* Run-ahead form of the 10 Hz loop (gps.c:2703): ch is [nblocks][nchan], all blocks
  * prepared by the host model first (it never reads the loop's output except
- * carr_phase).  Block 0 seeds the carrier from ch[0][i].carr_phase; later blocks
- * continue exactly, re-seeding a slot from its carr_phase only when its prn changes.
+ * carr_phase).  Block 0 seeds the carrier from ch[0][i].carr_phase under the same rule as
+ * gpsiq_generate_block (the value handed out by the previous call continues exactly); later
+ * blocks continue exactly, re-seeding a slot from its carr_phase only when its prn changes.
  * dst receives nblocks*2*nsamp elements; dst_is_device != 0 means dst is a device
- * pointer on the context's device (no D2H). */
+ * pointer on the context's device (no D2H).  carr_phase_out[nchan] (may be NULL) receives
+ * the carrier phase after the last block, to be put into the next batch's block 0. */
 int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan,
                          int nsamp, double fs, int sample_size,
-                         void *dst, int dst_is_device);
+                         void *dst, int dst_is_device, double *carr_phase_out);
 
 /* Page-locked host memory for fifo buffers (hipHostMalloc): a device-to-host copy into it
  * is a single DMA.  NULL on failure.  Usable as the allocator of host/fifo.c. */

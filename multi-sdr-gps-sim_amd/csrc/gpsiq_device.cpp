@@ -304,7 +304,7 @@ int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int 
 }
 
 int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp,
-                         double fs, int sample_size, void *dst, int dst_is_device)
+                         double fs, int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
 {
     if (!c || !ch || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
@@ -317,7 +317,13 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     for (int b = 0; b < nblocks; ++b) {
         for (int i = 0; i < nchan; ++i) {
             const gpsiq_chan_t &d = ch[(size_t) b * nchan + i];
-            const bool cont = b > 0 && d.prn > 0 && prev_prn[i] == d.prn;
+            bool cont;
+            if (b == 0) {      // continue a previous call exactly if the caller hands back what it was given
+                cont = d.prn > 0 && c->carry_prn[i] == d.prn && c->handed[i] == d.carr_phase;
+                if (cont) carry[i] = c->carry[i];
+            } else {
+                cont = d.prn > 0 && prev_prn[i] == d.prn;
+            }
             uint64_t nxt = 0;
             int rc = quantize_one(d, delt, nsamp, cont ? &carry[i] : nullptr, &q[(size_t) b * nchan + i], &nxt);
             if (rc) return rc;
@@ -325,7 +331,16 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
             prev_prn[i] = d.prn > 0 ? d.prn : 0;
         }
     }
-    return run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+    int rc = run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+    if (rc) return rc;
+    if (nblocks > 0)
+        for (int i = 0; i < nchan; ++i) {
+            c->carry_prn[i] = prev_prn[i];
+            c->carry[i] = carry[i];
+            c->handed[i] = prev_prn[i] ? carr_phase_to_double(carry[i]) : 0.0;
+            if (carr_phase_out) carr_phase_out[i] = c->handed[i];
+        }
+    return GPSIQ_OK;
 }
 
 }  // extern "C"

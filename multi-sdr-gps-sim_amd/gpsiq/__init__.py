@@ -69,7 +69,7 @@ _quantize = _sig("gpsiq_quantize", _i, _vp, _i, _d, _i, _vp, _vp, _vp)
 _create = _sig("gpsiq_create", _i, C.POINTER(_vp), _i)
 _destroy = _sig("gpsiq_destroy", None, _vp)
 _generate_block = _sig("gpsiq_generate_block", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp)
-_generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i)
+_generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i, _vp)
 _set_descriptors = _sig("gpsiq_set_descriptors", _i, _vp, _vp, _i, _i)
 _launch = _sig("gpsiq_launch", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i)
 _synchronize = _sig("gpsiq_synchronize", _i, _vp, _vp)
@@ -234,17 +234,20 @@ class Context:
         _check(_generate_block(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _p(out), _p(carr)))
         return out, carr
 
-    def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None, host_ptr=None):
+    def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None, host_ptr=None, carr_out=None):
+        """carr_out: optional float64[nchan] array that receives the carrier phase after the
+        last block (hand it back as block 0's carr_phase of the next batch to continue exactly)."""
         desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
         nb, nc = desc.shape
+        co = None if carr_out is None else _p(carr_out)
         if host_ptr is not None:      # caller-owned host buffer (e.g. pinned), nb*2*nsamp elements
-            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(host_ptr), 0))
+            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(host_ptr), 0, co))
             return None
         if device_ptr is not None:
-            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(device_ptr), 1))
+            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(device_ptr), 1, co))
             return None
         out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
-        _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(out), 0))
+        _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(out), 0, co))
         return out
 
     # -- resident-descriptor path (device buffers) --

@@ -190,6 +190,28 @@ def test_drop_in_block_calls_carry_the_carrier(ctx, oracle):
         assert np.array_equal(out, want[b]), b
 
 
+def test_batches_chain_like_one_batch(ctx, oracle):
+    """Two gpsiq_generate_batch calls, the second fed the carr_phase the first handed out
+    (the 30 s epoch loop of INTEGRATION.md section 3), equal one call over all blocks; a batch also
+    continues a gpsiq_generate_block call and vice versa."""
+    fs, ns, nb, nc = 2.6e6, 26000, 6, 7
+    d = synth_blocks(nb, nc, seed=52)
+    qo = oracle.quantize_blocks(d, fs, ns)
+    want = np.stack([oracle.block_fixed(qo[b], ns, SC08) for b in range(nb)])
+    carr = np.zeros(nc)
+    first = ctx.generate_batch(d[:2], ns, fs, SC08, carr_out=carr)
+    d2 = d[2:5].copy()
+    d2["carr_phase"][0] = carr
+    second = ctx.generate_batch(d2, ns, fs, SC08, carr_out=carr)
+    d3 = d[5].copy()
+    d3["carr_phase"] = carr
+    third, _ = ctx.generate_block(d3, ns, fs, SC08)
+    assert np.array_equal(np.concatenate([first, second, third[None, :]]), want)
+    # not handing the phase back re-seeds from the double: a (tiny) phase jump, different samples
+    again = ctx.generate_batch(d[2:5], ns, fs, SC08)
+    assert not np.array_equal(again, want[2:5])
+
+
 def test_time_sharding_is_seamless(ctx, oracle):
     """Any sub-range of blocks launched on its own equals the same blocks of one big launch
     (the property the multi-GPU time sharding rests on), and int8 == int16>>4 throughout."""
