@@ -30,8 +30,6 @@ struct gpsiq_ctx {
     // staging for the synchronous entry points
     void          *d_out = nullptr;
     size_t         out_cap = 0;
-    void          *h_pinned = nullptr;
-    size_t         pinned_cap = 0;
     // carrier carry per slot (gpsiq_generate_block)
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     double   handed[GPSIQ_MAX_CHAN] = {};
@@ -128,7 +126,6 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->d_tab) (void) hipFree(c->d_tab);
     if (c->d_desc) (void) hipFree(c->d_desc);
     if (c->d_out) (void) hipFree(c->d_out);
-    if (c->h_pinned) (void) hipHostFree(c->h_pinned);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
