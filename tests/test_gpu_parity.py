@@ -263,6 +263,36 @@ def test_baseline_size_properties(ctx, oracle):
         assert np.array_equal(got, oracle.block_fixed_range(q[blk], n0, 2048, SC16))
 
 
+@pytest.mark.parametrize("variant", ["generic", "rows", "rowsx", "tile", "seg"])
+def test_quantised_descriptor_fuzz(ctx, oracle, variant):
+    """Random QUANTISED descriptors straight into the kernels: full-range carrier steps
+    (|step| up to 0.5 cycle/sample), code steps up to the row kernel's limit, arbitrary
+    fractions, nav bits, chips next to the period end, negative / zero / large gains."""
+    from gpsiq.abi import QCHAN_DTYPE
+    rng = np.random.default_rng(2025)
+    max_step = ((31 << 56) - 1) // 63
+    for case in range(12):
+        nb, nc = int(rng.integers(1, 4)), int(rng.integers(1, 17))
+        ns = int(rng.integers(1, 5000))
+        q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+        q["prn"] = rng.integers(0, 33, size=(nb, nc))              # 0 = unused slot
+        q["carr_phase"] = rng.integers(0, 1 << 59, size=(nb, nc), dtype=np.uint64)
+        q["carr_step"] = rng.integers(-(1 << 58) + 1, 1 << 58, size=(nb, nc))
+        q["code_frac"] = rng.integers(0, 1 << 56, size=(nb, nc), dtype=np.uint64)
+        q["code_step"] = rng.integers(1, max_step + 1, size=(nb, nc), dtype=np.uint64)
+        q["code_step"][0, :] = max_step                             # the limit itself
+        q["chip0"] = rng.integers(0, 1023, size=(nb, nc))
+        q["chip0"][:, ::3] = 1022
+        q["icode"] = rng.integers(0, 20, size=(nb, nc))
+        q["nav_bits"] = rng.integers(0, 1 << 32, size=(nb, nc), dtype=np.uint64).astype(np.uint32)
+        q["gain"] = rng.choice([0.0, -0.7, 1.0, 0.3333, 2.0, -300.0, 1e-3, 17.25], size=(nb, nc))
+        ctx.set_descriptors(q)
+        for ss in (SC08, SC16):
+            got = run_device(ctx, q, ns, ss, variant)
+            for b in range(nb):
+                assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, ss)), (case, b, ss)
+
+
 def test_bad_arguments_are_errors(ctx):
     import torch
     d = synth_blocks(1, 2, seed=81)
