@@ -4,7 +4,7 @@ REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --no-cpu-baseline"   # the default command: --gpus 1 --steps 20 --warmup 3
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
 tail -3 $OUT/kt.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
