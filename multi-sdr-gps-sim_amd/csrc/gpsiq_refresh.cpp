@@ -52,11 +52,14 @@ GpsTime advance(GpsTime g, double dt)
     return g;
 }
 
-// The reference is built with gcc, which fuses sin(x) and cos(x) of one argument into a
-// single glibc sincos() call, and sincos() is not always bit-identical to separate sin()/cos()
-// (6 ranges in 4800 differ by one ulp).  Calling sincos() explicitly makes the result
-// independent of which compiler builds this file.
-inline void sin_cos(double x, double *s, double *c) { ::sincos(x, s, c); }
+// sin and cos of one argument must come from two separate libm calls: the reference's own
+// build (Makefile:5, gcc -Og) does not fuse them, whereas an optimising build may turn the pair
+// into one glibc sincos(), whose results are not always bit-identical (one ulp in ~0.2 % of
+// the ranges).  Routing the calls through non-inlinable functions keeps any compiler from
+// fusing them, so the descriptors match the reference whatever builds this file.
+__attribute__((noinline)) double sin_only(double x) { return std::sin(x); }
+__attribute__((noinline)) double cos_only(double x) { return std::cos(x); }
+inline void sin_cos(double x, double *s, double *c) { *s = sin_only(x); *c = cos_only(x); }
 
 inline double norm3(const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }   // gps.c:255-257
 
@@ -178,8 +181,8 @@ double iono_delay(const gpsiq_iono_t &io, double sec, const double *llh, const d
     double phi_i = phi_u + psi * caz;
     if (phi_i > 0.416) phi_i = 0.416;
     else if (phi_i < -0.416) phi_i = -0.416;
-    const double lam_i = lam_u + psi * saz / std::cos(phi_i * kPi);
-    const double phi_m = phi_i + 0.064 * std::cos((lam_i - 1.617) * kPi);
+    const double lam_i = lam_u + psi * saz / cos_only(phi_i * kPi);
+    const double phi_m = phi_i + 0.064 * cos_only((lam_i - 1.617) * kPi);
     const double phi_m2 = phi_m * phi_m, phi_m3 = phi_m2 * phi_m;
     double amp = io.alpha[0] + io.alpha[1] * phi_m + io.alpha[2] * phi_m2 + io.alpha[3] * phi_m3;
     if (amp < 0.0) amp = 0.0;
