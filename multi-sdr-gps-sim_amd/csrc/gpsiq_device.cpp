@@ -303,10 +303,11 @@ int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int 
 int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp,
                          double fs, int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
 {
-    if (!c || !ch || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
+    if (!c || (!ch && nblocks) || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
     if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    if (nblocks == 0) return GPSIQ_OK;                    // an empty batch leaves the carried phases alone
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     int prev_prn[GPSIQ_MAX_CHAN] = {};

@@ -293,6 +293,36 @@ def test_quantised_descriptor_fuzz(ctx, oracle, variant):
                 assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, ss)), (case, b, ss)
 
 
+def test_empty_and_maximum_block_sizes(ctx, oracle):
+    """Empty launches are no-ops; the longest block the descriptor format allows (32 nav bits
+    = 0.62 s of signal) is exact from the first to the last sample; one sample more is an error."""
+    import torch
+    d = synth_blocks(1, 16, seed=91)
+    d["icode"], d["ibit"], d["iword"] = 0, 0, 0
+    d["code_phase"] = d["code_phase"] % 500.0
+    fs = 13.0e6
+    ns_max = int(0.6 * fs)                               # 7.8 M samples, 30 nav bits
+    q, _ = gpsiq.quantize_blocks(d, fs, ns_max)
+    ctx.set_descriptors(q)
+    ctx.launch(0, 0, ns_max, SC16, 0, 4 * ns_max)        # zero blocks: nothing to do, no error
+    ctx.launch(0, 1, 0, SC16, 0, 0)                      # zero samples
+    a = torch.empty(4 * ns_max, dtype=torch.uint8, device="cuda")
+    b = torch.empty(4 * ns_max, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.launch(0, 1, ns_max, SC16, a.data_ptr(), 4 * ns_max, stream=s, variant=gpsiq.variants()["seg"])
+    ctx.launch(0, 1, ns_max, SC16, b.data_ptr(), 4 * ns_max, stream=s, variant=gpsiq.variants()["generic"])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    a16 = a.view(torch.int16)
+    for n0 in (0, 1234567, ns_max - 4096):
+        got = a16[2 * n0: 2 * (n0 + 4096)].cpu().numpy()
+        assert np.array_equal(got, oracle.block_fixed_range(q[0], n0, 4096, SC16))
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.quantize_blocks(d, fs, int(0.7 * fs))      # would need more than 32 nav bits
+    out = ctx.generate_batch(d[:0], 100, fs, SC16)       # empty batch
+    assert out.shape == (0, 200)
+
+
 def test_bad_arguments_are_errors(ctx):
     import torch
     d = synth_blocks(1, 2, seed=81)
