@@ -123,11 +123,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (libgpsiq has no CPU path)"
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; the modulo only matters when the multi-rank path is exercised on a box
+    # with fewer GPUs than ranks (GPSIQ_BENCH_BACKEND=gloo, see scripts/gpu_validate.sh)
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
+    backend = os.environ.get("GPSIQ_BENCH_BACKEND", "nccl")    # nccl == RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     fs, nchan, ss = args.fs, args.nchan, args.sample_size
     nsamp = int(round(fs / 10))                      # NUM_IQ_SAMPLES, reference sdr.h:26
@@ -146,7 +153,7 @@ def main():
     q, (b0, b1) = shard_descriptors(desc_all, fs, nsamp, rank, world)
     assert b1 - b0 == nblocks
 
-    ctx = gpsiq.Context(local_rank)
+    ctx = gpsiq.Context(dev)
     ctx.set_descriptors(q)
     ring = torch.empty(nblocks * stride, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -174,7 +181,7 @@ def main():
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    t_max = max_over_ranks(t_local, dist, device="cuda")
+    t_max = max_over_ranks(t_local, dist, device="cuda" if backend == "nccl" else "cpu")
     launch_ms = e0.elapsed_time(e1) / args.steps       # HIP events on the launch stream
 
     if args.sweep and rank == 0:
