@@ -210,6 +210,20 @@ def main():
         ctx.set_descriptors(q)
 
     if args.sweep and rank == 0:
+        # the whole drop-in batch call with a DEVICE destination: host quantiser + descriptor
+        # upload + kernel (no D2H) -- shows what the host side of gpsiq_generate_batch costs
+        nb_d = min(nblocks, len(desc_all))
+        ctx.generate_batch(desc_all[:nb_d], nsamp, fs, ss, device_ptr=ring.data_ptr())
+        dt = float("inf")
+        for _ in range(5):
+            t1 = time.perf_counter()
+            ctx.generate_batch(desc_all[:nb_d], nsamp, fs, ss, device_ptr=ring.data_ptr())
+            dt = min(dt, time.perf_counter() - t1)
+        print(f"[device-dst] gpsiq_generate_batch -> device memory: {nb_d} blocks in {dt * 1e3:.1f} ms = "
+              f"{nb_d / dt / 1e3:.0f} kblocks/s = {nb_d * 0.1 / dt:.0f}x real time (kernel alone {launch_ms:.1f} ms)", file=sys.stderr)
+        ctx.set_descriptors(q)
+
+    if args.sweep and rank == 0:
         # the host refresh that feeds the kernel (gpsiq_refresh_batch, reference gps.c:2731-2765):
         # blocks per second on this host, 1 thread and all threads
         from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks

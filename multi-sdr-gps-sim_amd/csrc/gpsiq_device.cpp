@@ -3,6 +3,9 @@
 // There is deliberately no CPU path here: without a GPU gpsiq_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -27,6 +30,8 @@ struct gpsiq_ctx {
     int            nblocks = 0, nchan = 0;
     uint64_t       max_code_step = 0;
     int            max_active = 0;      // most active channels in any resident block
+    gpsiq_qchan_t *h_desc = nullptr;   // page-locked staging of the compacted descriptors
+    size_t         h_desc_cap = 0;
     // staging for the synchronous entry points
     void          *d_out = nullptr;
     size_t         out_cap = 0;
@@ -42,6 +47,14 @@ struct gpsiq_ctx {
         if (e_ != hipSuccess)                                                                \
             return fail(GPSIQ_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));             \
     } while (0)
+
+// GPSIQ_TRACE=1 in the environment prints the host-side phase times of the batch call to stderr
+static double wall_ms()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec * 1e3 + (double) ts.tv_nsec * 1e-6;
+}
 
 static int ensure_desc(gpsiq_ctx *c, size_t n)
 {
@@ -126,6 +139,7 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->d_tab) (void) hipFree(c->d_tab);
     if (c->d_desc) (void) hipFree(c->d_desc);
     if (c->d_out) (void) hipFree(c->d_out);
+    if (c->h_desc) (void) hipHostFree(c->h_desc);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -151,32 +165,56 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t) nblocks * (size_t) nchan;
-    uint64_t mx = 0;
-    int max_active = 0;
-    // Device copy is compacted per block: active channels first, unused slots (zeroed)
-    // after them.  The sum over channels is commutative modulo 2^16, so slot order is free.
-    std::vector<gpsiq_qchan_t> packed(n);
-    for (int b = 0; b < nblocks; ++b) {
-        int na = 0;
-        for (int s = 0; s < nchan; ++s) {
-            const size_t i = (size_t) b * nchan + s;
-            if (q[i].prn > 32) return fail(GPSIQ_E_ARG, "descriptor %zu: prn %u", i, q[i].prn);
-            if (!q[i].prn) continue;
-            if (q[i].chip0 >= GPSIQ_CA_SEQ_LEN || q[i].icode >= 20 || (q[i].code_frac >> GPSIQ_CODE_FRAC_BITS) ||
-                (q[i].code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(q[i].gain > -4.0e6 && q[i].gain < 4.0e6))
-                return fail(GPSIQ_E_RANGE, "descriptor %zu outside the NCO format", i);
-            if (q[i].code_step > mx) mx = q[i].code_step;
-            packed[(size_t) b * nchan + na++] = q[i];
-        }
-        for (int s = na; s < nchan; ++s) std::memset(&packed[(size_t) b * nchan + s], 0, sizeof(gpsiq_qchan_t));
-        if (na > max_active) max_active = na;
-    }
     int rc = ensure_desc(c, n ? n : 1);
     if (rc) return rc;
+    if (n > c->h_desc_cap) {
+        if (c->h_desc) HIP_TRY(hipHostFree(c->h_desc));
+        c->h_desc = nullptr; c->h_desc_cap = 0;
+        HIP_TRY(hipHostMalloc((void **) &c->h_desc, n * sizeof(gpsiq_qchan_t), hipHostMallocDefault));
+        c->h_desc_cap = n;
+    }
+    // Device copy is compacted per block: active channels first, unused slots (zeroed)
+    // after them.  The sum over channels is commutative modulo 2^16, so slot order is free.
+    // Validation + compaction run on host threads straight into the page-locked staging buffer.
+    struct PJob { const gpsiq_qchan_t *q; gpsiq_qchan_t *out; int nchan; uint64_t mx; int max_active; int rc; size_t bad; };
+    PJob pj = {q, c->h_desc, nchan, 0, 0, GPSIQ_OK, 0};
+    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    const double t0 = trace ? wall_ms() : 0.0;
+    parallel_for(nblocks, 0, 128, [](void *p, int b0, int b1) {
+        PJob &j = *static_cast<PJob *>(p);
+        uint64_t mx = 0;
+        int max_active = 0;
+        for (int b = b0; b < b1; ++b) {
+            int na = 0;
+            for (int s = 0; s < j.nchan; ++s) {
+                const size_t i = (size_t) b * j.nchan + s;
+                const gpsiq_qchan_t &d = j.q[i];
+                if (!d.prn) continue;
+                if (d.prn > 32 || d.chip0 >= GPSIQ_CA_SEQ_LEN || d.icode >= 20 || (d.code_frac >> GPSIQ_CODE_FRAC_BITS) ||
+                    (d.code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(d.gain > -4.0e6 && d.gain < 4.0e6)) {
+                    if (__sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, d.prn > 32 ? GPSIQ_E_ARG : GPSIQ_E_RANGE)) j.bad = i;
+                    continue;
+                }
+                if (d.code_step > mx) mx = d.code_step;
+                j.out[(size_t) b * j.nchan + na++] = d;
+            }
+            for (int s = na; s < j.nchan; ++s) std::memset(&j.out[(size_t) b * j.nchan + s], 0, sizeof(gpsiq_qchan_t));
+            if (na > max_active) max_active = na;
+        }
+        for (uint64_t cur = j.mx; mx > cur && !__sync_bool_compare_and_swap(&j.mx, cur, mx); cur = j.mx) {}
+        for (int cur = j.max_active; max_active > cur && !__sync_bool_compare_and_swap(&j.max_active, cur, max_active); cur = j.max_active) {}
+    }, &pj);
+    if (pj.rc != GPSIQ_OK) return fail(pj.rc, "descriptor %zu outside the NCO format (prn %u)", pj.bad, q[pj.bad].prn);
+    const uint64_t mx = pj.mx;
+    const int max_active = pj.max_active;
     if (n) {
         // make sure no launch still reads the previous descriptors
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(c->d_desc, packed.data(), n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice));
+        const double t1 = trace ? wall_ms() : 0.0;
+        HIP_TRY(hipMemcpy(c->d_desc, c->h_desc, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice));
+        if (trace)
+            std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %.2f ms\n",
+                         nblocks, t1 - t0, wall_ms() - t1);
     }
     c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx; c->max_active = max_active;
     return GPSIQ_OK;
@@ -308,29 +346,47 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
     if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
     if (nblocks == 0) return GPSIQ_OK;                    // an empty batch leaves the carried phases alone
+    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    const double t0 = trace ? wall_ms() : 0.0;
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+    // pass 1, on host threads: everything but the carrier carry is independent per block
+    struct QJob { const gpsiq_chan_t *ch; gpsiq_qchan_t *q; int nchan, nsamp; double delt; int rc; char err[256]; };
+    QJob qj = {ch, q.data(), nchan, nsamp, 1.0 / fs, GPSIQ_OK, ""};
+    parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
+        QJob &j = *static_cast<QJob *>(p);
+        for (int b = b0; b < b1; ++b)
+            for (int i = 0; i < j.nchan; ++i) {
+                int rc = quantize_one(j.ch[(size_t) b * j.nchan + i], j.delt, j.nsamp, nullptr, &j.q[(size_t) b * j.nchan + i], nullptr);
+                if (rc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, rc))
+                    std::snprintf(j.err, sizeof j.err, "block %d: %s", b, gpsiq_last_error());
+            }
+    }, &qj);
+    if (qj.rc != GPSIQ_OK) return fail(qj.rc, "%s", qj.err);
+    const double t1 = trace ? wall_ms() : 0.0;
+    // pass 2, serial: exact carrier prefix p_{k+1} = p_k + nsamp*step_k (mod 2^59)
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     int prev_prn[GPSIQ_MAX_CHAN] = {};
-    const double delt = 1.0 / fs;
+    const uint64_t mask = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1;
     for (int b = 0; b < nblocks; ++b) {
         for (int i = 0; i < nchan; ++i) {
-            const gpsiq_chan_t &d = ch[(size_t) b * nchan + i];
+            gpsiq_qchan_t &qq = q[(size_t) b * nchan + i];
+            const int prn = qq.prn;                       // 0 for an idle slot; only q is touched here (cache-resident)
             bool cont;
-            if (b == 0) {      // continue a previous call exactly if the caller hands back what it was given
-                cont = d.prn > 0 && c->carry_prn[i] == d.prn && c->handed[i] == d.carr_phase;
-                if (cont) carry[i] = c->carry[i];
-            } else {
-                cont = d.prn > 0 && prev_prn[i] == d.prn;
-            }
-            uint64_t nxt = 0;
-            int rc = quantize_one(d, delt, nsamp, cont ? &carry[i] : nullptr, &q[(size_t) b * nchan + i], &nxt);
-            if (rc) return rc;
-            carry[i] = nxt;
-            prev_prn[i] = d.prn > 0 ? d.prn : 0;
+            if (b == 0)        // continue a previous call exactly if the caller hands back what it was given
+                cont = prn && c->carry_prn[i] == prn && c->handed[i] == ch[i].carr_phase;
+            else
+                cont = prn && prev_prn[i] == prn;
+            if (cont) qq.carr_phase = (b == 0 ? c->carry[i] : carry[i]) & mask;
+            carry[i] = prn ? (qq.carr_phase + (uint64_t) qq.carr_step * (uint64_t) nsamp) & mask : 0;
+            prev_prn[i] = prn;
         }
     }
+    const double t2 = trace ? wall_ms() : 0.0;
     int rc = run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
     if (rc) return rc;
+    if (trace)
+        std::fprintf(stderr, "[gpsiq trace] batch %d blocks: quantise %.2f ms, carrier prefix %.2f ms, upload+kernel%s %.2f ms\n",
+                     nblocks, t1 - t0, t2 - t1, dst_is_device ? "" : "+D2H", wall_ms() - t2);
     if (nblocks > 0)
         for (int i = 0; i < nchan; ++i) {
             c->carry_prn[i] = prev_prn[i];

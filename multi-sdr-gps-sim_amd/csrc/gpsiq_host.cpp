@@ -5,8 +5,12 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <pthread.h>
+#include <unistd.h>
+#include <vector>
 
 namespace gpsiq {
 
@@ -19,6 +23,116 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- parallel_for: a small persistent worker pool -----------------------------
+// Spawning threads per call costs more than the work of a 4000-block batch on a 256-core
+// host (measured: 65 pthread_create/join ~ 2.4 ms vs 0.6 ms of quantising), so the workers
+// are created once, on first use, and sleep on a condition variable between jobs.  Ranges are
+// handed out in chunks from a shared counter; the caller works too.  One job at a time: a
+// second caller (or a nested call) simply runs its range inline.  The workers are detached
+// and never exit; the library is not meant to be dlclose()d.
+namespace {
+constexpr int kMaxWorkers = 63;
+struct Pool {
+    pthread_mutex_t submit, m;
+    pthread_cond_t  go, done;
+    int             nworkers;
+    unsigned long   gen;                 // job generation, bumped under m
+    unsigned long   start_gen[kMaxWorkers];
+    int             want, pending;       // workers [0, want) take part; pending = not finished yet
+    void          (*fn)(void *, int, int);
+    void           *ctx;
+    long            n, chunk, next;
+};
+Pool g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+               0, 0, {}, 0, 0, nullptr, nullptr, 0, 0, 0};
+
+void pool_run_chunks()
+{
+    Pool &p = g_pool;
+    for (;;) {
+        const long b = __atomic_fetch_add(&p.next, p.chunk, __ATOMIC_RELAXED);
+        if (b >= p.n) break;
+        const long e = b + p.chunk < p.n ? b + p.chunk : p.n;
+        p.fn(p.ctx, (int) b, (int) e);
+    }
+}
+
+void *pool_worker(void *arg)
+{
+    Pool &p = g_pool;
+    const int idx = (int) (intptr_t) arg;
+    unsigned long seen = p.start_gen[idx];
+    for (;;) {
+        pthread_mutex_lock(&p.m);
+        while (p.gen == seen) pthread_cond_wait(&p.go, &p.m);
+        seen = p.gen;
+        const bool mine = idx < p.want;
+        pthread_mutex_unlock(&p.m);
+        if (!mine) continue;
+        pool_run_chunks();
+        pthread_mutex_lock(&p.m);
+        if (--p.pending == 0) pthread_cond_signal(&p.done);
+        pthread_mutex_unlock(&p.m);
+    }
+    return nullptr;
+}
+
+void pool_after_fork_in_child()          // the child has none of the parent's threads
+{
+    Pool &p = g_pool;
+    pthread_mutex_init(&p.submit, nullptr);
+    pthread_mutex_init(&p.m, nullptr);
+    pthread_cond_init(&p.go, nullptr);
+    pthread_cond_init(&p.done, nullptr);
+    p.nworkers = 0;
+    p.want = p.pending = 0;
+}
+}  // namespace
+
+void parallel_for(int n, int nthreads, int grain, void (*fn)(void *, int, int), void *ctx)
+{
+    if (n <= 0) return;
+    if (grain < 1) grain = 1;
+    if (nthreads <= 0) {
+        long c = sysconf(_SC_NPROCESSORS_ONLN);
+        nthreads = c > 0 ? (int) c : 1;
+        const int useful = n / grain + 1;
+        if (nthreads > useful) nthreads = useful;
+    }
+    if (nthreads > n) nthreads = n;
+    if (nthreads > kMaxWorkers + 1) nthreads = kMaxWorkers + 1;
+    Pool &p = g_pool;
+    if (nthreads <= 1 || pthread_mutex_trylock(&p.submit) != 0) { fn(ctx, 0, n); return; }
+    static bool atfork_set = false;
+    if (!atfork_set) { pthread_atfork(nullptr, nullptr, pool_after_fork_in_child); atfork_set = true; }
+    while (p.nworkers < nthreads - 1) {
+        pthread_t th;
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        p.start_gen[p.nworkers] = p.gen;                  // no job is in flight while we hold submit
+        const int rc = pthread_create(&th, &at, pool_worker, (void *) (intptr_t) p.nworkers);
+        pthread_attr_destroy(&at);
+        if (rc != 0) break;
+        ++p.nworkers;
+    }
+    const int helpers = nthreads - 1 < p.nworkers ? nthreads - 1 : p.nworkers;
+    if (helpers == 0) { pthread_mutex_unlock(&p.submit); fn(ctx, 0, n); return; }
+    pthread_mutex_lock(&p.m);
+    p.fn = fn; p.ctx = ctx; p.n = n; p.next = 0;
+    const long per = ((long) n + (long) (helpers + 1) * 4 - 1) / ((long) (helpers + 1) * 4);
+    p.chunk = per > grain ? per : grain;
+    p.want = p.pending = helpers;
+    ++p.gen;
+    pthread_cond_broadcast(&p.go);
+    pthread_mutex_unlock(&p.m);
+    pool_run_chunks();
+    pthread_mutex_lock(&p.m);
+    while (p.pending) pthread_cond_wait(&p.done, &p.m);
+    pthread_mutex_unlock(&p.m);
+    pthread_mutex_unlock(&p.submit);
 }
 
 // C/A code of one PRN (replaces codegen(), reference gps.c:272-309): G1 = x^10+x^3+1,

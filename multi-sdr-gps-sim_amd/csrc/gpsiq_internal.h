@@ -15,6 +15,10 @@ double   carr_phase_to_double(uint64_t fixed);
 int  quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t *carry_in,
                   gpsiq_qchan_t *q, uint64_t *carry_out);
 
+// Run fn(ctx, begin, end) over [0, n) on up to nthreads host threads (<= 0: one per online
+// CPU, but at least `grain` items per thread).  Returns after all parts are done.
+void parallel_for(int n, int nthreads, int grain, void (*fn)(void *ctx, int begin, int end), void *ctx);
+
 // Kernel variants (gpsiq_launch's `variant`).
 enum Variant {
     kAuto = 0,      // fast when every resident descriptor allows it, else generic

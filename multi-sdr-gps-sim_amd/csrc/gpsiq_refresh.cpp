@@ -15,8 +15,6 @@
 
 #include <cmath>
 #include <cstring>
-#include <pthread.h>
-#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -236,13 +234,13 @@ struct Job {
     int nchan, gain_x2; const gpsiq_track_t *trk; const double *ant_pat;
     Range *rng;            // [nblocks + 1][nchan], row 0 = the state before the batch
     gpsiq_chan_t *out;
-    int b0, b1, pass;
+    int pass;
 };
 
-void *worker(void *p)
+void work(void *p, int b0, int b1)
 {
     const Job &j = *static_cast<const Job *>(p);
-    for (int b = j.b0; b < j.b1; ++b) {
+    for (int b = b0; b < b1; ++b) {
         if (j.pass == 0) {                                   // ranges: independent per block
             const Site site = site_from_ecef(j.xyz + 3 * (size_t) b);
             for (int c = 0; c < j.nchan; ++c)
@@ -280,26 +278,6 @@ void *worker(void *p)
             }
         }
     }
-    return nullptr;
-}
-
-void run_parallel(Job proto, int nblocks, int nthreads)
-{
-    if (nthreads > nblocks) nthreads = nblocks;
-    if (nthreads <= 1) { proto.b0 = 0; proto.b1 = nblocks; worker(&proto); return; }
-    std::vector<Job> jobs((size_t) nthreads, proto);
-    std::vector<pthread_t> th((size_t) nthreads);
-    for (int i = 0; i < nthreads; ++i) {
-        jobs[(size_t) i].b0 = (int) ((long) nblocks * i / nthreads);
-        jobs[(size_t) i].b1 = (int) ((long) nblocks * (i + 1) / nthreads);
-        if (pthread_create(&th[(size_t) i], nullptr, worker, &jobs[(size_t) i]) != 0) {
-            worker(&jobs[(size_t) i]);               // could not spawn: do it here
-            th[(size_t) i] = pthread_t();
-            jobs[(size_t) i].pass = -1;
-        }
-    }
-    for (int i = 0; i < nthreads; ++i)
-        if (jobs[(size_t) i].pass != -1) pthread_join(th[(size_t) i], nullptr);
 }
 
 }  // namespace
@@ -337,13 +315,6 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
     if (!eph || !iono || !xyz || !trk || !out) return fail(GPSIQ_E_ARG, "null argument");
     if (nchan < 1 || nchan > GPSIQ_MAX_CHAN || nblocks < 0) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     if (nblocks == 0) return GPSIQ_OK;
-    if (nthreads <= 0) {
-        // one thread per online CPU, but never less than ~1000 blocks (a few ms of work) each
-        long n = sysconf(_SC_NPROCESSORS_ONLN);
-        nthreads = n > 0 ? (int) n : 1;
-        const int useful = nblocks / 1024 + 1;
-        if (nthreads > useful) nthreads = useful;
-    }
     double ant_pat[37];
     for (int i = 0; i < 37; ++i) ant_pat[i] = std::pow(10.0, -kAntPatDb[i] / 20.0);    // gps.c:2688-2689
 
@@ -360,10 +331,10 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
     }
     t[0] = GpsTime{week, sec};
 
-    Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0, 0, 0};
-    run_parallel(job, nblocks, nthreads);
+    Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0};
+    parallel_for(nblocks, nthreads, 1024, work, &job);      // >= ~1000 blocks (a few ms) per thread
     job.pass = 1;
-    run_parallel(job, nblocks, nthreads);
+    parallel_for(nblocks, nthreads, 1024, work, &job);
 
     for (int c = 0; c < nchan; ++c) {                      // chan.rho0 = rho1 (gps.c:2063)
         if (trk[c].prn <= 0) continue;
