@@ -210,6 +210,21 @@ def main():
         ctx.set_descriptors(q)
 
     if args.sweep and rank == 0:
+        # the real-time drop-in call: ONE block per call into a page-locked host buffer, as the
+        # patched gps thread would issue it every 0.1 s (quantise, H2D, kernel, D2H, sync)
+        lat = []
+        for k in range(60):
+            ch1 = desc_all[k % len(desc_all)]
+            t1 = time.perf_counter()
+            ctx.generate_block(ch1, nsamp, fs, ss, host_ptr=pinned.data_ptr())
+            lat.append(time.perf_counter() - t1)
+        lat = sorted(lat[10:])
+        print(f"[block] gpsiq_generate_block -> pinned host memory: median {lat[len(lat) // 2] * 1e6:.0f} us, "
+              f"max {lat[-1] * 1e6:.0f} us per 0.1 s block ({0.1 / lat[len(lat) // 2]:.0f}x real time, one call at a time)",
+              file=sys.stderr)
+        ctx.set_descriptors(q)
+
+    if args.sweep and rank == 0:
         # the whole drop-in batch call with a DEVICE destination: host quantiser + descriptor
         # upload + kernel (no D2H) -- shows what the host side of gpsiq_generate_batch costs
         nb_d = min(nblocks, len(desc_all))

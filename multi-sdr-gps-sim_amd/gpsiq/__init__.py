@@ -227,10 +227,15 @@ class Context:
             pass
 
     # -- drop-in entry points (host buffers) --
-    def generate_block(self, ch, nsamp, fs, sample_size):
+    def generate_block(self, ch, nsamp, fs, sample_size, host_ptr=None):
+        """One 0.1 s block, the call that replaces gps.c:2767-2846.  host_ptr: optional
+        caller-owned host buffer of 2*nsamp elements (e.g. a page-locked fifo buffer)."""
         ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
-        out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
         carr = np.zeros(len(ch), dtype=np.float64)
+        if host_ptr is not None:
+            _check(_generate_block(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _vp(host_ptr), _p(carr)))
+            return None, carr
+        out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
         _check(_generate_block(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _p(out), _p(carr)))
         return out, carr
 
