@@ -125,6 +125,21 @@ void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512[512]);
 int gpsiq_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
                    gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out);
 
+/* The same for a whole timeline of nblocks consecutive blocks, ch[nblocks][nchan] ->
+ * out[nblocks][nchan], quantised on host threads and chained with the exact carrier prefix
+ * p_{k+1} = p_k + nsamp*step_k (mod 2^59): block 0 starts from carry_in (if non-NULL) or its
+ * own carr_phase; a later block continues the previous one while the slot keeps its PRN and
+ * re-seeds from its own carr_phase when the slot is re-allocated (gps.c:2208-2210).
+ * This is what gpsiq_generate_batch does internally; a multi-GPU host calls it once and gives
+ * every device a contiguous slice of `out` (gpsiq_shard_range + gpsiq_set_descriptors), so
+ * each shard starts bit-exactly where its predecessor ends and no device talks to another. */
+int gpsiq_quantize_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp,
+                         gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out);
+
+/* Contiguous balanced split of a block timeline over `world` devices/processes:
+ * rank r owns [*begin, *end); the first nblocks % world ranks own one block more. */
+int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end);
+
 /* ---- device context ------------------------------------------------------ */
 /* device = HIP device ordinal.  Fails (GPSIQ_E_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
@@ -155,6 +170,13 @@ int gpsiq_generate_block(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
 int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, int dst_is_device, double *carr_phase_out);
+
+/* One shard of a time-sharded run: synthesise nblocks already-quantised blocks
+ * (a contiguous slice of gpsiq_quantize_batch's output, which carries the exact carrier
+ * phase of every block) into dst, host or device as above.  Synchronous.  Does not touch
+ * the carrier continuation state of gpsiq_generate_block/_batch. */
+int gpsiq_generate_quantized(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan,
+                             int nsamp, int sample_size, void *dst, int dst_is_device);
 
 /* Page-locked host memory for fifo buffers (hipHostMalloc): a device-to-host copy into it
  * is a single DMA.  NULL on failure.  Usable as the allocator of host/fifo.c. */

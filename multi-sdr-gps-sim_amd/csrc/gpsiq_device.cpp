@@ -288,12 +288,12 @@ const char *gpsiq_variant_name(int v)
 
 // ---- synchronous drop-in entry points ---------------------------------------
 
-static int run_to_host_or_device(gpsiq_ctx *c, const std::vector<gpsiq_qchan_t> &q, int nblocks, int nchan,
+static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nblocks, int nchan,
                                  int nsamp, int sample_size, void *dst, int dst_is_device)
 {
     const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
     const size_t stride = (blk_bytes + 15) & ~(size_t) 15;
-    int rc = gpsiq_set_descriptors(c, q.data(), nblocks, nchan);
+    int rc = gpsiq_set_descriptors(c, q, nblocks, nchan);
     if (rc) return rc;
     if (!nblocks || !nsamp) return GPSIQ_OK;
     if (dst_is_device && stride == blk_bytes) {
@@ -327,7 +327,7 @@ int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int 
         int rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[(size_t) i], &next[i]);
         if (rc) return rc;
     }
-    int rc = run_to_host_or_device(c, q, 1, nchan, nsamp, sample_size, dst, 0);
+    int rc = run_to_host_or_device(c, q.data(), 1, nchan, nsamp, sample_size, dst, 0);
     if (rc) return rc;
     for (int i = 0; i < nchan; ++i) {
         c->carry_prn[i] = ch[i].prn > 0 ? ch[i].prn : 0;
@@ -336,6 +336,17 @@ int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int 
         if (carr_phase_out) carr_phase_out[i] = ch[i].prn > 0 ? c->handed[i] : ch[i].carr_phase;
     }
     return GPSIQ_OK;
+}
+
+int gpsiq_generate_quantized(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp,
+                             int sample_size, void *dst, int dst_is_device)
+{
+    if (!c || (!q && nblocks) || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0) return fail(GPSIQ_E_ARG, "bad nsamp %d", nsamp);
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    if (nblocks == 0) return GPSIQ_OK;
+    return run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
 }
 
 int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp,
@@ -349,44 +360,20 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
-    // pass 1, on host threads: everything but the carrier carry is independent per block
-    struct QJob { const gpsiq_chan_t *ch; gpsiq_qchan_t *q; int nchan, nsamp; double delt; int rc; char err[256]; };
-    QJob qj = {ch, q.data(), nchan, nsamp, 1.0 / fs, GPSIQ_OK, ""};
-    parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
-        QJob &j = *static_cast<QJob *>(p);
-        for (int b = b0; b < b1; ++b)
-            for (int i = 0; i < j.nchan; ++i) {
-                int rc = quantize_one(j.ch[(size_t) b * j.nchan + i], j.delt, j.nsamp, nullptr, &j.q[(size_t) b * j.nchan + i], nullptr);
-                if (rc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, rc))
-                    std::snprintf(j.err, sizeof j.err, "block %d: %s", b, gpsiq_last_error());
-            }
-    }, &qj);
-    if (qj.rc != GPSIQ_OK) return fail(qj.rc, "%s", qj.err);
-    const double t1 = trace ? wall_ms() : 0.0;
-    // pass 2, serial: exact carrier prefix p_{k+1} = p_k + nsamp*step_k (mod 2^59)
+    // continue a previous call exactly where the caller hands back what it was given
+    bool cont0[GPSIQ_MAX_CHAN];
+    for (int i = 0; i < nchan; ++i)
+        cont0[i] = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     int prev_prn[GPSIQ_MAX_CHAN] = {};
-    const uint64_t mask = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1;
-    for (int b = 0; b < nblocks; ++b) {
-        for (int i = 0; i < nchan; ++i) {
-            gpsiq_qchan_t &qq = q[(size_t) b * nchan + i];
-            const int prn = qq.prn;                       // 0 for an idle slot; only q is touched here (cache-resident)
-            bool cont;
-            if (b == 0)        // continue a previous call exactly if the caller hands back what it was given
-                cont = prn && c->carry_prn[i] == prn && c->handed[i] == ch[i].carr_phase;
-            else
-                cont = prn && prev_prn[i] == prn;
-            if (cont) qq.carr_phase = (b == 0 ? c->carry[i] : carry[i]) & mask;
-            carry[i] = prn ? (qq.carr_phase + (uint64_t) qq.carr_step * (uint64_t) nsamp) & mask : 0;
-            prev_prn[i] = prn;
-        }
-    }
+    int qrc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
+    if (qrc) return qrc;
     const double t2 = trace ? wall_ms() : 0.0;
-    int rc = run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+    int rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
     if (rc) return rc;
     if (trace)
-        std::fprintf(stderr, "[gpsiq trace] batch %d blocks: quantise %.2f ms, carrier prefix %.2f ms, upload+kernel%s %.2f ms\n",
-                     nblocks, t1 - t0, t2 - t1, dst_is_device ? "" : "+D2H", wall_ms() - t2);
+        std::fprintf(stderr, "[gpsiq trace] batch %d blocks: quantise + carrier prefix %.2f ms, upload+kernel%s %.2f ms\n",
+                     nblocks, t2 - t0, dst_is_device ? "" : "+D2H", wall_ms() - t2);
     if (nblocks > 0)
         for (int i = 0; i < nchan; ++i) {
             c->carry_prn[i] = prev_prn[i];

@@ -237,6 +237,43 @@ int quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t 
     return GPSIQ_OK;
 }
 
+int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
+                      const bool *cont0, const uint64_t *carry0, gpsiq_qchan_t *q,
+                      uint64_t *carry_end, int *last_prn)
+{
+    // pass 1, on host threads: everything but the carrier carry is independent per block
+    struct QJob { const gpsiq_chan_t *ch; gpsiq_qchan_t *q; int nchan, nsamp; double delt; int rc; char err[320]; };
+    QJob qj = {ch, q, nchan, nsamp, delt, GPSIQ_OK, ""};
+    parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
+        QJob &j = *static_cast<QJob *>(p);
+        for (int b = b0; b < b1; ++b)
+            for (int i = 0; i < j.nchan; ++i) {
+                int rc = quantize_one(j.ch[(size_t) b * j.nchan + i], j.delt, j.nsamp, nullptr, &j.q[(size_t) b * j.nchan + i], nullptr);
+                if (rc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, rc))
+                    std::snprintf(j.err, sizeof j.err, "block %d: %s", b, gpsiq_last_error());
+            }
+    }, &qj);
+    if (qj.rc != GPSIQ_OK) return fail(qj.rc, "%s", qj.err);
+    // pass 2, serial and touching only q (cache-resident): p_{k+1} = p_k + nsamp*step_k (mod 2^59)
+    uint64_t carry[GPSIQ_MAX_CHAN] = {};
+    int prev_prn[GPSIQ_MAX_CHAN] = {};
+    const uint64_t mask = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1;
+    for (int b = 0; b < nblocks; ++b)
+        for (int i = 0; i < nchan; ++i) {
+            gpsiq_qchan_t &qq = q[(size_t) b * nchan + i];
+            const int prn = qq.prn;
+            const bool cont = prn && (b == 0 ? (cont0 && cont0[i]) : prev_prn[i] == prn);
+            if (cont) qq.carr_phase = (b == 0 ? carry0[i] : carry[i]) & mask;
+            carry[i] = prn ? (qq.carr_phase + (uint64_t) qq.carr_step * (uint64_t) nsamp) & mask : 0;
+            prev_prn[i] = prn;
+        }
+    for (int i = 0; i < nchan; ++i) {
+        if (carry_end) carry_end[i] = carry[i];
+        if (last_prn) last_prn[i] = prev_prn[i];
+    }
+    return GPSIQ_OK;
+}
+
 }  // namespace gpsiq
 
 using namespace gpsiq;
@@ -274,6 +311,27 @@ int gpsiq_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
                               carry_out ? &carry_out[c] : nullptr);
         if (rc != GPSIQ_OK) return rc;
     }
+    return GPSIQ_OK;
+}
+
+int gpsiq_quantize_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp,
+                         gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out)
+{
+    if ((!ch || !out) && nblocks) return fail(GPSIQ_E_ARG, "null descriptor pointer");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
+    bool cont0[GPSIQ_MAX_CHAN];
+    for (int i = 0; i < nchan; ++i) cont0[i] = carry_in != nullptr;
+    return quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, carry_in, out, carry_out, nullptr);
+}
+
+int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end)
+{
+    if (nblocks < 0 || world < 1 || rank < 0 || rank >= world || !begin || !end)
+        return fail(GPSIQ_E_ARG, "bad shard request: %d blocks, rank %d of %d", nblocks, rank, world);
+    const int base = nblocks / world, extra = nblocks % world;       // the first `extra` ranks take one more
+    *begin = rank * base + (rank < extra ? rank : extra);
+    *end = *begin + base + (rank < extra ? 1 : 0);
     return GPSIQ_OK;
 }
 

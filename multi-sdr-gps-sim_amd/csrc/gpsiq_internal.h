@@ -15,6 +15,14 @@ double   carr_phase_to_double(uint64_t fixed);
 int  quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t *carry_in,
                   gpsiq_qchan_t *q, uint64_t *carry_out);
 
+// Quantise nblocks x nchan descriptors (threaded, every block from its own carr_phase), then
+// chain the carrier exactly: block 0 slot i starts from carry0[i] where cont0[i] is set, a later
+// block continues the previous one while the slot keeps its PRN, and re-seeds from its own
+// carr_phase otherwise.  carry_end / last_prn (may be null) receive the state after the last block.
+int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
+                      const bool *cont0, const uint64_t *carry0, gpsiq_qchan_t *q,
+                      uint64_t *carry_end, int *last_prn);
+
 // Run fn(ctx, begin, end) over [0, n) on up to nthreads host threads (<= 0: one per online
 // CPU, but at least `grain` items per thread).  Returns after all parts are done.
 void parallel_for(int n, int nthreads, int grain, void (*fn)(void *ctx, int begin, int end), void *ctx);

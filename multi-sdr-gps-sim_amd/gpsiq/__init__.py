@@ -70,6 +70,9 @@ _create = _sig("gpsiq_create", _i, C.POINTER(_vp), _i)
 _destroy = _sig("gpsiq_destroy", None, _vp)
 _generate_block = _sig("gpsiq_generate_block", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp)
 _generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i, _vp)
+_generate_quantized = _sig("gpsiq_generate_quantized", _i, _vp, _vp, _i, _i, _i, _i, _vp, _i)
+_quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp)
+_shard_range = _sig("gpsiq_shard_range", _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _set_descriptors = _sig("gpsiq_set_descriptors", _i, _vp, _vp, _i, _i)
 _launch = _sig("gpsiq_launch", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i)
 _synchronize = _sig("gpsiq_synchronize", _i, _vp, _vp)
@@ -134,17 +137,17 @@ def quantize_blocks(desc, fs, nsamp, carry0=None):
     desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
     nb, nc = desc.shape
     q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
-    carry = carry0
-    for b in range(nb):
-        cin = None
-        if carry is not None:
-            cin = np.array(carry, dtype=np.uint64)
-            if b > 0:
-                for c in range(nc):
-                    if desc[b, c]["prn"] != desc[b - 1, c]["prn"]:
-                        cin[c] = np.uint64(int(np.floor(np.ldexp(float(desc[b, c]["carr_phase"]), 59))))
-        q[b], carry = quantize(desc[b], fs, nsamp, cin)
-    return q, carry
+    cin = None if carry0 is None else np.ascontiguousarray(carry0, dtype=np.uint64)
+    cout = np.zeros(nc, dtype=np.uint64)
+    _check(_quantize_batch(_p(desc), nb, nc, float(fs), int(nsamp), _p(q), None if cin is None else _p(cin), _p(cout)))
+    return q, cout
+
+
+def shard_range(nblocks, rank, world):
+    """gpsiq_shard_range: the contiguous block range [begin, end) of `rank`."""
+    b, e = C.c_int(0), C.c_int(0)
+    _check(_shard_range(int(nblocks), int(rank), int(world), C.byref(b), C.byref(e)))
+    return b.value, e.value
 
 
 def track_init(eph, iono, week, sec, xyz, trk):
@@ -253,6 +256,20 @@ class Context:
             return None
         out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
         _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(out), 0, co))
+        return out
+
+    def generate_quantized(self, q, nsamp, sample_size, device_ptr=None, host_ptr=None):
+        """One shard of a time-sharded run: a slice of quantize_blocks()' output -> IQ elements."""
+        q = np.ascontiguousarray(q, dtype=QCHAN_DTYPE)
+        nb, nc = q.shape
+        if host_ptr is not None:
+            _check(_generate_quantized(self._h, _p(q), nb, nc, int(nsamp), int(sample_size), _vp(host_ptr), 0))
+            return None
+        if device_ptr is not None:
+            _check(_generate_quantized(self._h, _p(q), nb, nc, int(nsamp), int(sample_size), _vp(device_ptr), 1))
+            return None
+        out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
+        _check(_generate_quantized(self._h, _p(q), nb, nc, int(nsamp), int(sample_size), _p(out), 0))
         return out
 
     # -- resident-descriptor path (device buffers) --

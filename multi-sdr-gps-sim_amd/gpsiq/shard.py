@@ -8,14 +8,7 @@ data path needs no collective (RCCL is only used for the bench's barrier / max-t
 """
 import numpy as np
 
-from . import quantize_blocks
-
-
-def shard_range(nblocks_total, rank, world):
-    """Contiguous, balanced split: the first (nblocks_total % world) ranks get one more."""
-    base, extra = divmod(int(nblocks_total), int(world))
-    b0 = rank * base + min(rank, extra)
-    return b0, b0 + base + (1 if rank < extra else 0)
+from . import quantize_blocks, shard_range  # noqa: F401  (shard_range: the C-ABI's contiguous balanced split)
 
 
 def shard_descriptors(desc_all, fs, nsamp, rank, world):

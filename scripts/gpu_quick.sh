@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-( timeout 600 python bench.py --sweep --no-cpu-baseline --steps 5 ) > gpurun_out/bench_q.log 2>&1; grep -E "device-dst|host-dst|block\]" gpurun_out/bench_q.log | tail; tail -3 gpurun_out/bench_q.log | cut -c1-300
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_q.log 2>&1; tail -15 gpurun_out/pytest_q.log

@@ -212,6 +212,30 @@ def test_batches_chain_like_one_batch(ctx, oracle):
     assert not np.array_equal(again, want[2:5])
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_quantised_shards_equal_the_batch_call(ctx, oracle, world):
+    """The C-ABI's multi-GPU recipe on one device: gpsiq_quantize_batch over the whole timeline,
+    gpsiq_shard_range per rank, gpsiq_generate_quantized per shard == one gpsiq_generate_batch
+    over everything == the oracle, including a slot that is re-allocated mid-run."""
+    fs, ns, nb, nc = 2.6e6, 52000, 21, 9
+    d = synth_blocks(nb, nc, seed=88)
+    d["prn"][6:9, 4] = 0
+    d["prn"][9:, 4] = 31
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    assert q.tobytes() == oracle.quantize_blocks(d, fs, ns).tobytes()
+    shards = []
+    for r in range(world):
+        b0, b1 = gpsiq.shard_range(nb, r, world)
+        shards.append(ctx.generate_quantized(q[b0:b1], ns, SC16))
+    got = np.concatenate(shards)
+    assert got.shape == (nb, 2 * ns)
+    whole = gpsiq.Context().generate_batch(d, ns, fs, SC16)       # fresh context: nothing handed over
+    assert np.array_equal(got, whole)
+    for b in (0, 8, 9, 20):
+        assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, SC16))
+    assert ctx.generate_quantized(q[:0], ns, SC16).shape == (0, 2 * ns)
+
+
 def test_time_sharding_is_seamless(ctx, oracle):
     """Any sub-range of blocks launched on its own equals the same blocks of one big launch
     (the property the multi-GPU time sharding rests on), and int8 == int16>>4 throughout."""

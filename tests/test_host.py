@@ -71,6 +71,67 @@ def test_quantiser_definition():
         assert int(carry[c]) == (int(q[c]["carr_phase"]) + ns * int(q[c]["carr_step"])) % (1 << 59)
 
 
+def _chain_blocks_one_by_one(d, fs, ns, carry0=None):
+    """gpsiq_quantize_batch's contract, restated with the single-block call."""
+    nb, nc = d.shape
+    q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+    carry = None if carry0 is None else np.array(carry0, dtype=np.uint64)
+    for b in range(nb):
+        cin = None
+        if carry is not None:
+            cin = carry.copy()
+            if b > 0:
+                for c in range(nc):
+                    if d[b, c]["prn"] != d[b - 1, c]["prn"]:
+                        cin[c] = np.uint64(int(np.floor(np.ldexp(float(d[b, c]["carr_phase"]), 59))))
+        q[b], carry = gpsiq.quantize(d[b], fs, ns, cin)
+    return q, carry
+
+
+@pytest.mark.parametrize("nb,with_carry", [(1, False), (7, True), (3001, False), (3001, True)])
+def test_batch_quantiser_is_the_block_quantiser_chained(nb, with_carry):
+    """Threaded gpsiq_quantize_batch == gpsiq_quantize block after block (3001 blocks span
+    many worker chunks), including slots that go idle and come back with another PRN."""
+    fs, ns = 2.6e6, 260000
+    d = synth_blocks(nb, 12, seed=77 + nb)
+    if nb > 4:
+        d["prn"][2:4, 3] = 0
+        d["prn"][4:, 3] = 21
+        d["prn"][nb // 2:, 7] = 30
+    carry0 = (np.arange(12, dtype=np.uint64) * np.uint64(0x0123456789ABCDE)) % np.uint64(1 << 59) if with_carry else None
+    q, end = gpsiq.quantize_blocks(d, fs, ns, carry0)
+    q1, end1 = _chain_blocks_one_by_one(d, fs, ns, carry0)
+    assert q.tobytes() == q1.tobytes()
+    assert (end == end1).all()
+    # and a second call gives the same bytes (the pool hands chunks out in a different order every time)
+    q2, _ = gpsiq.quantize_blocks(d, fs, ns, carry0)
+    assert q2.tobytes() == q.tobytes()
+
+
+def test_batch_quantiser_reports_the_offending_block():
+    d = synth_blocks(500, 4, seed=5)
+    d["icode"][321, 2] = 20
+    with pytest.raises(gpsiq.GpsiqError) as e:
+        gpsiq.quantize_blocks(d, 2.6e6, 260000)
+    assert e.value.code == -2 and "block 321" in str(e.value)
+    q, end = gpsiq.quantize_blocks(d[:0], 2.6e6, 260000)        # an empty timeline is fine
+    assert q.shape == (0, 4) and (end == 0).all()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("nblocks", [0, 1, 7, 8, 299, 35999])
+def test_shard_range_is_a_contiguous_balanced_partition(nblocks, world):
+    edges = [gpsiq.shard_range(nblocks, r, world) for r in range(world)]
+    assert edges[0][0] == 0 and edges[-1][1] == nblocks
+    for r in range(1, world):
+        assert edges[r][0] == edges[r - 1][1]
+    sizes = [e - b for b, e in edges]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    for bad in [(nblocks, world, world), (nblocks, -1, world), (-1, 0, world), (nblocks, 0, 0)]:
+        with pytest.raises(gpsiq.GpsiqError):
+            gpsiq.shard_range(*bad)
+
+
 @pytest.mark.parametrize("field,value", [("prn", 33), ("code_phase", 1023.0), ("code_phase", -0.5), ("carr_phase", 1.0),
                                          ("carr_phase", -0.1), ("iword", 60), ("ibit", 30), ("icode", 20),
                                          ("f_carr", 2.0e6), ("f_code", 6.0e6), ("f_code", 0.0), ("f_carr", float("nan"))])

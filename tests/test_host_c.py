@@ -85,3 +85,47 @@ def test_gpsiq_play_end_to_end(host_built, oracle, tmp_path, sink, name, ss):
     plan = oracle.chunk_plan(sink, 2 * ns, nb)
     assert len(got) == plan.sum()
     assert np.array_equal(got, want[: plan.sum()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3])
+def test_gpsiq_shard_parts_concatenate_to_the_single_run(host_built, oracle, tmp_path, world):
+    """C host, time-sharded: every rank quantises the whole timeline, renders its own block
+    range (gpsiq_shard_range + gpsiq_generate_quantized) and writes its part; the parts
+    concatenate to the stream the one-block-at-a-time program (gpsiq_play, iqfile sink) writes,
+    which is the oracle's.  All ranks share device 0 here; on a node each has its own GPU."""
+    fs, ns, nb, nc, ss = 2.6e6, 260000, 10, 12, SC16
+    d = synth_blocks(nb, nc, seed=17)
+    d["prn"][4:, 5] = 0
+    d["prn"][7:, 5] = 29           # slot re-allocated inside the last shard
+    dpath = str(tmp_path / "desc.bin")
+    write_descriptors(dpath, d, fs, ns, ss)
+    parts = []
+    for r in range(world):
+        out = str(tmp_path / f"part{r}.bin")
+        p = subprocess.run([os.path.join(host_built, "gpsiq_shard"), dpath, out, str(r), str(world), "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        parts.append(np.fromfile(out, dtype=np.int16))
+    got = np.concatenate(parts)
+    q = oracle.quantize_blocks(d, fs, ns)
+    want = np.concatenate([oracle.block_fixed(q[b], ns, ss, seq=True) for b in range(nb)])
+    assert np.array_equal(got, want)
+    single = str(tmp_path / "single.bin")
+    p = subprocess.run([os.path.join(host_built, "gpsiq_play"), dpath, single, "iqfile"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert np.array_equal(np.fromfile(single, dtype=np.int16), got)
+
+
+def test_c_hosts_fail_loudly_without_a_gpu(host_built, tmp_path):
+    """No CPU fallback anywhere: on a box without a GPU both C programs stop at gpsiq_create."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    d = synth_blocks(2, 4, seed=1)
+    dpath = str(tmp_path / "desc.bin")
+    write_descriptors(dpath, d, 2.6e6, 260000, SC08)
+    for argv in (["gpsiq_play", dpath, str(tmp_path / "o.bin")], ["gpsiq_shard", dpath, str(tmp_path / "p.bin"), "0", "1"]):
+        p = subprocess.run([os.path.join(host_built, argv[0])] + argv[1:], capture_output=True, text=True, timeout=120)
+        assert p.returncode != 0
+        assert "gpsiq" in p.stderr and "device" in p.stderr.lower(), p.stderr
