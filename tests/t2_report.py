@@ -2,7 +2,7 @@
 """Tier T2 report: a whole BASELINE config-1 length run (299 blocks = 29.9 s)
 through the reference's own loop (carrier phase carried by its double accumulator) against
 the fixed-point oracle with the library's exact carrier carry.  CPU only; needs oracle/_ref.
-Usage: python scripts/t2_report.py [fs] [nchan] [nblocks]"""
+Usage: python tests/t2_report.py [fs] [nchan] [nblocks]"""
 import os
 import sys
 import time
