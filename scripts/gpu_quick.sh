@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-{ nproc; cat /sys/fs/cgroup/cpu.max 2>&1; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us /sys/fs/cgroup/cpu/cpu.cfs_period_us 2>&1; python -c "import os; print(len(os.sched_getaffinity(0)))"; cat /proc/self/cgroup; lscpu | grep -E "Model name|Socket|Core|Thread|MHz"; cat /sys/fs/cgroup/cpu.stat 2>&1 | head -8; } > gpurun_out/cpuinfo.log 2>&1; cat gpurun_out/cpuinfo.log
+( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fuzz" 2>&1 | tail -15 ) > gpurun_out/pytest_q.log 2>&1; tail -15 gpurun_out/pytest_q.log

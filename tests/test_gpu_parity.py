@@ -317,6 +317,37 @@ def test_quantised_descriptor_fuzz(ctx, oracle, variant):
                 assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, ss)), (case, b, ss)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_quantised_descriptor_fuzz_long_blocks(ctx, oracle, seed):
+    """The same kind of random quantised descriptors over blocks long enough to cross tile
+    and chunk boundaries of every row kernel (32768-sample tiles, up to 4 chunks per wave),
+    with block lengths that leave partial rows and partial tiles, and a strided destination."""
+    from gpsiq.abi import QCHAN_DTYPE
+    rng = np.random.default_rng(7700 + seed)
+    max_step = ((31 << 56) - 1) // 63
+    nb, nc = 3, int(rng.choice([3, 4, 7, 8, 11, 12, 16]))
+    ns = int(rng.choice([32768, 32769, 65535, 131072 + 64, 200001, 262144 + 17]))
+    q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+    q["prn"] = rng.integers(0, 33, size=(nb, nc))
+    q["carr_phase"] = rng.integers(0, 1 << 59, size=(nb, nc), dtype=np.uint64)
+    q["carr_step"] = rng.integers(-(1 << 58) + 1, 1 << 58, size=(nb, nc))
+    q["code_frac"] = rng.integers(0, 1 << 56, size=(nb, nc), dtype=np.uint64)
+    # keep the block inside the 32 nav bits a descriptor carries (icode and chip0 add up to one more bit)
+    room = (30 * 20 * 1023) << 56
+    q["code_step"] = rng.integers(1, min(max_step, room // ns) + 1, size=(nb, nc), dtype=np.uint64)
+    q["chip0"] = rng.integers(0, 1023, size=(nb, nc))
+    q["icode"] = rng.integers(0, 20, size=(nb, nc))
+    q["nav_bits"] = rng.integers(0, 1 << 32, size=(nb, nc), dtype=np.uint64).astype(np.uint32)
+    q["gain"] = rng.choice([0.0, -0.7, 1.0, 0.3333, 2.0, 1e-3], size=(nb, nc))
+    ctx.set_descriptors(q)
+    want = {ss: [oracle.block_fixed(q[b], ns, ss) for b in range(nb)] for ss in (SC08, SC16)}
+    for variant in VARIANTS:
+        for ss in (SC08, SC16):
+            got = run_device(ctx, q, ns, ss, variant)
+            for b in range(nb):
+                assert np.array_equal(got[b], want[ss][b]), (variant, ss, b, ns, nc)
+
+
 def test_empty_and_maximum_block_sizes(ctx, oracle):
     """Empty launches are no-ops; the longest block the descriptor format allows (32 nav bits
     = 0.62 s of signal) is exact from the first to the last sample; one sample more is an error."""
