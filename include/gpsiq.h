@@ -343,6 +343,17 @@ int gpsiq_chunker_init(gpsiq_chunker_t *ck, int sink_kind, int sample_size,
  * sample_size) through the rules of gps.c:2839-2865.  Returns number of buffers
  * enqueued, or negative on error (acquire returned NULL = FIFO halted). */
 int gpsiq_chunker_push(gpsiq_chunker_t *ck, const void *elems, size_t nelem);
+/* In-place form for the sinks that take one block per buffer (iqfile, Pluto; gps.c:2860-2865):
+ * gpsiq_chunker_reserve returns where the next nelem elements go inside the buffer being
+ * filled (iq->data8 / iq->data16 at validLength), so that gpsiq_generate_block can write its
+ * block there directly -- with page-locked fifo buffers the device-to-host copy lands in
+ * place and the block is never copied on the host.  It returns NULL (no error recorded) when
+ * the block cannot be contiguous in one buffer (HackRF's 262144-element chunks, or a buffer
+ * that is too small): use gpsiq_chunker_push then.  gpsiq_chunker_commit hands over what was
+ * written at the reserved position (validLength += nelem, enqueue, acquire the next buffer);
+ * returns the number of buffers enqueued (1) or negative on error. */
+void *gpsiq_chunker_reserve(gpsiq_chunker_t *ck, size_t nelem);
+int   gpsiq_chunker_commit(gpsiq_chunker_t *ck, size_t nelem);
 
 #ifdef __cplusplus
 }

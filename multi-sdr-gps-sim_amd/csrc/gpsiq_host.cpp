@@ -386,4 +386,26 @@ int gpsiq_chunker_push(gpsiq_chunker_t *ck, const void *elems, size_t nelem)
     return enq;
 }
 
+void *gpsiq_chunker_reserve(gpsiq_chunker_t *ck, size_t nelem)
+{
+    if (!ck || !ck->cur || ck->sink_kind == GPSIQ_SINK_HACKRF) return nullptr;
+    gpsiq_iq_buf_t *b = ck->cur;
+    if ((size_t) b->validLength + nelem > (size_t) b->totalLength) return nullptr;
+    return ck->sample_size == GPSIQ_SC16 ? (void *) (b->data16 + b->validLength) : (void *) (b->data8 + b->validLength);
+}
+
+int gpsiq_chunker_commit(gpsiq_chunker_t *ck, size_t nelem)
+{
+    if (!ck) return fail(GPSIQ_E_ARG, "null chunker argument");
+    if (!ck->cur) return fail(GPSIQ_E_STATE, "fifo halted");
+    if (ck->sink_kind == GPSIQ_SINK_HACKRF) return fail(GPSIQ_E_STATE, "HackRF chunks are not handed over in place");
+    gpsiq_iq_buf_t *b = ck->cur;
+    if ((size_t) b->validLength + nelem > (size_t) b->totalLength)
+        return fail(GPSIQ_E_RANGE, "commit of %zu elements overruns the fifo buffer of %u", nelem, b->totalLength);
+    b->validLength += (unsigned) nelem;
+    ck->enqueue(ck->user, b);                      // gps.c:2860-2864
+    if (!(ck->cur = ck->acquire(ck->user))) return fail(GPSIQ_E_STATE, "fifo halted");
+    return 1;
+}
+
 }  // extern "C"

@@ -90,9 +90,12 @@ int main(int argc, char **argv)
         for (uint32_t i = 0; b > 0 && i < h.nchan; ++i)          /* chan[i].carr_phase persists (gps.c:2821) */
             if (cur[i].prn > 0 && cur[i].prn == desc[(size_t) (b - 1) * h.nchan + i].prn)
                 cur[i].carr_phase = carr[i];
-        rc = gpsiq_generate_block(gq, cur, (int) h.nchan, (int) h.nsamp, h.fs, (int) h.sample_size, blk, carr);
+        /* iqfile / Pluto take one block per buffer: synthesise straight into the page-locked fifo
+           buffer; HackRF's 262144-element chunks (gps.c:2847-2856) go through the staging block */
+        void *inplace = gpsiq_chunker_reserve(&ck, block_elems);
+        rc = gpsiq_generate_block(gq, cur, (int) h.nchan, (int) h.nsamp, h.fs, (int) h.sample_size, inplace ? inplace : blk, carr);
         if (rc != GPSIQ_OK) break;
-        int n = gpsiq_chunker_push(&ck, blk, block_elems);
+        int n = inplace ? gpsiq_chunker_commit(&ck, block_elems) : gpsiq_chunker_push(&ck, blk, block_elems);
         if (n < 0) rc = n;
     }
     if (rc != GPSIQ_OK) fprintf(stderr, "gpsiq: %s\n", gpsiq_last_error());

@@ -167,7 +167,7 @@ class Chunker(C.Structure):
                 ("sink_kind", C.c_int), ("sample_size", C.c_int)]
 
 
-def run_chunker(sink, ss, blocks, buf_len):
+def run_chunker(sink, ss, blocks, buf_len, in_place=False):
     lib = C.CDLL(gpsiq.LIB_PATH)
     dt = np.int8 if ss == SC08 else np.int16
     pool, enq = [], []
@@ -196,8 +196,16 @@ def run_chunker(sink, ss, blocks, buf_len):
     lib.gpsiq_chunker_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     assert lib.gpsiq_chunker_init(C.byref(ck), sink, ss, a, e, None) == 0
     total = 0
+    lib.gpsiq_chunker_reserve.argtypes = [C.c_void_p, C.c_size_t]
+    lib.gpsiq_chunker_reserve.restype = C.c_void_p
+    lib.gpsiq_chunker_commit.argtypes = [C.c_void_p, C.c_size_t]
     for blk in blocks:
-        n = lib.gpsiq_chunker_push(C.byref(ck), blk.ctypes.data, blk.size)
+        where = lib.gpsiq_chunker_reserve(C.byref(ck), blk.size) if in_place else None
+        if where:                      # the producer writes into the fifo buffer itself
+            C.memmove(where, blk.ctypes.data, blk.nbytes)
+            n = lib.gpsiq_chunker_commit(C.byref(ck), blk.size)
+        else:
+            n = lib.gpsiq_chunker_push(C.byref(ck), blk.ctypes.data, blk.size)
         assert n >= 0, gpsiq._last_error()
         total += n
     assert total == len(enq)
@@ -217,6 +225,24 @@ def test_chunker_follows_reference_rules(oracle, sink, ss):
     assert [len(x) for x in enq] == list(plan)
     flat = np.concatenate(blocks)
     assert np.array_equal(np.concatenate(enq), flat[: plan.sum()])
+
+
+@pytest.mark.parametrize("sink", [SINK_IQFILE, SINK_HACKRF, SINK_PLUTOSDR])
+def test_chunker_in_place_handoff_equals_push(sink):
+    """reserve/commit (block written straight into the fifo buffer) enqueues exactly what push
+    does; HackRF chunks and too-small buffers decline the reservation instead."""
+    rng = np.random.default_rng(3)
+    nelem, nb = 520000, 4
+    blocks = [rng.integers(-100, 100, size=nelem).astype(np.int16) for _ in range(nb)]
+    buf_len = 262144 if sink == SINK_HACKRF else nelem
+    a = run_chunker(sink, SC16, blocks, buf_len, in_place=True)
+    b = run_chunker(sink, SC16, blocks, buf_len, in_place=False)
+    assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    if sink != SINK_HACKRF:
+        assert [len(x) for x in a] == [nelem] * nb
+        # a buffer smaller than the block: no reservation, and push reports the misfit
+        with pytest.raises(AssertionError):
+            run_chunker(sink, SC16, blocks, nelem - 2, in_place=True)
 
 
 def test_chunker_matches_reference_capture():
