@@ -11,6 +11,7 @@
 //   * nothing is read from HBM per sample: the only traffic is the IQ write.
 // No MFMA: there is no contraction in this path; it is integer VALU + LDS gather.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "gpsiq_internal.h"
 
@@ -394,7 +395,7 @@ template <int FMT, int NCH, int ROWS>
 __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
     size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block,
-    int chunks)
+    int chunks, int big_wgs, int big_blocks, int tiles_small)
 {
     __shared__ uint32_t lut[NCH][512];
     __shared__ uint32_t ext[NCH][kPrnExtWords];
@@ -402,7 +403,17 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     __shared__ gpsiq_qchan_t qs[NCH];
 
     const int tid = threadIdx.x;
-    const int blk = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    // workgroups [0, big_wgs) run `chunks` chunks per wave over blocks [0, big_blocks); the rest
+    // of the grid covers the last blocks with one-chunk workgroups, so that what is still
+    // running when the grid drains is short (workgroups are dispatched in id order)
+    int blk, tile;
+    if ((int) blockIdx.x < big_wgs) {
+        blk = blockIdx.x / tiles_per_block; tile = blockIdx.x % tiles_per_block;
+    } else {
+        const int r = (int) blockIdx.x - big_wgs;
+        blk = big_blocks + r / tiles_small; tile = r % tiles_small;
+        chunks = 1;
+    }
     const gpsiq_qchan_t *q_blk = desc + (size_t) (block0 + blk) * nchan;
     const int nq = nchan < NCH ? nchan : NCH;
     for (int i = tid; i < NCH * 12; i += kRowsThreads)
@@ -546,6 +557,20 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
 }
 
 // ---------------------------------------------------------------------------
+// Grid-shape policy of the seg variant; the defaults can be overridden for experiments with
+// GPSIQ_SEG_MIN_WGS / GPSIQ_SEG_TAIL_WGS (read once).
+struct SegPolicy { long min_wgs; int tail_wgs; };
+static const SegPolicy &seg_policy()
+{
+    static const SegPolicy pol = [] {
+        SegPolicy p = {8192, 512};
+        if (const char *e = std::getenv("GPSIQ_SEG_MIN_WGS")) p.min_wgs = std::atol(e);
+        if (const char *e = std::getenv("GPSIQ_SEG_TAIL_WGS")) p.tail_wgs = std::atoi(e);
+        return p;
+    }();
+    return pol;
+}
+
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
                           const DeviceTables *tab, hipStream_t stream, int max_active)
@@ -555,21 +580,30 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
     if (variant == kTile || variant == kSeg) {
         constexpr int rows = 64;
         const int rows_total = (nsamp + 63) / 64;
-        // seg: up to 8 chunks per wave (one workgroup covers 262144 samples = a 2.6 Msps block),
-        // fewer when that would leave CUs without work
+        // seg: several chunks per wave amortise the per-workgroup set-up (LUT build, start
+        // products), but long workgroups make the drain of the grid expensive: the grid must
+        // stay several rounds deep, and the last blocks are covered by one-chunk workgroups
+        // so that the drain is a quarter as long.
         int chunks = 1;
+        const int tiles1 = (rows_total + kWaves * rows - 1) / (kWaves * rows);
+        int tail_blocks = 0;
         if (variant == kSeg) {
-            // more chunks per wave amortise the per-workgroup set-up, but the grid must stay
-            // many rounds deep (512 resident workgroups) or the tail round eats the gain
+            const SegPolicy &pol = seg_policy();
             for (int cand = 4; cand > 1; cand >>= 1) {
                 const long wgs = (long) nblocks * ((rows_total + kWaves * rows * cand - 1) / (kWaves * rows * cand));
-                if (wgs >= 8192) { chunks = cand; break; }
+                if (wgs >= pol.min_wgs) { chunks = cand; break; }
+            }
+            if (chunks > 1) {
+                tail_blocks = (pol.tail_wgs + tiles1 - 1) / tiles1;
+                if (tail_blocks > nblocks / 2) tail_blocks = nblocks / 2;
             }
         }
         const int wg_rows = kWaves * rows * chunks;
         const int tiles = (rows_total + wg_rows - 1) / wg_rows;
-        dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
-#define GPSIQ_LAUNCH_T(F, N) hipLaunchKernelGGL((synth_tile<F, N, rows>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, chunks)
+        const int big_blocks = nblocks - tail_blocks;
+        const int big_wgs = tiles * big_blocks;
+        dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kRowsThreads);
+#define GPSIQ_LAUNCH_T(F, N) hipLaunchKernelGGL((synth_tile<F, N, rows>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, chunks, big_wgs, big_blocks, tiles1)
         const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
         if (sample_size == GPSIQ_SC16) {
             if (slots == 4) GPSIQ_LAUNCH_T(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_T(GPSIQ_SC16, 8);
