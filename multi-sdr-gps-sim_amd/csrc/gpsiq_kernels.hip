@@ -559,13 +559,14 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
 // ---------------------------------------------------------------------------
 // Grid-shape policy of the seg variant; the defaults can be overridden for experiments with
 // GPSIQ_SEG_MIN_WGS / GPSIQ_SEG_TAIL_WGS (read once).
-struct SegPolicy { long min_wgs; int tail_wgs; };
+struct SegPolicy { long min_wgs; int tail_wgs; int max_chunks; };
 static const SegPolicy &seg_policy()
 {
     static const SegPolicy pol = [] {
-        SegPolicy p = {8192, 512};
+        SegPolicy p = {8192, 512, 4};
         if (const char *e = std::getenv("GPSIQ_SEG_MIN_WGS")) p.min_wgs = std::atol(e);
         if (const char *e = std::getenv("GPSIQ_SEG_TAIL_WGS")) p.tail_wgs = std::atoi(e);
+        if (const char *e = std::getenv("GPSIQ_SEG_MAX_CHUNKS")) p.max_chunks = std::atoi(e);
         return p;
     }();
     return pol;
@@ -589,7 +590,7 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
         int tail_blocks = 0;
         if (variant == kSeg) {
             const SegPolicy &pol = seg_policy();
-            for (int cand = 4; cand > 1; cand >>= 1) {
+            for (int cand = pol.max_chunks; cand > 1; cand >>= 1) {
                 const long wgs = (long) nblocks * ((rows_total + kWaves * rows * cand - 1) / (kWaves * rows * cand));
                 if (wgs >= pol.min_wgs) { chunks = cand; break; }
             }
