@@ -80,7 +80,7 @@ static int ensure_out(gpsiq_ctx *c, size_t bytes)
 static int pick_variant(const gpsiq_ctx *c, int variant)
 {
     if (variant == kAuto)
-        return c->max_code_step <= kRowsMaxCodeStep ? kSeg : kGeneric;
+        return c->max_code_step <= kRowsMaxCodeStep ? kSeg : c->max_code_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
     return variant;
 }
 
@@ -96,7 +96,9 @@ static int check_launch(const gpsiq_ctx *c, int block0, int nblocks, int nsamp, 
     if (stride < (size_t) 2 * (size_t) nsamp * (size_t) sample_size || (stride & 3))
         return fail(GPSIQ_E_ARG, "block stride %zu too small or not a multiple of 4", stride);
     if (variant < 0 || variant >= kNumVariants) return fail(GPSIQ_E_ARG, "unknown variant %d", variant);
-    if (variant >= kRows && c->max_code_step > kRowsMaxCodeStep)
+    if (variant == kSegHalf && c->max_code_step > kHalfRowsMaxCodeStep)
+        return fail(GPSIQ_E_RANGE, "half-row kernel needs f_code/fs <= 1 chip per sample");
+    if (variant >= kRows && variant != kSegHalf && c->max_code_step > kRowsMaxCodeStep)
         return fail(GPSIQ_E_RANGE, "row kernel needs f_code/fs <= 31/63 chip per sample");
     return GPSIQ_OK;
 }
@@ -282,6 +284,7 @@ const char *gpsiq_variant_name(int v)
     case kRowsX: return "rowsx";
     case kTile: return "tile";
     case kSeg: return "seg";
+    case kSegHalf: return "segh";
     default: return "?";
     }
 }

@@ -35,12 +35,16 @@ enum Variant {
     kRowsX = 3,     // same rows, channel-inner loop order with all NCO state in registers
     kTile = 4,      // rowsx with trimmed per-tile overhead, 64 rows per wave (32768-sample tiles)
     kSeg = 5,       // tile kernel, each wave running several consecutive 64-row chunks
+    kSegHalf = 6,   // seg with one window per 32 samples: for sample rates down to 1.023 Msps
     kNumVariants
 };
 
 // The row kernel needs all 64 lanes of a row inside one 32-chip window:
 // 63*code_step + (1 chip) <= 32 chips.
 constexpr uint64_t kRowsMaxCodeStep = ((UINT64_C(31) << GPSIQ_CODE_FRAC_BITS) - 1) / 63;
+// With a window per half row (32 lanes): 31*code_step + (1 chip) <= 32 chips, i.e. up to one
+// chip per sample (fs >= 1.023 Msps).
+constexpr uint64_t kHalfRowsMaxCodeStep = ((UINT64_C(31) << GPSIQ_CODE_FRAC_BITS) - 1) / 31;
 
 }  // namespace gpsiq
 #endif

@@ -382,37 +382,44 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
 // Tile kernel ("tile"/"seg"): the row kernel in channel-inner order with the per-tile
 // overhead trimmed, because the path is VALU-issue bound (profiles/r01_pmc_counters.txt:
 // 9.7 VALU instructions per (channel,row) against 7 in the core):
-//   * a wave owns `chunks` consecutive chunks of ROWS rows (a contiguous run of samples):
+//   * a wave owns `wave_rows` consecutive rows, worked in chunks of ROWS rows (the last chunk
+//     may be partial), i.e. one contiguous run of samples:
 //     the per-lane NCO words and the window-builder state simply continue from chunk to
 //     chunk, so the start products, the mod-1023 / mod-20 set-up and the LUT build are
-//     paid once per workgroup, not once per 64 rows ("seg": chunks > 1, one workgroup
-//     per block at 2.6 Msps; "tile": chunks = 1 for small launches);
+//     paid once per workgroup, not once per 64 rows ("seg": the host cuts every block into
+//     equal runs of ~250 rows per wave; "tile": wave_rows = ROWS);
 //   * LUT build: thread k owns LUT entry k of every channel, so sin/cos of k are formed
 //     once and each entry costs two f64 multiplies and two truncations;
 //   * window set-up in 32-bit chip arithmetic (a block never advances 2^32 chips);
 //   * a chunk whose rows all lie inside the block runs a check-free row loop.
-template <int FMT, int NCH, int ROWS>
+//   * H = 2 ("segh"): one window per HALF row (32 lanes), so a row may span up to 63 chips
+//     and the kernel works down to one chip per sample (1.023 Msps); lanes 32..63 read the
+//     second window of their row (two LDS addresses per wave read instead of one).
+template <int FMT, int NCH, int ROWS, int H>
 __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
     size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block,
-    int chunks, int big_wgs, int big_blocks, int tiles_small)
+    int wave_rows, int big_wgs, int big_blocks, int tiles_small)
 {
     __shared__ uint32_t lut[NCH][512];
     __shared__ uint32_t ext[NCH][kPrnExtWords];
-    __shared__ uint32_t win[kWaves][ROWS][NCH];
+    __shared__ uint32_t win[kWaves][ROWS * H][NCH];     // one window per (row or half row, channel)
     __shared__ gpsiq_qchan_t qs[NCH];
+    static_assert(H == 1 || H == 2, "one window per row or per half row");
+    constexpr int kSpan = 64 / H;                        // samples per window
 
     const int tid = threadIdx.x;
-    // workgroups [0, big_wgs) run `chunks` chunks per wave over blocks [0, big_blocks); the rest
-    // of the grid covers the last blocks with one-chunk workgroups, so that what is still
-    // running when the grid drains is short (workgroups are dispatched in id order)
+    // workgroups [0, big_wgs) give every wave `wave_rows` consecutive rows (several chunks of
+    // ROWS rows, the last one possibly partial) of blocks [0, big_blocks); the rest of the grid
+    // covers the last blocks with one-chunk workgroups, so that what is still running when the
+    // grid drains is short (workgroups are dispatched in id order)
     int blk, tile;
     if ((int) blockIdx.x < big_wgs) {
         blk = blockIdx.x / tiles_per_block; tile = blockIdx.x % tiles_per_block;
     } else {
         const int r = (int) blockIdx.x - big_wgs;
         blk = big_blocks + r / tiles_small; tile = r % tiles_small;
-        chunks = 1;
+        wave_rows = ROWS;
     }
     const gpsiq_qchan_t *q_blk = desc + (size_t) (block0 + blk) * nchan;
     const int nq = nchan < NCH ? nchan : NCH;
@@ -438,15 +445,15 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     uint8_t *blk_dst = dst + (size_t) blk * block_stride;
 
     const int wave = tid >> 6, lane = tid & 63;
-    const uint32_t wave_samples = (uint32_t) chunks * (ROWS * 64);
+    const uint32_t wave_samples = (uint32_t) wave_rows * 64u;
     const uint32_t n_wave = ((uint32_t) tile * kWaves + (uint32_t) wave) * wave_samples;
     if (n_wave >= (uint32_t) nsamp) return;             // whole wave past the block end
 
-    // ---- window builder: lane (c, g) prepares rows g, g+G, g+2G, ... of channel c ----
-    constexpr int kPad = NCH <= 4 ? 4 : NCH <= 8 ? 8 : 16;   // lanes per row group
+    // ---- window builder: lane (c, g) prepares windows g, g+G, g+2G, ... of channel c ----
+    constexpr int kPad = NCH <= 4 ? 4 : NCH <= 8 ? 8 : 16;   // lanes per window group
     constexpr int kGroups = 64 / kPad;
-    constexpr int kRun = ROWS / kGroups;
-    static_assert(ROWS % kGroups == 0, "rows per chunk must split over the lane groups");
+    constexpr int kRun = ROWS * H / kGroups;
+    static_assert((ROWS * H) % kGroups == 0, "windows per chunk must split over the lane groups");
     const int c_raw = lane % kPad, wg = lane / kPad;
     const int wc = c_raw < NCH ? c_raw : 0;                  // surplus lanes shadow channel 0
     const bool w_store = c_raw < NCH;
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     {
         const gpsiq_qchan_t &q = qs[wc];
         w_on = q.prn != 0 ? 0xffffffffu : 0u;
-        const uint32_t n_row = n_wave + (uint32_t) wg * 64u;
+        const uint32_t n_row = n_wave + (uint32_t) wg * (uint32_t) kSpan;
         const unsigned __int128 T = (unsigned __int128) q.code_frac +
                                     (unsigned __int128) q.code_step * (unsigned __int128) n_row;
         const uint32_t A = (uint32_t) q.chip0 + (uint32_t) (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
@@ -465,8 +472,9 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         w_icur = ic % 20u;
         w_navw = q.nav_bits >> ((ic / 20u) & 31u);               // bit 0 = current nav bit
         w_rot = A;                                               // only A mod 32 matters
-        // chips per builder step: 64*kGroups samples (<= 1024 * 0.5 chips: one period wrap at most)
-        const unsigned __int128 step = (unsigned __int128) q.code_step * (unsigned) (64 * kGroups);
+        // chips per builder step: kSpan*kGroups samples (<= 1024 samples at <= 0.5 chip, or
+        // <= 512 samples at <= 1 chip: one period wrap at most)
+        const unsigned __int128 step = (unsigned __int128) q.code_step * (unsigned) (kSpan * kGroups);
         w_dint = (uint32_t) (uint64_t) (step >> GPSIQ_CODE_FRAC_BITS);
         w_dfr = (uint64_t) step & kCodeFracMask;
     }
@@ -487,14 +495,14 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     }
 
     const unsigned char *lut_b = reinterpret_cast<const unsigned char *>(&lut[0][0]);
-    const uint32_t *w_row = &win[wave][0][0];
+    const uint32_t *w_row = &win[wave][H == 2 ? lane >> 5 : 0][0];   // upper half wave: second window of the row
     uint32_t *w_dst = &win[wave][wg][wc];
 
     auto row_body = [&](int r, uint32_t n_chunk, bool check) {
         s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const uint32_t w = w_row[r * NCH + c];
+            const uint32_t w = w_row[r * (H * NCH) + c];
             const uint32_t b = (uint32_t) (Q[c] >> 56);
             const uint32_t m = (uint32_t) __builtin_amdgcn_sbfe((int) w, b, 1u);
             const uint32_t sgn = m | 0x00010001u;
@@ -510,9 +518,8 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
             store_sample<FMT>(blk_dst, n, __builtin_bit_cast(uint32_t, acc0 + acc1));
     };
 
-    for (int ch = 0; ch < chunks; ++ch) {
-        const uint32_t n_chunk = n_wave + (uint32_t) ch * (ROWS * 64);
-        if (n_chunk >= (uint32_t) nsamp) break;          // wave-uniform
+    for (int row0 = 0; row0 < wave_rows; row0 += ROWS) {
+        const uint32_t n_chunk = n_wave + (uint32_t) row0 * 64u;
         // windows of this chunk (the builder state carries over from the previous chunk)
 #pragma unroll 4
         for (int i = 0; i < kRun; ++i) {
@@ -541,11 +548,14 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        if (n_chunk + (uint32_t) (ROWS * 64) <= (uint32_t) nsamp) {
+        int rows = wave_rows - row0;                         // the wave's last chunk may be partial
+        rows = rows < ROWS ? rows : ROWS;
+        if (n_chunk + (uint32_t) rows * 64u <= (uint32_t) nsamp) {
 #pragma unroll 1
-            for (int r = 0; r < ROWS; ++r) row_body(r, n_chunk, false);
-        } else {
-            const int rows = (int) (((uint32_t) nsamp - n_chunk + 63u) >> 6);
+            for (int r = 0; r < rows; ++r) row_body(r, n_chunk, false);
+        } else {                                             // the block ends inside this chunk
+            const int in_block = (int) (((uint32_t) nsamp - n_chunk + 63u) >> 6);
+            rows = rows < in_block ? rows : in_block;
 #pragma unroll 1
             for (int r = 0; r < rows; ++r) row_body(r, n_chunk, true);
         }
@@ -557,16 +567,23 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
 }
 
 // ---------------------------------------------------------------------------
-// Grid-shape policy of the seg variant; the defaults can be overridden for experiments with
-// GPSIQ_SEG_MIN_WGS / GPSIQ_SEG_TAIL_WGS (read once).
-struct SegPolicy { long min_wgs; int tail_wgs; int max_chunks; };
+// Grid-shape policy of the seg variants; the defaults can be overridden for experiments with
+// GPSIQ_SEG_TAIL_WGS / GPSIQ_SEG_MAX_WAVE_ROWS / GPSIQ_SEG_SETUP_ROWS / GPSIQ_SEG_DRAIN (read once).
+struct SegPolicy {
+    int    tail_wgs;        // one-chunk workgroups at the end of the grid
+    int    max_wave_rows;   // longest run of rows a wave may own
+    double setup_rows;      // per-workgroup set-up, in row-times (measured: tile vs seg = 4 %)
+    double drain_rounds;    // time lost while the grid drains, in workgroup durations
+    double resident_wgs;    // 256 CUs x 2 workgroups (67 KB LDS each)
+};
 static const SegPolicy &seg_policy()
 {
     static const SegPolicy pol = [] {
-        SegPolicy p = {8192, 512, 4};
-        if (const char *e = std::getenv("GPSIQ_SEG_MIN_WGS")) p.min_wgs = std::atol(e);
+        SegPolicy p = {512, 512, 3.5, 0.3, 512.0};
         if (const char *e = std::getenv("GPSIQ_SEG_TAIL_WGS")) p.tail_wgs = std::atoi(e);
-        if (const char *e = std::getenv("GPSIQ_SEG_MAX_CHUNKS")) p.max_chunks = std::atoi(e);
+        if (const char *e = std::getenv("GPSIQ_SEG_MAX_WAVE_ROWS")) p.max_wave_rows = std::atoi(e);
+        if (const char *e = std::getenv("GPSIQ_SEG_SETUP_ROWS")) p.setup_rows = std::atof(e);
+        if (const char *e = std::getenv("GPSIQ_SEG_DRAIN")) p.drain_rounds = std::atof(e);
         return p;
     }();
     return pol;
@@ -578,33 +595,42 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
 {
     if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
     uint8_t *d = static_cast<uint8_t *>(dst);
-    if (variant == kTile || variant == kSeg) {
-        constexpr int rows = 64;
+    if (variant == kTile || variant == kSeg || variant == kSegHalf) {
+        const bool half = variant == kSegHalf;
+        const int rows = half ? 32 : 64;                  // rows per chunk (the window array holds 64 windows per wave)
         const int rows_total = (nsamp + 63) / 64;
-        // seg: several chunks per wave amortise the per-workgroup set-up (LUT build, start
-        // products), but long workgroups make the drain of the grid expensive: the grid must
-        // stay several rounds deep, and the last blocks are covered by one-chunk workgroups
-        // so that the drain is a quarter as long.
-        int chunks = 1;
+        // seg: many rows per wave amortise the per-workgroup set-up (LUT build, start products),
+        // but long workgroups make the drain of the grid expensive.  Every block is cut into
+        // nwg workgroups whose 8 waves all get the same number of rows, so no wave idles while
+        // its workgroup holds a CU slot, whatever the block length.  nwg maximises
+        //   (rows used / rows scheduled) x (rows per wave / (rows per wave + set-up)) x (rounds / (rounds + drain)),
+        // a model fitted to the measured variant sweeps; the last blocks are covered by
+        // one-chunk workgroups so that the drain is short.
         const int tiles1 = (rows_total + kWaves * rows - 1) / (kWaves * rows);
-        int tail_blocks = 0;
-        if (variant == kSeg) {
+        int wave_rows = rows, tiles = tiles1, tail_blocks = 0;
+        if (variant != kTile) {
             const SegPolicy &pol = seg_policy();
-            for (int cand = pol.max_chunks; cand > 1; cand >>= 1) {
-                const long wgs = (long) nblocks * ((rows_total + kWaves * rows * cand - 1) / (kWaves * rows * cand));
-                if (wgs >= pol.min_wgs) { chunks = cand; break; }
+            double best = 0.0;
+            for (int nwg = 1; nwg <= tiles1; ++nwg) {
+                const int wr = (rows_total + kWaves * nwg - 1) / (kWaves * nwg);
+                if (wr > pol.max_wave_rows) continue;
+                if (wr < rows && nwg < tiles1) break;
+                const double fill = (double) rows_total / ((double) kWaves * nwg * wr);
+                const double amort = (double) wr / ((double) wr + pol.setup_rows);
+                const double rounds = (double) nblocks * nwg / pol.resident_wgs;
+                const double score = fill * amort * rounds / (rounds + pol.drain_rounds);
+                if (score > best) { best = score; wave_rows = wr > rows ? wr : rows; tiles = nwg; }
             }
-            if (chunks > 1) {
+            if (wave_rows > rows) {
                 tail_blocks = (pol.tail_wgs + tiles1 - 1) / tiles1;
                 if (tail_blocks > nblocks / 2) tail_blocks = nblocks / 2;
             }
         }
-        const int wg_rows = kWaves * rows * chunks;
-        const int tiles = (rows_total + wg_rows - 1) / wg_rows;
         const int big_blocks = nblocks - tail_blocks;
         const int big_wgs = tiles * big_blocks;
         dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kRowsThreads);
-#define GPSIQ_LAUNCH_T(F, N) hipLaunchKernelGGL((synth_tile<F, N, rows>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, chunks, big_wgs, big_blocks, tiles1)
+#define GPSIQ_LAUNCH_T(F, N) do { if (half) hipLaunchKernelGGL((synth_tile<F, N, 32, 2>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1); \
+                                  else hipLaunchKernelGGL((synth_tile<F, N, 64, 1>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1); } while (0)
         const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
         if (sample_size == GPSIQ_SC16) {
             if (slots == 4) GPSIQ_LAUNCH_T(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_T(GPSIQ_SC16, 8);

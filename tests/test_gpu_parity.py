@@ -12,7 +12,7 @@ from test_golden import CASES, load_case
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["generic", "rows", "rowsx", "tile", "seg"]
+VARIANTS = ["generic", "rows", "rowsx", "tile", "seg", "segh"]
 
 
 @pytest.fixture(scope="module")
@@ -138,17 +138,56 @@ def test_int8_wraps_like_the_reference(ctx, oracle, variant):
     assert np.array_equal(run_device(ctx, q, ns, SC16, variant)[0], oracle.block_fixed(q[0], ns, SC16))
 
 
-def test_low_sample_rate_uses_generic_kernel(ctx, oracle):
-    """f_code/fs > 31/63: the row kernel's 32-chip window does not hold a row; auto falls
-    back to the generic kernel and asking for the row kernel is an error, not wrong output."""
-    d = synth_blocks(1, 6, seed=41)
-    fs, ns = 1.5e6, 20000
+@pytest.mark.parametrize("fs,expect", [(2.048e6, "segh"), (2.0e6, "segh"), (1.5e6, "segh"), (1.1e6, "segh"),
+                                       (1.0e6, "generic"), (0.6e6, "generic")])
+def test_low_sample_rates(ctx, oracle, fs, expect):
+    """f_code/fs > 31/63 chip per sample (fs < 2.08 Msps): a 64-sample row no longer fits one
+    32-chip window; auto takes the half-row-window kernel down to one chip per sample
+    (1.023 Msps) and the generic kernel below that.  Asking for a kernel the rate does not
+    allow is an error, not wrong output."""
+    d = synth_blocks(2, 11, seed=41)
+    ns = int(fs) // 10
     q, _ = gpsiq.quantize_blocks(d, fs, ns)
     ctx.set_descriptors(q)
-    assert np.array_equal(run_device(ctx, q, ns, SC16, "auto")[0], oracle.block_fixed(q[0], ns, SC16))
-    with pytest.raises(gpsiq.GpsiqError) as e:
-        run_device(ctx, q, ns, SC16, "rows")
-    assert e.value.code == -2
+    want = [oracle.block_fixed(q[b], ns, SC16) for b in range(2)]
+    got = run_device(ctx, q, ns, SC16, "auto")
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    got = run_device(ctx, q, ns, SC08, expect)
+    assert np.array_equal(got[1], oracle.block_fixed(q[1], ns, SC08))
+    for v in ("rows", "seg") + (("segh",) if expect == "generic" else ()):
+        with pytest.raises(gpsiq.GpsiqError) as e:
+            run_device(ctx, q, ns, SC16, v)
+        assert e.value.code == -2
+    # auto == the expected kernel, bit for bit and by name
+    assert np.array_equal(run_device(ctx, q, ns, SC16, expect), run_device(ctx, q, ns, SC16, "auto"))
+
+
+def test_half_row_kernel_fuzz(ctx, oracle):
+    """Random quantised descriptors with code steps up to the half-row kernel's limit
+    (one chip per sample), long enough to cross chunk boundaries."""
+    from gpsiq.abi import QCHAN_DTYPE
+    rng = np.random.default_rng(4242)
+    max_step = ((31 << 56) - 1) // 31
+    for case in range(6):
+        nb, nc = 2, int(rng.integers(1, 17))
+        ns = int(rng.choice([1, 31, 33, 2047, 2049, 16384, 16385, 70001]))
+        q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+        q["prn"] = rng.integers(0, 33, size=(nb, nc))
+        q["carr_phase"] = rng.integers(0, 1 << 59, size=(nb, nc), dtype=np.uint64)
+        q["carr_step"] = rng.integers(-(1 << 58) + 1, 1 << 58, size=(nb, nc))
+        q["code_frac"] = rng.integers(0, 1 << 56, size=(nb, nc), dtype=np.uint64)
+        q["code_step"] = rng.integers(max_step // 2, max_step + 1, size=(nb, nc), dtype=np.uint64)
+        q["code_step"][0, :] = max_step
+        q["chip0"] = rng.integers(0, 1023, size=(nb, nc))
+        q["chip0"][:, ::3] = 1022
+        q["icode"] = rng.integers(0, 20, size=(nb, nc))
+        q["nav_bits"] = rng.integers(0, 1 << 32, size=(nb, nc), dtype=np.uint64).astype(np.uint32)
+        q["gain"] = rng.choice([0.0, -0.7, 1.0, 0.3333, 2.0, 17.25], size=(nb, nc))
+        ctx.set_descriptors(q)
+        for ss in (SC08, SC16):
+            got = run_device(ctx, q, ns, ss, "segh")
+            for b in range(nb):
+                assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, ss)), (case, b, ss, ns, nc)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -287,7 +326,7 @@ def test_baseline_size_properties(ctx, oracle):
         assert np.array_equal(got, oracle.block_fixed_range(q[blk], n0, 2048, SC16))
 
 
-@pytest.mark.parametrize("variant", ["generic", "rows", "rowsx", "tile", "seg"])
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_quantised_descriptor_fuzz(ctx, oracle, variant):
     """Random QUANTISED descriptors straight into the kernels: full-range carrier steps
     (|step| up to 0.5 cycle/sample), code steps up to the row kernel's limit, arbitrary
