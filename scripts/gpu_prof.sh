@@ -13,3 +13,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2.log 2>&1
 find $OUT -type f | head -50
 du -sh $OUT
+# summarise on the box too (the .db files can be large; only the text summaries are needed)
+( cd $REPO && python scripts/prof_summary.py gpurun_out/prof ${PROF_TAG:-r01_final} > $OUT/summary.log 2>&1; tail -3 $OUT/summary.log )
+find $OUT -name "*.db" -size +8M -delete
+mkdir -p $REPO/gpurun_out/profiles_out; cp $REPO/profiles/${PROF_TAG:-r01_final}_* $REPO/profiles/pmc_traffic.json $REPO/gpurun_out/profiles_out/
