@@ -434,7 +434,10 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         for (int c = 0; c < NCH; ++c) {
             const double g = qs[c].gain;
             const int ts = (int) (sk * g), tc = (int) (ck * g);   // gps.c:2781-2782
-            lut[c][tid] = ((uint32_t) tc & 0xffffu) | ((uint32_t) ts << 16);
+            // int8 output keeps bits 4..11 of each 16-bit sum (gps.c:2845): with the entries
+            // pre-shifted by 4 (still modulo 2^16) those bits are bytes 1 and 3 of the packed sum
+            constexpr int kPre = FMT == GPSIQ_SC08 ? 4 : 0;
+            lut[c][tid] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
         }
     }
     for (int e = tid; e < NCH * kPrnExtWords; e += kRowsThreads) {
@@ -514,8 +517,13 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
             Q[c] += dQ[c];
         }
         const uint32_t n = n_chunk + (uint32_t) lane + (uint32_t) r * 64u;
-        if (!check || n < (uint32_t) nsamp)
-            store_sample<FMT>(blk_dst, n, __builtin_bit_cast(uint32_t, acc0 + acc1));
+        if (!check || n < (uint32_t) nsamp) {
+            const uint32_t iq = __builtin_bit_cast(uint32_t, acc0 + acc1);
+            if (FMT == GPSIQ_SC16)
+                *reinterpret_cast<uint32_t *>(blk_dst + n * 4u) = iq;                     // gps.c:2842
+            else                                                                         // bytes 1 and 3, see the LUT build
+                *reinterpret_cast<uint16_t *>(blk_dst + n * 2u) = (uint16_t) __builtin_amdgcn_perm(iq, iq, 0x0c0c0301u);
+        }
     };
 
     for (int row0 = 0; row0 < wave_rows; row0 += ROWS) {
