@@ -460,11 +460,11 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     const int c_raw = lane % kPad, wg = lane / kPad;
     const int wc = c_raw < NCH ? c_raw : 0;                  // surplus lanes shadow channel 0
     const bool w_store = c_raw < NCH;
-    uint32_t w_on, w_k, w_icur, w_navw, w_rot, w_dint;
+    uint32_t w_k, w_nrev, w_nrot, w_dint;
+    int32_t w_e1;
     uint64_t w_fr, w_dfr;
     {
         const gpsiq_qchan_t &q = qs[wc];
-        w_on = q.prn != 0 ? 0xffffffffu : 0u;
         const uint32_t n_row = n_wave + (uint32_t) wg * (uint32_t) kSpan;
         const unsigned __int128 T = (unsigned __int128) q.code_frac +
                                     (unsigned __int128) q.code_step * (unsigned __int128) n_row;
@@ -472,9 +472,11 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         w_fr = (uint64_t) T & kCodeFracMask;
         w_k = A % GPSIQ_CA_SEQ_LEN;                              // chip inside the period
         const uint32_t ic = q.icode + A / GPSIQ_CA_SEQ_LEN;
-        w_icur = ic % 20u;
-        w_navw = q.nav_bits >> ((ic / 20u) & 31u);               // bit 0 = current nav bit
-        w_rot = A;                                               // only A mod 32 matters
+        // chips until the current nav bit ends, minus one (0..20459)
+        w_e1 = (int32_t) ((20u - ic % 20u) * GPSIQ_CA_SEQ_LEN - w_k) - 1;
+        // nav bits of this block, current bit in bit 31, the following ones below it
+        w_nrev = __builtin_bitreverse32(q.nav_bits >> ((ic / 20u) & 31u));
+        w_nrot = 0u - A;                                         // minus the rotation: only (-A) mod 32 matters
         // chips per builder step: kSpan*kGroups samples (<= 1024 samples at <= 0.5 chip, or
         // <= 512 samples at <= 1 chip: one period wrap at most)
         const unsigned __int128 step = (unsigned __int128) q.code_step * (unsigned) (kSpan * kGroups);
@@ -533,24 +535,27 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         for (int i = 0; i < kRun; ++i) {
             const uint32_t lo = ext[wc][w_k >> 5], hi = ext[wc][(w_k >> 5) + 1];
             uint32_t S = __builtin_amdgcn_alignbit(hi, lo, w_k);   // 32 chips from chip k (shift uses k & 31)
-            const uint32_t d0 = 0u - (w_navw & 1u);
-            // window positions >= 1023-k are the next period; its nav bit differs only
-            // when this is the 20th period of the bit
-            const uint32_t to_wrap = GPSIQ_CA_SEQ_LEN - w_k;
-            uint32_t flip = 0u;
-            if (w_icur == 19u && to_wrap < 32u)
-                flip = ((w_navw ^ (w_navw >> 1)) & 1u) ? (0xffffffffu << to_wrap) : 0u;
-            S ^= d0 ^ flip;
-            if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_rotateleft32(S, w_rot & 31u) & w_on;
+            S ^= (uint32_t) ((int32_t) w_nrev >> 31);
+            // the window holds the start of the next nav bit when fewer than 32 chips of the
+            // current one are left: 0.16 % of the windows, so the whole wave skips the correction
+            // unless some lane needs it
+            const bool edge = (uint32_t) w_e1 < 31u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(edge) != 0, 0)) {
+                if (edge && ((w_nrev ^ (w_nrev << 1)) >> 31)) S ^= 0xfffffffeu << w_e1;
+            }
+            // rotate left by A mod 32 (alignbit rotates right by its low 5 bits); an unused slot
+            // needs no masking: its LUT entries are all zero
+            if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_amdgcn_alignbit(S, S, w_nrot);
             w_fr += w_dfr;
             const uint32_t adv = w_dint + (uint32_t) (w_fr >> GPSIQ_CODE_FRAC_BITS);
             w_fr &= kCodeFracMask;
-            w_rot += adv;
-            w_k += adv;
-            if (w_k >= GPSIQ_CA_SEQ_LEN) {
-                w_k -= GPSIQ_CA_SEQ_LEN;
-                if (++w_icur == 20u) { w_icur = 0u; w_navw >>= 1; }
-            }
+            w_nrot -= adv;
+            const uint32_t k2 = w_k + adv;                        // adv < 1023: one period wrap at most
+            w_k = k2 - GPSIQ_CA_SEQ_LEN < k2 ? k2 - GPSIQ_CA_SEQ_LEN : k2;
+            const int32_t e = w_e1 - (int32_t) adv;               // adv < 20460: one bit edge at most
+            const int32_t m = e >> 31;
+            w_e1 = e + (m & (int32_t) (20 * GPSIQ_CA_SEQ_LEN));
+            w_nrev <<= (uint32_t) m & 1u;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
