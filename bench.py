@@ -265,6 +265,34 @@ def main():
         ctx.set_descriptors(q)
 
     if args.sweep and rank == 0:
+        # the whole run-ahead chain of INTEGRATION.md section 3 on a BASELINE config-4 shaped scenario:
+        # RINEX file -> subframes -> nav words -> per-block refresh with the 30 s nav refreshes
+        # (host, gpsiq/pipeline.py) -> IQ in device memory (one gpsiq_generate_batch)
+        import tempfile
+        from gpsiq.pipeline import RunAhead
+        from gpsiq.scenario import circle_track, llh_to_ecef, synth_rinex_records, write_rinex_nav
+        pos = llh_to_ecef(35.681298, 139.766247, 10.0)
+        utc = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
+                   A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=2190, dtls=18)
+        with tempfile.TemporaryDirectory() as td:
+            path = write_rinex_nav(os.path.join(td, "cfg4.21n"), synth_rinex_records(12, pos, 2190, 270000.0, seed=35, sets=2), utc, 2)
+            nb4 = min(5999, (ring.numel() // (4 * nsamp)))          # 600 s when the ring holds it (int16 output)
+            xyz = circle_track(pos, nb4)
+            t1 = time.perf_counter()
+            eph4, utc4, nset = gpsiq.rinex_read(path, 2)
+            ieph = gpsiq.rinex_select(eph4, nset, 2190, 270000.0)
+            svs = [sv for sv in range(32) if eph4[ieph, sv]["vflg"]]
+            ra = RunAhead(eph4[ieph], utc4, svs, 2190, 270000.0, xyz[0])
+            d4 = ra.descriptors(xyz[1:])
+            t2 = time.perf_counter()
+            ctx.generate_batch(d4, nsamp, fs, 2, device_ptr=ring.data_ptr())
+            t3 = time.perf_counter()
+        print(f"[pipeline] RINEX -> {nb4} blocks x {len(svs)} ch, circle track, int16 @ {fs / 1e6:g} Msps: host chain "
+              f"{(t2 - t1) * 1e3:.1f} ms + gpsiq_generate_batch {(t3 - t2) * 1e3:.1f} ms = {nb4 * 0.1 / (t3 - t1):.0f}x real time "
+              f"end to end ({nb4 * 0.1:.0f} s of signal)", file=sys.stderr)
+        ctx.set_descriptors(q)
+
+    if args.sweep and rank == 0:
         # the host refresh that feeds the kernel (gpsiq_refresh_batch, reference gps.c:2731-2765):
         # blocks per second on this host, 1 thread and all threads
         from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks

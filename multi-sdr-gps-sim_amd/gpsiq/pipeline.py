@@ -1,0 +1,87 @@
+"""Run-ahead host pipeline over the C-ABI: everything the reference's gps thread computes on
+the host between channel allocation and the sample loop, for a whole scenario at once.
+
+    RINEX ephemeris set -> subframes (eph2sbf) -> nav words (generateNavMsg) -> per-block
+    range / code phase / gain (gps.c:2731-2765) -> gpsiq_chan_t[nblocks][nchan]
+
+with the reference's 30 s navigation-message refresh (gps.c:2870, 2878-2885) at the right
+blocks.  The set of satellites is fixed for the run: re-running allocateChannel()
+(gps.c:2905) and switching ephemeris sets (gps.c:2887-2903) stay host policy, as in
+INTEGRATION.md section 3.  Every call below is one C-ABI entry point; this module is only the
+loop around them.
+"""
+import numpy as np
+
+from . import (CHAN_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_subframes, refresh_batch,
+               track_init)
+
+
+def gps_time_after(sec, steps):
+    """incGpsTime(.., 0.1) applied `steps` times to a time that is a whole number of
+    milliseconds (gps.c:1105-1124 rounds to the millisecond at every step)."""
+    return round(round(sec * 1000.0) + 100.0 * steps) / 1000.0
+
+
+def epoch_plan(sec, nblocks):
+    """Split blocks 0..nblocks-1 (block k is generated at receiver time sec + 0.1*(k+1)) at
+    the blocks after which the reference refreshes the navigation message: whenever the
+    block's time is a multiple of 30 s (igrx % 300 == 0, gps.c:2870-2878).
+    Returns [(first_block, one_past_last_block, roll_after)] ."""
+    plan, b = [], 0
+    t0 = round(sec * 10.0)                       # tenths of a second
+    while b < nblocks:
+        to_edge = 300 - (int(t0) + b) % 300      # blocks up to and including the one at the next 30 s edge
+        e = min(nblocks, b + to_edge)
+        plan.append((b, e, e == b + to_edge))
+        b = e
+    return plan
+
+
+class RunAhead:
+    def __init__(self, eph_set, utc, svs, week, sec, xyz0, alm=None, iono=None):
+        """eph_set: gpsiq_rinex_eph_t[32] (one ephemeris set); svs: satellite indices (0-based)
+        to allocate, one channel each; (week, sec): receiver start time; xyz0: ECEF start position."""
+        self.week, self.sec = int(week), float(sec)
+        self.svs = list(svs)
+        n = len(self.svs)
+        self.orbit = np.ascontiguousarray(eph_set[self.svs]["orbit"])
+        if iono is None:
+            iono = np.zeros((), dtype=IONO_DTYPE)
+            iono["enable"], iono["vflg"], iono["alpha"], iono["beta"] = 1, utc["vflg"], utc["alpha"], utc["beta"]
+        self.iono = iono
+        self.sbf = np.zeros((n, 53, 10), dtype=np.uint32)
+        self.nav = np.zeros(n, dtype=NAV_STATE_DTYPE)
+        self.trk = np.zeros(n, dtype=TRACK_DTYPE)
+        for i, sv in enumerate(self.svs):
+            self.sbf[i] = nav_subframes(eph_set[sv]["nav"], utc, alm)          # eph2sbf, gps.c:2190
+            nav_message(self.sbf[i], self.week, self.sec, True, self.nav[i:i + 1])   # gps.c:2196
+            self.trk[i]["prn"] = sv + 1
+            self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+            self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
+        self.ipage0 = self.nav["ipage"].copy()
+        track_init(self.orbit, self.iono, self.week, self.sec, np.asarray(xyz0, dtype=np.float64), self.trk)   # gps.c:2199-2214
+        self.carr_phase0 = self.trk["carr_phase"].copy()
+        self.blocks_done = 0
+
+    def descriptors(self, xyz, carr_phase=None, gain_x2=False, nthreads=0):
+        """Channel state at gps.c:2766 for the next len(xyz) blocks (xyz[k] = ECEF position of
+        block k).  carr_phase: what the previous Context.generate_batch call handed out
+        (carr_out) when continuing a run; None on the first call = the allocation's value.
+        Only block 0's carr_phase is read by the library, which carries it exactly from there."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        out = []
+        for b0, b1, roll in epoch_plan(gps_time_after(self.sec, self.blocks_done), len(xyz)):
+            t = gps_time_after(self.sec, self.blocks_done)
+            d = refresh_batch(self.orbit, self.iono, self.week, t, xyz[b0:b1], self.trk, gain_x2=gain_x2, nthreads=nthreads)
+            out.append(d)
+            self.blocks_done += b1 - b0
+            if roll:                                                          # gps.c:2878-2885
+                t_roll = gps_time_after(self.sec, self.blocks_done)
+                for i in range(len(self.svs)):
+                    nav_message(self.sbf[i], self.week, t_roll, False, self.nav[i:i + 1])
+                    self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
+                    self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+        desc = np.concatenate(out) if out else np.zeros((0, len(self.svs)), dtype=CHAN_DTYPE)
+        # the loop's own state (gps.c:2821), not the host model's
+        desc["carr_phase"] = (self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64))[None, :]
+        return desc

@@ -267,9 +267,10 @@ int ref_inc_gps_time(int *week, double *sec, double dt)
  * gps.c:2692 / gps.c:2932 do.  xyz is [nblocks+1][3]: xyz[0] the allocation position,
  * xyz[k+1] the position of block k.  out is [nblocks][nchan].
  */
-int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in, int week, double sec,
-                       const double *xyz_in, int nblocks, int nchan, int sdr_type,
-                       const gpsiq_track_t *trk_in, gpsiq_chan_t *out, double *carr_init)
+static int refresh_epochs(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in, int week, double sec,
+                          const double *xyz_in, int nblocks, int nchan, int sdr_type,
+                          const gpsiq_track_t *trk_in, const uint32_t *sbf_in, const int *ipage_in,
+                          gpsiq_chan_t *out, double *carr_init)
 {
     if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return -1;
     ref_nchan = nchan;
@@ -279,7 +280,7 @@ int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in,
     static ephem_t eph[1][MAX_SAT];
     ionoutc_t ionoutc;
     double gain[GPSIQ_MAX_CHAN], ant_pat[37], path_loss, ant_gain;
-    int i, sv, ibs, ieph = 0, iumd;
+    int i, sv, ibs, ieph = 0, iumd, igrx;
     gpstime_t grx = { week, sec };
     double (*xyz)[3] = (double (*)[3]) xyz_in;
 
@@ -299,6 +300,12 @@ int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in,
         codegen(chan[i].ca, chan[i].prn);
         for (int k = 0; k < N_DWRD; k++) chan[i].dwrd[k] = trk_in[i].dwrd[k];
         chan[i].g0.week = trk_in[i].g0_week; chan[i].g0.sec = trk_in[i].g0_sec;
+        if (sbf_in) {                                               /* chan.sbf / chan.ipage as eph2sbf + generateNavMsg(init) left them */
+            for (int p = 0; p < N_SBF_PAGE; p++)
+                for (int w = 0; w < N_DWRD_SBF; w++)
+                    chan[i].sbf[p][w] = sbf_in[((size_t) i * N_SBF_PAGE + p) * N_DWRD_SBF + w];
+            chan[i].ipage = ipage_in[i];
+        }
         computeRange(&rho, eph[0][sv], &ionoutc, grx, xyz[0]);      /* gps.c:2199 */
         chan[i].rho0 = rho;
         r_xyz = rho.range;
@@ -325,10 +332,35 @@ int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in,
             o->gain = gain[i];
             for (int k = 0; k < N_DWRD; k++) o->dwrd[k] = (uint32_t) chan[i].dwrd[k];
         }
+        if (sbf_in) {                /* the 30 s navigation-message refresh, gps.c:2870 and 2878-2885 */
+#include "ref_igrx.inc"
+#include "ref_navroll.inc"
+            }                        /* closes the block opened at gps.c:2879 */
+        }
         grx = incGpsTime(grx, 0.1);                                 /* gps.c:2932 */
     }
-    (void) path_loss; (void) ant_gain; (void) ibs; (void) ieph;
+    (void) path_loss; (void) ant_gain; (void) ibs; (void) ieph; (void) igrx;
     return 0;
+}
+
+int ref_refresh_blocks(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in, int week, double sec,
+                       const double *xyz_in, int nblocks, int nchan, int sdr_type,
+                       const gpsiq_track_t *trk_in, gpsiq_chan_t *out, double *carr_init)
+{
+    return refresh_epochs(eph_in, iono_in, week, sec, xyz_in, nblocks, nchan, sdr_type, trk_in, NULL, NULL, out, carr_init);
+}
+
+/* The same loop with the reference's 30 s navigation-message refresh in it (gps.c:2870,
+ * 2878-2885: generateNavMsg(grx, &chan[i], 0) whenever grx is a multiple of 30 s).
+ * sbf is [nchan][53][10] (eph2sbf output per channel), ipage the page counter after
+ * generateNavMsg(init). */
+int ref_refresh_epochs(const gpsiq_ephem_t *eph_in, const gpsiq_iono_t *iono_in, int week, double sec,
+                       const double *xyz_in, int nblocks, int nchan, int sdr_type,
+                       const gpsiq_track_t *trk_in, const uint32_t *sbf_in, const int *ipage_in,
+                       gpsiq_chan_t *out, double *carr_init)
+{
+    if (!sbf_in || !ipage_in) return -1;
+    return refresh_epochs(eph_in, iono_in, week, sec, xyz_in, nblocks, nchan, sdr_type, trk_in, sbf_in, ipage_in, out, carr_init);
 }
 
 /* ---- navigation message --------------------------------------- */

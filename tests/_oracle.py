@@ -185,6 +185,27 @@ class Ref:
             raise RuntimeError(rc)
         return out, carr
 
+    def refresh_epochs(self, eph, iono, week, sec, xyz, trk, sbf, ipage, sdr_type=1):
+        """refresh_blocks with the reference's 30 s navigation-message refresh in the loop
+        (gps.c:2870, 2878-2885).  sbf [nchan][53][10], ipage [nchan] as left by generateNavMsg(init)."""
+        eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+        iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        trk = np.ascontiguousarray(trk, dtype=TRACK_DTYPE)
+        sbf = np.ascontiguousarray(sbf, dtype=np.uint32)
+        ipage = np.ascontiguousarray(ipage, dtype=np.int32)
+        nb, nc = len(xyz) - 1, len(trk)
+        assert sbf.shape == (nc, 53, 10) and ipage.shape == (nc,)
+        out = np.zeros((nb, nc), dtype=CHAN_DTYPE)
+        carr = np.zeros(nc)
+        self.lib.ref_refresh_epochs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = self.lib.ref_refresh_epochs(_ptr(eph), _ptr(iono), int(week), float(sec), _ptr(xyz), nb, nc, sdr_type,
+                                         _ptr(trk), _ptr(sbf), _ptr(ipage), _ptr(out), _ptr(carr))
+        if rc:
+            raise RuntimeError(rc)
+        return out, carr
+
     def nav_parity(self, source, nib=False):
         self.lib.ref_nav_parity.restype = C.c_uint
         return int(self.lib.ref_nav_parity(C.c_uint(int(source) & 0xFFFFFFFF), int(bool(nib))))

@@ -1,0 +1,113 @@
+"""The run-ahead host pipeline (gpsiq/pipeline.py: RINEX set -> subframes -> nav words -> per-block
+refresh, with the 30 s navigation-message refresh at the right blocks) against the reference's
+own loop with its own refresh lines in it (oracle/_ref: gps.c:2731-2765, 2870, 2878-2885), over
+several 30 s epochs, and on to IQ bytes on the GPU."""
+import numpy as np
+import pytest
+
+import gpsiq
+from gpsiq.abi import NAV_STATE_DTYPE, SC08, TRACK_DTYPE
+from gpsiq.pipeline import RunAhead, epoch_plan, gps_time_after
+from gpsiq.scenario import circle_track, llh_to_ecef, synth_rinex_records, write_rinex_nav
+
+TOKYO = llh_to_ecef(35.681298, 139.766247, 10.0)
+WEEK = 2190
+UTC = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
+           A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=2190, dtls=18)
+
+
+def test_epoch_plan_is_the_reference_rule():
+    """igrx % 300 == 0 after the block generated at a multiple of 30 s (gps.c:2870-2878)."""
+    for sec, nb in ((270000.0, 700), (270020.0, 700), (270029.9, 5), (270000.1, 299), (270010.0, 0)):
+        plan = epoch_plan(sec, nb)
+        if nb == 0:
+            assert plan == []
+            continue
+        assert [p[0] for p in plan] == [0] + [p[1] for p in plan[:-1]] and plan[-1][1] == nb
+        for b0, b1, roll in plan:
+            times = [int(round(gps_time_after(sec, k + 1) * 10.0 + 0.0)) for k in range(b0, b1)]
+            assert all(t % 300 != 0 for t in times[:-1])
+            assert (times[-1] % 300 == 0) == roll
+
+
+def scenario(tmp_path, sec, nblocks, moving=False):
+    recs = synth_rinex_records(12, TOKYO, WEEK, 270000.0, seed=35, sets=2)
+    path = write_rinex_nav(str(tmp_path / "run.21n"), recs, UTC, 2)
+    eph, utc, n = gpsiq.rinex_read(path, 2)
+    ieph = gpsiq.rinex_select(eph, n, WEEK, sec)
+    svs = [sv for sv in range(32) if eph[ieph, sv]["vflg"]]
+    if moving:
+        xyz = circle_track(TOKYO, nblocks, radius_m=200.0, period_s=45.0)
+    else:
+        xyz = np.repeat(TOKYO[None, :], nblocks + 1, axis=0)
+    return path, eph, utc, ieph, svs, xyz
+
+
+@pytest.mark.parametrize("sec,moving", [(270020.0, False), (270000.0, True)])
+def test_multi_epoch_descriptors_match_the_reference_loop(ref, tmp_path, sec, moving):
+    nblocks = 700
+    path, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving)
+    ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+    desc = ra.descriptors(xyz[1:])
+
+    reph, rutc, rn = ref.read_rinex(path, 2)
+    n = len(svs)
+    rtrk = np.zeros(n, dtype=TRACK_DTYPE)
+    rsbf = np.zeros((n, 53, 10), dtype=np.uint32)
+    ipage = np.zeros(n, dtype=np.int32)
+    for i, sv in enumerate(svs):
+        rsbf[i] = ref.nav_subframes(reph[ieph, sv]["nav"], rutc)
+        st = np.zeros(1, dtype=NAV_STATE_DTYPE)
+        ref.nav_message(rsbf[i], WEEK, sec, True, st)
+        rtrk[i]["prn"], rtrk[i]["g0_week"], rtrk[i]["g0_sec"], rtrk[i]["dwrd"] = sv + 1, st[0]["g0_week"], st[0]["g0_sec"], st[0]["dwrd"]
+        ipage[i] = st[0]["ipage"]
+    want, carr = ref.refresh_epochs(np.ascontiguousarray(reph[ieph, svs]["orbit"]), ra.iono, WEEK, sec, xyz, rtrk, rsbf, ipage)
+    for f in ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd"):
+        assert desc[f].tobytes() == want[f].tobytes(), f
+    assert desc["carr_phase"][0].tobytes() == carr.tobytes()
+    # the navigation words really were refreshed where the reference refreshes them
+    edges = [e for _, e, roll in epoch_plan(sec, nblocks) if roll and e < nblocks]
+    assert len(edges) >= 2
+    for e in edges:
+        assert desc["dwrd"][e].tobytes() != desc["dwrd"][e - 1].tobytes()
+        assert desc["dwrd"][e - 1].tobytes() == desc["dwrd"][max(e - 300, 0)].tobytes()
+        assert (desc["iword"][e] < desc["iword"][e - 1]).all()          # the word counter starts over
+    assert len(svs) == 12 and (desc["iword"] < 60).all()
+
+
+def test_descriptors_in_pieces_equal_one_call(tmp_path):
+    """Calling the pipeline epoch by epoch (or in odd pieces) gives the same blocks as one call."""
+    sec, nblocks = 270010.0, 450
+    _, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving=True)
+    whole = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+    parts = [ra.descriptors(xyz[1 + a:1 + b]) for a, b in ((0, 7), (7, 200), (200, 201), (201, 450))]
+    assert np.concatenate(parts).tobytes() == whole.tobytes()
+
+
+@pytest.mark.gpu
+def test_multi_epoch_scenario_to_samples_on_gpu(oracle, tmp_path):
+    """RINEX -> two navigation refreshes -> IQ bytes: the blocks either side of each refresh
+    (and the first and last) equal the oracle, batch call == epoch-by-epoch calls."""
+    sec, nblocks, fs, ns = 270020.0, 420, 2.6e6, 260000
+    _, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving=True)
+    desc = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    import torch
+    ctx = gpsiq.Context(0)
+    buf = torch.empty(nblocks * 2 * ns, dtype=torch.int8, device="cuda")
+    ctx.generate_batch(desc, ns, fs, SC08, device_ptr=buf.data_ptr())
+    q = oracle.quantize_blocks(desc, fs, ns)
+    for b in (0, 99, 100, 101, 399, 400, 419):
+        got = buf[b * 2 * ns:(b + 1) * 2 * ns].cpu().numpy()
+        assert np.array_equal(got, oracle.block_fixed(q[b], ns, SC08)), b
+    # epoch by epoch with the carrier handed over, as INTEGRATION.md section 3 describes
+    ctx2 = gpsiq.Context(0)
+    ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+    buf2 = torch.empty_like(buf)
+    carr = None
+    for b0, b1, _ in epoch_plan(sec, nblocks):
+        d = ra.descriptors(xyz[1 + b0:1 + b1], carr_phase=carr)
+        carr = np.zeros(len(svs))
+        ctx2.generate_batch(d, ns, fs, SC08, device_ptr=buf2.data_ptr() + b0 * 2 * ns, carr_out=carr)
+    assert torch.equal(buf, buf2)
+    ctx.close(); ctx2.close()
