@@ -159,8 +159,51 @@ def make_rinex_golden():
     print("rinex:", n, "sets,", int(eph["vflg"].sum()), "records")
 
 
+def make_epochs_golden():
+    """Capture of the reference's block loop WITH its 30 s navigation-message refresh
+    (gps.c:2731-2765, 2870, 2878-2885) over three epochs, started from a synthetic RINEX file:
+    SHA-256 of every block's descriptors plus the blocks either side of each refresh verbatim
+    (tests/test_pipeline.py, for boxes without the reference)."""
+    import hashlib
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_pipeline import TOKYO, UTC, WEEK
+    from gpsiq.abi import NAV_STATE_DTYPE, TRACK_DTYPE, IONO_DTYPE
+    from gpsiq.scenario import circle_track, synth_rinex_records, write_rinex_nav
+    r = _oracle.load_ref()
+    sec, nblocks = 270020.0, 700
+    with tempfile.TemporaryDirectory() as td:
+        path = write_rinex_nav(os.path.join(td, "run.21n"), synth_rinex_records(12, TOKYO, WEEK, 270000.0, seed=35, sets=2), UTC, 2)
+        eph, utc, n = r.read_rinex(path, 2)
+    from gpsiq import rinex_select
+    ieph = rinex_select(eph, n, WEEK, sec)
+    svs = [sv for sv in range(32) if eph[ieph, sv]["vflg"]]
+    xyz = circle_track(TOKYO, nblocks, radius_m=200.0, period_s=45.0)
+    nc = len(svs)
+    trk = np.zeros(nc, dtype=TRACK_DTYPE)
+    sbf = np.zeros((nc, 53, 10), dtype=np.uint32)
+    ipage = np.zeros(nc, dtype=np.int32)
+    for i, sv in enumerate(svs):
+        sbf[i] = r.nav_subframes(eph[ieph, sv]["nav"], utc)
+        st = np.zeros(1, dtype=NAV_STATE_DTYPE)
+        r.nav_message(sbf[i], WEEK, sec, True, st)
+        trk[i]["prn"], trk[i]["g0_week"], trk[i]["g0_sec"], trk[i]["dwrd"] = sv + 1, st[0]["g0_week"], st[0]["g0_sec"], st[0]["dwrd"]
+        ipage[i] = st[0]["ipage"]
+    iono = np.zeros((), dtype=IONO_DTYPE)
+    iono["enable"], iono["vflg"], iono["alpha"], iono["beta"] = 1, utc["vflg"], utc["alpha"], utc["beta"]
+    desc, carr = r.refresh_epochs(np.ascontiguousarray(eph[ieph, svs]["orbit"]), iono, WEEK, sec, xyz, trk, sbf, ipage)
+    desc["carr_phase"] = carr[None, :]
+    keep = [0, 98, 99, 100, 101, 399, 400, 699]
+    sha = np.stack([np.frombuffer(hashlib.sha256(desc[b].tobytes()).digest(), dtype=np.uint8) for b in range(nblocks)])
+    np.savez_compressed(os.path.join(HERE, "epochs_circle.npz"), sec=sec, nblocks=nblocks, svs=np.array(svs), keep=np.array(keep),
+                        desc_keep=desc[keep].view(np.uint8).reshape(len(keep), nc, -1), sha256=sha)
+    print("epochs_circle:", desc.shape, "svs", svs)
+
+
 if __name__ == "__main__":
-    if "--rinex-only" in sys.argv:
+    if "--epochs-only" in sys.argv:
+        make_epochs_golden()
+    elif "--rinex-only" in sys.argv:
         make_rinex_golden()
     elif "--refresh-only" in sys.argv:
         make_refresh_golden()
@@ -170,3 +213,4 @@ if __name__ == "__main__":
         main()
         make_nav_golden()
         make_rinex_golden()
+        make_epochs_golden()

@@ -75,6 +75,24 @@ def test_multi_epoch_descriptors_match_the_reference_loop(ref, tmp_path, sec, mo
     assert len(svs) == 12 and (desc["iword"] < 60).all()
 
 
+def test_golden_multi_epoch_capture(tmp_path):
+    """Committed capture of the reference loop incl. its nav refresh (runs without /root/reference):
+    every block's descriptors by SHA-256, the blocks either side of each refresh byte for byte."""
+    import hashlib
+    import os
+    from gpsiq.abi import CHAN_DTYPE
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "epochs_circle.npz"))
+    sec, nblocks = float(z["sec"]), int(z["nblocks"])
+    _, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving=True)
+    assert svs == list(z["svs"])
+    desc = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    want = np.ascontiguousarray(z["desc_keep"]).view(CHAN_DTYPE).reshape(len(z["keep"]), len(svs))
+    for k, b in enumerate(z["keep"]):
+        assert desc[b].tobytes() == want[k].tobytes(), b
+    for b in range(nblocks):
+        assert hashlib.sha256(desc[b].tobytes()).digest() == z["sha256"][b].tobytes(), b
+
+
 def test_descriptors_in_pieces_equal_one_call(tmp_path):
     """Calling the pipeline epoch by epoch (or in odd pieces) gives the same blocks as one call."""
     sec, nblocks = 270010.0, 450
