@@ -17,6 +17,7 @@
  *   gps.c:145-213    sinTable512 / cosTable512          -> gpsiq_carrier_table() (table built in-library)
  *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
  *   gps.c:2731-2765  per-block host refresh              -> gpsiq_refresh_batch(), gpsiq_track_init()
+ *   gps.c:2142-2162  checkSatVisibility()                -> gpsiq_sat_visibility()
  *   gps.c:617-884, 1008-1072, 2066-2140  nav words     -> gpsiq_nav_subframes/_message/_parity()
  *   gps.c:1131-1891  readRinex2 / readRinex3             -> gpsiq_rinex_read(), gpsiq_rinex_select()
  *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
@@ -235,6 +236,13 @@ typedef struct gpsiq_track {       /* per-channel host state that persists betwe
  * way allocateChannel() does (gps.c:2199-2214).  prn, g0 and dwrd must be filled by the caller. */
 int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
                      const double xyz[3], gpsiq_track_t *trk, int nchan);
+
+/* checkSatVisibility() (gps.c:2142-2162): geometric azimuth / elevation (radians, no light-time
+ * correction) of one satellite from ECEF position xyz at receiver time (week, sec), and the test
+ * elevation > elv_mask_deg.  Returns 1 visible, 0 not visible, negative on error; azel may be NULL.
+ * (allocateChannel() itself always passes a mask of 0 degrees, gps.c:2175.) */
+int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const double xyz[3],
+                         double elv_mask_deg, double azel[2]);
 
 /* Blocks k = 0..nblocks-1 at receiver times t_k = incGpsTime^(k+1)(week, sec) (the reference
  * advances grx by 0.1 s before the first block, gps.c:2692, and after every block, gps.c:2932)

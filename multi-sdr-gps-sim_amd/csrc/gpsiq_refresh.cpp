@@ -308,6 +308,24 @@ int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int wee
     return GPSIQ_OK;
 }
 
+int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const double xyz[3],
+                         double elv_mask_deg, double azel[2])
+{
+    (void) week;                                  // satpos() reads only the seconds of the week (gps.c:525-530)
+    if (!eph || !xyz) return fail(GPSIQ_E_ARG, "null argument");
+    const Site site = site_from_ecef(xyz);                                   // gps.c:2150-2151
+    const SvState s = sv_state(*eph, sec);                                   // gps.c:2153: no light-time correction here
+    const double los[3] = {s.pos[0] - xyz[0], s.pos[1] - xyz[1], s.pos[2] - xyz[2]};
+    double neu[3];
+    for (int k = 0; k < 3; ++k)
+        neu[k] = site.t[k][0] * los[0] + site.t[k][1] * los[1] + site.t[k][2] * los[2];   // gps.c:476-482
+    double az = std::atan2(neu[1], neu[0]);                                   // gps.c:488-499
+    if (az < 0.0) az += (2.0 * kPi);
+    const double el = std::atan2(neu[2], std::sqrt(neu[0] * neu[0] + neu[1] * neu[1]));
+    if (azel) { azel[0] = az; azel[1] = el; }
+    return el * kR2D > elv_mask_deg ? 1 : 0;                                 // gps.c:2158-2161
+}
+
 int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
                         const double *xyz, int nblocks, int nchan, int gain_x2,
                         gpsiq_track_t *trk, gpsiq_chan_t *out, int nthreads)

@@ -80,6 +80,7 @@ _time_launches = _sig("gpsiq_time_launches", _i, _vp, _i, _i, _i, _i, _vp, _sz, 
 _host_alloc = _sig("gpsiq_host_alloc", _vp, _sz)
 _host_free = _sig("gpsiq_host_free", None, _vp)
 _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
+_sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _nav_parity = _sig("gpsiq_nav_parity", C.c_uint32, C.c_uint32, _i)
 _nav_subframes = _sig("gpsiq_nav_subframes", _i, _vp, _vp, _vp, _vp)
@@ -158,6 +159,14 @@ def track_init(eph, iono, week, sec, xyz, trk):
     assert trk.dtype == TRACK_DTYPE and trk.flags.c_contiguous
     _check(_track_init(_p(eph), _p(iono), int(week), float(sec), _p(xyz), _p(trk), len(trk)))
     return trk
+
+
+def sat_visibility(eph, week, sec, xyz, elv_mask_deg=0.0):
+    """checkSatVisibility() (reference gps.c:2142-2162) for one ephemeris: (visible, azel[2] in radians)."""
+    eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    azel = np.zeros(2)
+    return bool(_check(_sat_visibility(_p(eph), int(week), float(sec), _p(xyz), float(elv_mask_deg), _p(azel)))), azel
 
 
 def refresh_batch(eph, iono, week, sec, xyz, trk, gain_x2=False, nthreads=0):

@@ -5,15 +5,16 @@ the host between channel allocation and the sample loop, for a whole scenario at
     range / code phase / gain (gps.c:2731-2765) -> gpsiq_chan_t[nblocks][nchan]
 
 with the reference's 30 s navigation-message refresh (gps.c:2870, 2878-2885) at the right
-blocks.  The set of satellites is fixed for the run: re-running allocateChannel()
-(gps.c:2905) and switching ephemeris sets (gps.c:2887-2903) stay host policy, as in
-INTEGRATION.md section 3.  Every call below is one C-ABI entry point; this module is only the
-loop around them.
+blocks.  RunAhead keeps a fixed set of satellites; RunAheadAllocating also restates the
+allocation policy of allocateChannel() (gps.c:2164-2235: visible satellites, lowest PRN first,
+into the first free channel, at the start and at every 30 s refresh, always seen from the start
+position as the reference does).  Switching ephemeris sets (gps.c:2887-2903) stays with the
+caller.  Every call below is one C-ABI entry point; this module is only the loop around them.
 """
 import numpy as np
 
-from . import (CHAN_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_subframes, refresh_batch,
-               track_init)
+from . import (CHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_subframes,
+               refresh_batch, sat_visibility, track_init)
 
 
 def gps_time_after(sec, steps):
@@ -85,3 +86,75 @@ class RunAhead:
         # the loop's own state (gps.c:2821), not the host model's
         desc["carr_phase"] = (self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64))[None, :]
         return desc
+
+
+class RunAheadAllocating:
+    """RunAhead with the reference's channel allocation in the loop: nchan channels, satellites
+    allocated and released at the start and at every 30 s refresh as allocateChannel() does."""
+
+    def __init__(self, eph_set, utc, nchan, week, sec, xyz0, alm=None, iono=None):
+        self.week, self.sec, self.nchan = int(week), float(sec), int(nchan)
+        self.eph_set, self.utc, self.alm = eph_set, utc, alm
+        self.xyz0 = np.ascontiguousarray(xyz0, dtype=np.float64)
+        if iono is None:
+            iono = np.zeros((), dtype=IONO_DTYPE)
+            iono["enable"], iono["vflg"], iono["alpha"], iono["beta"] = 1, utc["vflg"], utc["alpha"], utc["beta"]
+        self.iono = iono
+        self.allocated_sat = [-1] * 32                                   # gps.c:2668-2669
+        self.orbit = np.zeros(self.nchan, dtype=EPHEM_DTYPE)
+        self.sbf = np.zeros((self.nchan, 53, 10), dtype=np.uint32)
+        self.nav = np.zeros(self.nchan, dtype=NAV_STATE_DTYPE)
+        self.trk = np.zeros(self.nchan, dtype=TRACK_DTYPE)               # prn 0 = free channel (gps.c:2664-2665)
+        self.blocks_done = 0
+        self.nsat = [self.allocate(self.sec)]                            # gps.c:2675
+
+    def allocate(self, t):
+        """allocateChannel() at receiver time t (gps.c:2164-2235); returns the number of visible satellites."""
+        nsat = 0
+        for sv in range(32):
+            e = self.eph_set[sv]
+            visible = bool(e["vflg"]) and sat_visibility(e["orbit"], self.week, t, self.xyz0, 0.0)[0]
+            if visible:
+                nsat += 1
+                if self.allocated_sat[sv] == -1:
+                    for i in range(self.nchan):
+                        if self.trk[i]["prn"] == 0:
+                            self.trk[i]["prn"] = sv + 1
+                            self.orbit[i] = e["orbit"]
+                            self.sbf[i] = nav_subframes(e["nav"], self.utc, self.alm)               # gps.c:2190
+                            self.nav[i] = np.zeros((), dtype=NAV_STATE_DTYPE)
+                            nav_message(self.sbf[i], self.week, t, True, self.nav[i:i + 1])          # gps.c:2193
+                            self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+                            self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
+                            track_init(self.orbit[i:i + 1], self.iono, self.week, t, self.xyz0, self.trk[i:i + 1])   # gps.c:2196-2214
+                            self.allocated_sat[sv] = i
+                            break
+            elif self.allocated_sat[sv] >= 0:                            # gps.c:2224-2231
+                self.trk[self.allocated_sat[sv]]["prn"] = 0
+                self.allocated_sat[sv] = -1
+        return nsat
+
+    def descriptors(self, xyz, gain_x2=False, nthreads=0):
+        """As RunAhead.descriptors.  carr_phase of every block is the value allocateChannel() gave the
+        channel's current satellite: the library re-seeds a slot from it whenever the slot's PRN changes
+        and carries the phase itself otherwise."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        out = []
+        for b0, b1, roll in epoch_plan(gps_time_after(self.sec, self.blocks_done), len(xyz)):
+            t = gps_time_after(self.sec, self.blocks_done)
+            if self.trk["prn"].max() > 0:
+                d = refresh_batch(self.orbit, self.iono, self.week, t, xyz[b0:b1], self.trk, gain_x2=gain_x2, nthreads=nthreads)
+            else:
+                d = np.zeros((b1 - b0, self.nchan), dtype=CHAN_DTYPE)
+            d["carr_phase"] = np.where(self.trk["prn"] > 0, self.trk["carr_phase"], 0.0)[None, :]
+            out.append(d)
+            self.blocks_done += b1 - b0
+            if roll:
+                t_roll = gps_time_after(self.sec, self.blocks_done)
+                for i in range(self.nchan):                              # gps.c:2878-2885
+                    if self.trk[i]["prn"] > 0:
+                        nav_message(self.sbf[i], self.week, t_roll, False, self.nav[i:i + 1])
+                        self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
+                        self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+                self.nsat.append(self.allocate(t_roll))                  # gps.c:2909
+        return np.concatenate(out) if out else np.zeros((0, self.nchan), dtype=CHAN_DTYPE)

@@ -89,10 +89,11 @@ def _elevation_deg(e, sec, xyz):
     return float(np.degrees(np.arcsin(np.dot(los, up) / np.linalg.norm(los))))
 
 
-def synth_constellation(nsat, xyz, sec, seed=1, min_elev_deg=8.0):
+def synth_constellation(nsat, xyz, sec, seed=1, min_elev_deg=8.0, max_elev_deg=None):
     """nsat broadcast-ephemeris sets (EPHEM_DTYPE) of GPS-like orbits that are all above
-    min_elev_deg at receiver position xyz and time-of-week sec, with the working variables
-    the reference derives when it reads RINEX (A, n, sq1e2, omgkdot: gps.c:1456-1461)."""
+    min_elev_deg (and, if given, below max_elev_deg: satellites about to rise or set) at
+    receiver position xyz and time-of-week sec, with the working variables the reference
+    derives when it reads RINEX (A, n, sq1e2, omgkdot: gps.c:1456-1461)."""
     from .abi import EPHEM_DTYPE
     rng = SplitMix64(seed)
     out = np.zeros(nsat, dtype=EPHEM_DTYPE)
@@ -119,7 +120,8 @@ def synth_constellation(nsat, xyz, sec, seed=1, min_elev_deg=8.0):
         e["tgd"] = -(0.5 + rng.uniform()) * 1e-8
         e["toe_sec"] = toe
         e["toc_sec"] = toe
-        if _elevation_deg(e, sec, xyz) > min_elev_deg:
+        el = _elevation_deg(e, sec, xyz)
+        if el > min_elev_deg and (max_elev_deg is None or el < max_elev_deg):
             out[k] = e
             k += 1
     return out
@@ -232,10 +234,12 @@ def write_rinex_nav(path, records, utc=None, version=2, gzip_it=False, extra_com
     return path
 
 
-def synth_rinex_records(nsat, xyz, week, sec, seed=1, sets=2):
+def synth_rinex_records(nsat, xyz, week, sec, seed=1, sets=2, eph=None):
     """Broadcast records for nsat satellites visible at (week, sec), repeated for `sets`
-    consecutive two-hour issues (so the reader has to group them into hourly sets)."""
-    eph = synth_constellation(nsat, xyz, sec, seed=seed)
+    consecutive two-hour issues (so the reader has to group them into hourly sets).
+    eph: optional ready-made orbits (EPHEM_DTYPE[nsat]) instead of synth_constellation's."""
+    if eph is None:
+        eph = synth_constellation(nsat, xyz, sec, seed=seed)
     rng = SplitMix64(seed + 5)
     recs = []
     for k in range(sets):

@@ -59,6 +59,8 @@ static int ref_nchan = 12;
 #include "ref_eph2sbf.inc"           /* gps.c:617-884  eph2sbf() */
 #include "ref_parity.inc"            /* gps.c:890-1072 countBits, decode_wordN, validate_parityN, computeChecksum */
 #include "ref_navmsg.inc"            /* gps.c:2066-2140 generateNavMsg() */
+#include "ref_allocsat.inc"          /* gps.c:236       allocatedSat[] */
+#include "ref_allocate.inc"          /* gps.c:2142-2235 checkSatVisibility(), allocateChannel() */
 
 /* ---- capturing fifo (the tap SURVEY.md section 0 fact 6 asks for) --------- */
 static struct {
@@ -430,6 +432,88 @@ int ref_nav_message(const uint32_t *sbf_in /* [53][10] */, int week, double sec,
     }
     st->ipage = ch.ipage; st->g0_week = ch.g0.week; st->g0_sec = ch.g0.sec;
     return 0;
+}
+
+/* ---- the whole host side of the block loop, allocation included ----------------------- */
+static void load_full_eph(ephem_t *e, const gpsiq_rinex_eph_t *in)
+{
+    load_eph(e, &in->orbit);                    /* orbit + working variables */
+    e->vflg = in->vflg; e->sva = in->sva; e->svh = in->svh; e->code = in->code; e->flag = in->flag; e->fit = in->fit;
+    e->t.y = in->t_y; e->t.m = in->t_m; e->t.d = in->t_d; e->t.hh = in->t_hh; e->t.mm = in->t_mm; e->t.sec = in->t_sec;
+    e->toc.week = in->toc_week; e->toc.sec = in->nav.toc_sec;
+    e->toe.week = in->nav.toe_week; e->toe.sec = in->nav.toe_sec;
+    e->iodc = in->nav.iodc; e->iode = in->nav.iode; e->deltan = in->nav.deltan; e->omgdot = in->nav.omgdot;
+}
+
+/* Channel allocation at the start (gps.c:2663-2675), then per block the refresh lines
+ * (gps.c:2731-2765) and, at every multiple of 30 s, the navigation-message refresh and the
+ * re-allocation (gps.c:2870, 2878-2885, 2909; one ephemeris set, so gps.c:2887-2903 never
+ * fires).  eph_set is one set of 32 satellites; xyz is [nblocks+1][3] with xyz[0] the position
+ * allocateChannel() always uses (gps.c:2675, 2909).  out is [nblocks][nchan]; nsat (may be
+ * NULL) receives allocateChannel()'s return value of every call, at most max_nsat entries. */
+int ref_run_host(const gpsiq_rinex_eph_t *eph_set, const gpsiq_nav_utc_t *utc, int week, double sec,
+                 const double *xyz_in, int nblocks, int nchan, int sdr_type, gpsiq_chan_t *out,
+                 int *nsat, int max_nsat)
+{
+    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return -1;
+    ref_nchan = nchan;
+    static simulator_t sim;
+    simulator_t *simulator = &sim;
+    static channel_t chan[GPSIQ_MAX_CHAN];
+    static ephem_t eph[1][MAX_SAT];
+    static almanac_gps_t alm_store;
+    almanac_gps_t *alm = &alm_store;
+    ionoutc_t ionoutc;
+    double gain[GPSIQ_MAX_CHAN], ant_pat[37], path_loss, ant_gain, elvmask = 0.0;
+    int i, sv, ibs, ieph = 0, iumd, igrx, ncalls = 0;
+    gpstime_t grx = { week, sec };
+    double (*xyz)[3] = (double (*)[3]) xyz_in;
+
+    memset(&sim, 0, sizeof sim);
+    sim.sdr_type = (sdr_type_t) sdr_type;
+    memset(chan, 0, sizeof chan);
+    memset(&alm_store, 0, sizeof alm_store);
+    memset(&ionoutc, 0, sizeof ionoutc);
+    ionoutc.enable = 1; ionoutc.vflg = utc->vflg;
+    ionoutc.alpha0 = utc->alpha[0]; ionoutc.alpha1 = utc->alpha[1]; ionoutc.alpha2 = utc->alpha[2]; ionoutc.alpha3 = utc->alpha[3];
+    ionoutc.beta0 = utc->beta[0]; ionoutc.beta1 = utc->beta[1]; ionoutc.beta2 = utc->beta[2]; ionoutc.beta3 = utc->beta[3];
+    ionoutc.A0 = utc->A0; ionoutc.A1 = utc->A1; ionoutc.dtls = utc->dtls; ionoutc.tot = utc->tot; ionoutc.wnt = utc->wnt;
+    memset(eph, 0, sizeof eph);
+    for (sv = 0; sv < MAX_SAT; sv++)
+        if (eph_set[sv].vflg) load_full_eph(&eph[0][sv], &eph_set[sv]);
+
+    for (i = 0; i < MAX_CHAN; i++) chan[i].prn = 0;                 /* gps.c:2664-2665 */
+    for (sv = 0; sv < MAX_SAT; sv++) allocatedSat[sv] = -1;         /* gps.c:2668-2669 */
+    i = allocateChannel(chan, alm, eph[ieph], ionoutc, grx, xyz[0], elvmask);   /* gps.c:2675 */
+    if (nsat && ncalls < max_nsat) nsat[ncalls] = i;
+    ncalls++;
+
+#include "ref_antinit.inc"           /* gps.c:2688-2689 ant_pat[] */
+
+    grx = incGpsTime(grx, 0.1);                                     /* gps.c:2692 */
+    for (iumd = 1; iumd <= nblocks; iumd++) {
+#include "ref_refresh.inc"           /* gps.c:2731-2765 */
+        for (i = 0; i < nchan; i++) {
+            gpsiq_chan_t *o = &out[(size_t) (iumd - 1) * nchan + i];
+            memset(o, 0, sizeof *o);
+            o->prn = chan[i].prn;
+            if (chan[i].prn <= 0) continue;
+            o->iword = chan[i].iword; o->ibit = chan[i].ibit; o->icode = chan[i].icode;
+            o->f_carr = chan[i].f_carr; o->f_code = chan[i].f_code;
+            o->carr_phase = chan[i].carr_phase; o->code_phase = chan[i].code_phase;
+            o->gain = gain[i];
+            for (int k = 0; k < N_DWRD; k++) o->dwrd[k] = (uint32_t) chan[i].dwrd[k];
+        }
+#include "ref_igrx.inc"              /* gps.c:2870 */
+#include "ref_navroll.inc"           /* gps.c:2878-2885 */
+            i = allocateChannel(chan, alm, eph[ieph], ionoutc, grx, xyz[0], elvmask);   /* gps.c:2909 */
+            if (nsat && ncalls < max_nsat) nsat[ncalls] = i;
+            ncalls++;
+        }                            /* closes the block opened at gps.c:2879 */
+        grx = incGpsTime(grx, 0.1);                                 /* gps.c:2932 */
+    }
+    (void) path_loss; (void) ant_gain; (void) ibs;
+    return ncalls;
 }
 
 /* ---- RINEX readers --------------------------------------------- */

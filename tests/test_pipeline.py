@@ -129,3 +129,80 @@ def test_multi_epoch_scenario_to_samples_on_gpu(oracle, tmp_path):
         ctx2.generate_batch(d, ns, fs, SC08, device_ptr=buf2.data_ptr() + b0 * 2 * ns, carr_out=carr)
     assert torch.equal(buf, buf2)
     ctx.close(); ctx2.close()
+
+
+def horizon_scenario(tmp_path, nblocks, seed=5):
+    """9 satellites well above the horizon and 9 within +-0.35 degrees of it at the start time, so
+    that allocateChannel() has satellites rising and setting at the 30 s refreshes."""
+    from gpsiq.scenario import _elevation_deg, synth_constellation
+    sec = 270000.0
+    high = synth_constellation(9, TOKYO, sec, seed=seed, min_elev_deg=15.0)
+    near = synth_constellation(60, TOKYO, sec, seed=seed + 100, min_elev_deg=-0.45, max_elev_deg=0.45)
+    el0 = np.array([_elevation_deg(e, sec, TOKYO) for e in near])
+    el1 = np.array([_elevation_deg(e, sec + 60.0, TOKYO) for e in near])
+    setting = near[(el0 > 0.05) & (el1 < el0 - 0.15)][:4]        # up now, below the horizon within a minute or two
+    rising = near[(el0 < -0.05) & (el1 > el0 + 0.15)][:5]        # the other way round
+    assert len(setting) == 4 and len(rising) == 5
+    orbits = np.concatenate([high, setting, rising])[np.random.default_rng(seed).permutation(18)]
+    recs = synth_rinex_records(len(orbits), TOKYO, WEEK, sec, seed=seed, sets=1, eph=orbits)
+    path = write_rinex_nav(str(tmp_path / "horizon.21n"), recs, UTC, 2)
+    eph, utc, n = gpsiq.rinex_read(path, 2)
+    xyz = circle_track(TOKYO, nblocks, radius_m=150.0, period_s=50.0)
+    return path, eph, utc, xyz, sec
+
+
+def test_visibility_matches_reference(ref, tmp_path):
+    """gpsiq_sat_visibility == checkSatVisibility (gps.c:2142-2162), through the allocation it drives:
+    the number of visible satellites allocateChannel() reports at every call."""
+    from gpsiq.pipeline import RunAheadAllocating
+    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, 1300)
+    ra = RunAheadAllocating(eph[0], utc, 12, WEEK, sec, xyz[0])
+    ra.descriptors(xyz[1:])
+    _, nsat = ref.run_host(eph[0], utc, WEEK, sec, xyz, 12)
+    assert list(nsat) == ra.nsat and len(nsat) == 5
+    vis, azel = gpsiq.sat_visibility(eph[0, 0]["orbit"], WEEK, sec, TOKYO)
+    assert 0.0 <= azel[0] < 2 * np.pi and -np.pi / 2 <= azel[1] <= np.pi / 2 and vis == (azel[1] > 0.0)
+
+
+@pytest.mark.parametrize("nchan,seed", [(12, 5), (16, 6), (8, 7)])
+def test_allocating_pipeline_matches_the_reference_loop(ref, tmp_path, nchan, seed):
+    """Channel allocation, release and re-allocation at the 30 s refreshes: every descriptor field of
+    every block equals the reference's own allocateChannel + refresh + nav-refresh lines."""
+    from gpsiq.pipeline import RunAheadAllocating
+    nblocks = 1300
+    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=seed)
+    ra = RunAheadAllocating(eph[0], utc, nchan, WEEK, sec, xyz[0])
+    desc = ra.descriptors(xyz[1:])
+    want, nsat = ref.run_host(eph[0], utc, WEEK, sec, xyz, nchan)
+    assert list(nsat) == ra.nsat
+    for f in ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd", "carr_phase"):
+        assert desc[f].tobytes() == want[f].tobytes(), f
+    prn = desc["prn"]
+    changes = int((prn[1:] != prn[:-1]).sum())
+    assert changes >= 1, "the scenario should exercise release / allocation"
+    if nchan == 16:          # room for everything: satellites are released and others allocated
+        assert ((prn[1:] == 0) & (prn[:-1] > 0)).any() and ((prn[1:] > 0) & (prn[:-1] == 0)).any()
+    # changes only happen right after a 30 s refresh
+    for b in np.nonzero((prn[1:] != prn[:-1]).any(axis=1))[0]:
+        assert (b + 1) % 300 == 0
+
+
+@pytest.mark.gpu
+def test_allocating_scenario_to_samples_on_gpu(oracle, tmp_path):
+    """Satellites released and allocated at a 30 s refresh: a slot that changes PRN is re-seeded
+    from the new satellite's carrier phase, every other slot is carried exactly; IQ == oracle."""
+    from gpsiq.abi import SC16
+    from gpsiq.pipeline import RunAheadAllocating
+    nblocks, fs, ns = 330, 2.6e6, 260000
+    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6)
+    desc = RunAheadAllocating(eph[0], utc, 16, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    assert (desc["prn"][300] != desc["prn"][299]).any()
+    import torch
+    ctx = gpsiq.Context(0)
+    buf = torch.empty(nblocks * 2 * ns, dtype=torch.int16, device="cuda")
+    ctx.generate_batch(desc, ns, fs, SC16, device_ptr=buf.data_ptr())
+    q = oracle.quantize_blocks(desc, fs, ns)
+    for b in (0, 298, 299, 300, 301, 329):
+        got = buf[b * 2 * ns:(b + 1) * 2 * ns].cpu().numpy()
+        assert np.array_equal(got, oracle.block_fixed(q[b], ns, SC16)), b
+    ctx.close()
