@@ -200,8 +200,30 @@ def make_epochs_golden():
     print("epochs_circle:", desc.shape, "svs", svs)
 
 
+def make_alloc_golden():
+    """Capture of the reference's host loop WITH channel allocation (allocateChannel at the start
+    and at every 30 s refresh, gps.c:2164-2235, 2663-2675, 2909) on a scenario with satellites
+    rising and setting: SHA-256 of every block's descriptors, the PRN map, nsat per call."""
+    import hashlib
+    import pathlib
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_pipeline import WEEK, horizon_scenario
+    r = _oracle.load_ref()
+    nblocks, nchan = 1300, 16
+    with tempfile.TemporaryDirectory() as td:
+        _, eph, utc, xyz, sec = horizon_scenario(pathlib.Path(td), nblocks, seed=6)
+    desc, nsat = r.run_host(eph[0], utc, WEEK, sec, xyz, nchan)
+    sha = np.stack([np.frombuffer(hashlib.sha256(desc[b].tobytes()).digest(), dtype=np.uint8) for b in range(nblocks)])
+    np.savez_compressed(os.path.join(HERE, "alloc_horizon.npz"), nblocks=nblocks, nchan=nchan, seed=6, nsat=nsat,
+                        prn=desc["prn"].astype(np.int8), sha256=sha)
+    print("alloc_horizon:", desc.shape, "nsat", list(nsat), "prn changes", int((desc["prn"][1:] != desc["prn"][:-1]).sum()))
+
+
 if __name__ == "__main__":
-    if "--epochs-only" in sys.argv:
+    if "--alloc-only" in sys.argv:
+        make_alloc_golden()
+    elif "--epochs-only" in sys.argv:
         make_epochs_golden()
     elif "--rinex-only" in sys.argv:
         make_rinex_golden()
@@ -214,3 +236,4 @@ if __name__ == "__main__":
         make_nav_golden()
         make_rinex_golden()
         make_epochs_golden()
+        make_alloc_golden()

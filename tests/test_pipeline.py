@@ -206,3 +206,19 @@ def test_allocating_scenario_to_samples_on_gpu(oracle, tmp_path):
         got = buf[b * 2 * ns:(b + 1) * 2 * ns].cpu().numpy()
         assert np.array_equal(got, oracle.block_fixed(q[b], ns, SC16)), b
     ctx.close()
+
+
+def test_golden_allocation_capture(tmp_path):
+    """Committed capture of the reference's allocating host loop (runs without /root/reference)."""
+    import hashlib
+    import os
+    from gpsiq.pipeline import RunAheadAllocating
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alloc_horizon.npz"))
+    nblocks, nchan = int(z["nblocks"]), int(z["nchan"])
+    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=int(z["seed"]))
+    ra = RunAheadAllocating(eph[0], utc, nchan, WEEK, sec, xyz[0])
+    desc = ra.descriptors(xyz[1:])
+    assert ra.nsat == list(z["nsat"])
+    assert np.array_equal(desc["prn"], z["prn"])
+    for b in range(nblocks):
+        assert hashlib.sha256(desc[b].tobytes()).digest() == z["sha256"][b].tobytes(), b
