@@ -125,7 +125,13 @@ def test_c_hosts_fail_loudly_without_a_gpu(host_built, tmp_path):
     d = synth_blocks(2, 4, seed=1)
     dpath = str(tmp_path / "desc.bin")
     write_descriptors(dpath, d, 2.6e6, 260000, SC08)
-    for argv in (["gpsiq_play", dpath, str(tmp_path / "o.bin")], ["gpsiq_shard", dpath, str(tmp_path / "p.bin"), "0", "1"]):
+    from gpsiq.scenario import llh_to_ecef, synth_rinex_records, write_rinex_nav
+    pos = llh_to_ecef(35.681298, 139.766247, 10.0)
+    utc = dict(alpha=[0.0] * 4, beta=[0.0] * 4, A0=0.0, A1=0.0, tot=233472, wnt=2190, dtls=18)
+    rinex = write_rinex_nav(str(tmp_path / "r.21n"), synth_rinex_records(6, pos, 2190, 270000.0, seed=3, sets=2), utc, 2)
+    np.repeat(pos[None, :], 3, axis=0).tofile(str(tmp_path / "xyz.bin"))
+    for argv in (["gpsiq_play", dpath, str(tmp_path / "o.bin")], ["gpsiq_shard", dpath, str(tmp_path / "p.bin"), "0", "1"],
+                 ["gpsiq_runahead", rinex, "2", "2190", "270000", str(tmp_path / "xyz.bin"), "2", "8", "2600000", "1", str(tmp_path / "q.bin")]):
         p = subprocess.run([os.path.join(host_built, argv[0])] + argv[1:], capture_output=True, text=True, timeout=120)
         assert p.returncode != 0
         assert "gpsiq" in p.stderr and "device" in p.stderr.lower(), p.stderr

@@ -144,11 +144,13 @@ def horizon_scenario(tmp_path, nblocks, seed=5):
     rising = near[(el0 < -0.05) & (el1 > el0 + 0.15)][:5]        # the other way round
     assert len(setting) == 4 and len(rising) == 5
     orbits = np.concatenate([high, setting, rising])[np.random.default_rng(seed).permutation(18)]
-    recs = synth_rinex_records(len(orbits), TOKYO, WEEK, sec, seed=seed, sets=1, eph=orbits)
+    recs = synth_rinex_records(len(orbits), TOKYO, WEEK, sec, seed=seed, sets=2, eph=orbits)
     path = write_rinex_nav(str(tmp_path / "horizon.21n"), recs, UTC, 2)
     eph, utc, n = gpsiq.rinex_read(path, 2)
+    ieph = gpsiq.rinex_select(eph, n, WEEK, sec)                 # the set gps_thread_ep would start with (gps.c:2588-2608)
+    assert ieph >= 0
     xyz = circle_track(TOKYO, nblocks, radius_m=150.0, period_s=50.0)
-    return path, eph, utc, xyz, sec
+    return path, eph[ieph:ieph + 1], utc, xyz, sec
 
 
 def test_visibility_matches_reference(ref, tmp_path):
@@ -222,3 +224,32 @@ def test_golden_allocation_capture(tmp_path):
     assert np.array_equal(desc["prn"], z["prn"])
     for b in range(nblocks):
         assert hashlib.sha256(desc[b].tobytes()).digest() == z["sha256"][b].tobytes(), b
+
+
+@pytest.mark.gpu
+def test_c_runahead_program_equals_the_python_pipeline(oracle, tmp_path):
+    """host/gpsiq_runahead.c (RINEX -> allocation -> refresh -> IQ -> file, every step a C-ABI call,
+    30 s epochs with nav refresh and re-allocation) writes the bytes the Python pipeline + one
+    gpsiq_generate_batch produce, and those equal the oracle."""
+    import os
+    import subprocess
+    from gpsiq.pipeline import RunAheadAllocating
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-sdr-gps-sim_amd", "host")
+    subprocess.run(["make", "-s", "-C", host], check=True)
+    nblocks, nchan, fs, ns = 330, 16, 2.6e6, 260000
+    path, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6)
+    xyz.tofile(str(tmp_path / "xyz.bin"))
+    out = str(tmp_path / "iq.bin")
+    r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "xyz.bin"),
+                        str(nblocks), str(nchan), repr(fs), "1", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, dtype=np.int8).reshape(nblocks, 2 * ns)
+    desc = RunAheadAllocating(eph[0], utc, nchan, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    assert (desc["prn"][300] != desc["prn"][299]).any()
+    ctx = gpsiq.Context(0)
+    want = ctx.generate_batch(desc, ns, fs, SC08)
+    ctx.close()
+    assert np.array_equal(got, want)
+    q = oracle.quantize_blocks(desc, fs, ns)
+    for b in (0, 99, 100, 299, 300, 329):
+        assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, SC08)), b
