@@ -8,8 +8,8 @@ with the reference's 30 s navigation-message refresh (gps.c:2870, 2878-2885) at 
 blocks.  RunAhead keeps a fixed set of satellites; RunAheadAllocating also restates the
 allocation policy of allocateChannel() (gps.c:2164-2235: visible satellites, lowest PRN first,
 into the first free channel, at the start and at every 30 s refresh, always seen from the start
-position as the reference does).  Switching ephemeris sets (gps.c:2887-2903) stays with the
-caller.  Every call below is one C-ABI entry point; this module is only the loop around them.
+position as the reference does) and the switch to the next ephemeris set (gps.c:2889-2906).
+Every call below is one C-ABI entry point; this module is only the loop around them.
 """
 import numpy as np
 
@@ -92,9 +92,13 @@ class RunAheadAllocating:
     """RunAhead with the reference's channel allocation in the loop: nchan channels, satellites
     allocated and released at the start and at every 30 s refresh as allocateChannel() does."""
 
-    def __init__(self, eph_set, utc, nchan, week, sec, xyz0, alm=None, iono=None):
+    def __init__(self, eph_sets, utc, nchan, week, sec, xyz0, ieph=0, alm=None, iono=None):
+        """eph_sets: gpsiq_rinex_eph_t[nsets][32] (or one set [32]); ieph: the set to start with
+        (gpsiq.rinex_select)."""
         self.week, self.sec, self.nchan = int(week), float(sec), int(nchan)
-        self.eph_set, self.utc, self.alm = eph_set, utc, alm
+        self.eph_sets = eph_sets if eph_sets.ndim == 2 else eph_sets[None, :]
+        self.ieph = int(ieph)
+        self.eph_set, self.utc, self.alm = self.eph_sets[self.ieph], utc, alm
         self.xyz0 = np.ascontiguousarray(xyz0, dtype=np.float64)
         if iono is None:
             iono = np.zeros((), dtype=IONO_DTYPE)
@@ -134,6 +138,26 @@ class RunAheadAllocating:
                 self.allocated_sat[sv] = -1
         return nsat
 
+    def refresh_ephemeris(self, t):
+        """gps.c:2889-2906: when the first valid satellite of the next set has its time of clock less
+        than an hour ahead, that set takes over (for the orbits immediately, for the navigation words
+        from the next refresh on: the subframes are rebuilt here, the word buffer is not)."""
+        if self.ieph + 1 >= len(self.eph_sets):
+            return
+        nxt = self.eph_sets[self.ieph + 1]
+        for sv in range(32):
+            if nxt[sv]["vflg"]:
+                dt = (int(nxt[sv]["toc_week"]) - self.week) * 604800.0 + (float(nxt[sv]["nav"]["toc_sec"]) - t)   # subGpsTime, gps.c:1096-1103
+                if dt < 3600.0:
+                    self.ieph += 1
+                    self.eph_set = self.eph_sets[self.ieph]
+                    for i in range(self.nchan):
+                        if self.trk[i]["prn"] != 0:
+                            e = self.eph_set[self.trk[i]["prn"] - 1]
+                            self.sbf[i] = nav_subframes(e["nav"], self.utc, self.alm)
+                            self.orbit[i] = e["orbit"]
+                break
+
     def descriptors(self, xyz, gain_x2=False, nthreads=0):
         """As RunAhead.descriptors.  carr_phase of every block is the value allocateChannel() gave the
         channel's current satellite: the library re-seeds a slot from it whenever the slot's PRN changes
@@ -156,5 +180,6 @@ class RunAheadAllocating:
                         nav_message(self.sbf[i], self.week, t_roll, False, self.nav[i:i + 1])
                         self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
                         self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+                self.refresh_ephemeris(t_roll)                           # gps.c:2889-2906
                 self.nsat.append(self.allocate(t_roll))                  # gps.c:2909
         return np.concatenate(out) if out else np.zeros((0, self.nchan), dtype=CHAN_DTYPE)

@@ -10,7 +10,8 @@
  *                 gpsiq_nav_subframes, gpsiq_nav_message(init), gpsiq_track_init
  *   gpsiq_refresh_batch                          computeRange/computeCodePhase/gain, gps.c:2731-2765
  *   gpsiq_generate_batch                         the sample loop + pack, gps.c:2767-2846
- *   gpsiq_nav_message(roll) + allocate()         the 30 s refresh, gps.c:2870-2909
+ *   gpsiq_nav_message(roll), next ephemeris set,
+ *   allocate()                                   the 30 s refresh, gps.c:2870-2909
  *
  *   gpsiq_runahead <rinex> <2|3> <week> <sec> <xyz.bin> <nblocks> <nchan> <fs> <1|2> <out.bin>
  *
@@ -39,7 +40,9 @@ static double time_after(double sec, long steps) { return round(round(sec * 1000
 struct host_state {
     int nchan, week;
     double xyz0[3];
-    const gpsiq_rinex_eph_t *eph;         /* one set of 32 */
+    const gpsiq_rinex_eph_t *eph;         /* the set in use: 32 satellites */
+    const gpsiq_rinex_eph_t *sets;        /* all sets [nsets][32] */
+    int nsets, ieph;
     gpsiq_nav_utc_t utc;
     gpsiq_iono_t iono;
     int allocated_sat[GPSIQ_MAX_SAT];
@@ -82,6 +85,31 @@ static int allocate(struct host_state *h, double t)
     return nsat;
 }
 
+/* gps.c:2889-2906: when the first valid satellite of the next set has its time of clock less than an
+ * hour ahead, that set takes over: orbits at once, subframes rebuilt (the word buffer picks them up at
+ * the next refresh). */
+static int refresh_ephemeris(struct host_state *h, double t)
+{
+    if (h->ieph + 1 >= h->nsets) return 0;
+    const gpsiq_rinex_eph_t *nxt = h->sets + (size_t) (h->ieph + 1) * GPSIQ_MAX_SAT;
+    for (int sv = 0; sv < GPSIQ_MAX_SAT; ++sv) {
+        if (!nxt[sv].vflg) continue;
+        const double dt = (double) (nxt[sv].toc_week - h->week) * 604800.0 + (nxt[sv].nav.toc_sec - t);   /* subGpsTime, gps.c:1096-1103 */
+        if (dt < 3600.0) {
+            h->ieph++;
+            h->eph = nxt;
+            for (int i = 0; i < h->nchan; ++i) {
+                if (h->trk[i].prn == 0) continue;
+                const gpsiq_rinex_eph_t *e = &h->eph[h->trk[i].prn - 1];
+                if (gpsiq_nav_subframes(&e->nav, &h->utc, NULL, h->sbf[i]) != GPSIQ_OK) return -1;
+                h->orbit[i] = e->orbit;
+            }
+        }
+        break;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc != 11) {
@@ -105,7 +133,7 @@ int main(int argc, char **argv)
     if (!xyz || !fx || fread(xyz, sizeof(double) * 3, (size_t) nblocks + 1, fx) != (size_t) nblocks + 1) { fprintf(stderr, "bad xyz file\n"); return 2; }
     fclose(fx);
 
-    h.nchan = nchan; h.week = week; h.eph = eph[ieph];
+    h.nchan = nchan; h.week = week; h.eph = eph[ieph]; h.sets = &eph[0][0]; h.nsets = nsets; h.ieph = ieph;
     memcpy(h.xyz0, xyz, sizeof h.xyz0);
     h.iono.enable = 1; h.iono.vflg = h.utc.vflg;
     memcpy(h.iono.alpha, h.utc.alpha, sizeof h.iono.alpha); memcpy(h.iono.beta, h.utc.beta, sizeof h.iono.beta);
@@ -155,6 +183,7 @@ int main(int argc, char **argv)
                 memcpy(h.trk[i].dwrd, h.nav[i].dwrd, sizeof h.trk[i].dwrd);
                 h.trk[i].g0_week = h.nav[i].g0_week; h.trk[i].g0_sec = h.nav[i].g0_sec;
             }
+            if (refresh_ephemeris(&h, tr) != 0) return die("ephemeris refresh");
             nsat = allocate(&h, tr);
             if (nsat < 0) return die("allocate");
             ++nalloc;
@@ -163,7 +192,7 @@ int main(int argc, char **argv)
         }
     }
     fclose(fo);
-    printf("%d blocks, %d channels, %d allocation passes, last nsat %d\n", nblocks, nchan, nalloc, nsat);
+    printf("%d blocks, %d channels, %d allocation passes, last nsat %d, ephemeris set %d of %d\n", nblocks, nchan, nalloc, nsat, h.ieph, nsets);
     gpsiq_host_free(buf);
     gpsiq_destroy(gq);
     free(desc); free(xyz);

@@ -447,25 +447,25 @@ static void load_full_eph(ephem_t *e, const gpsiq_rinex_eph_t *in)
 
 /* Channel allocation at the start (gps.c:2663-2675), then per block the refresh lines
  * (gps.c:2731-2765) and, at every multiple of 30 s, the navigation-message refresh and the
- * re-allocation (gps.c:2870, 2878-2885, 2909; one ephemeris set, so gps.c:2887-2903 never
- * fires).  eph_set is one set of 32 satellites; xyz is [nblocks+1][3] with xyz[0] the position
+ * ephemeris-set switch and the re-allocation (gps.c:2870, 2878-2885, 2889-2906, 2909).
+ * eph_sets is [nsets][32], ieph0 the set to start with; xyz is [nblocks+1][3] with xyz[0] the position
  * allocateChannel() always uses (gps.c:2675, 2909).  out is [nblocks][nchan]; nsat (may be
  * NULL) receives allocateChannel()'s return value of every call, at most max_nsat entries. */
-int ref_run_host(const gpsiq_rinex_eph_t *eph_set, const gpsiq_nav_utc_t *utc, int week, double sec,
+int ref_run_host(const gpsiq_rinex_eph_t *eph_sets, int nsets, int ieph0, const gpsiq_nav_utc_t *utc, int week, double sec,
                  const double *xyz_in, int nblocks, int nchan, int sdr_type, gpsiq_chan_t *out,
-                 int *nsat, int max_nsat)
+                 int *nsat, int max_nsat, int *ieph_end)
 {
-    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return -1;
+    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN || nsets < 1 || nsets > EPHEM_ARRAY_SIZE || ieph0 < 0 || ieph0 >= nsets) return -1;
     ref_nchan = nchan;
     static simulator_t sim;
     simulator_t *simulator = &sim;
     static channel_t chan[GPSIQ_MAX_CHAN];
-    static ephem_t eph[1][MAX_SAT];
+    static ephem_t eph[EPHEM_ARRAY_SIZE + 1][MAX_SAT];     /* one spare all-invalid set: gps.c:2890 looks at eph[ieph + 1] */
     static almanac_gps_t alm_store;
     almanac_gps_t *alm = &alm_store;
     ionoutc_t ionoutc;
-    double gain[GPSIQ_MAX_CHAN], ant_pat[37], path_loss, ant_gain, elvmask = 0.0;
-    int i, sv, ibs, ieph = 0, iumd, igrx, ncalls = 0;
+    double gain[GPSIQ_MAX_CHAN], ant_pat[37], path_loss, ant_gain, elvmask = 0.0, dt;
+    int i, sv, ibs, ieph = ieph0, iumd, igrx, ncalls = 0;
     gpstime_t grx = { week, sec };
     double (*xyz)[3] = (double (*)[3]) xyz_in;
 
@@ -479,8 +479,9 @@ int ref_run_host(const gpsiq_rinex_eph_t *eph_set, const gpsiq_nav_utc_t *utc, i
     ionoutc.beta0 = utc->beta[0]; ionoutc.beta1 = utc->beta[1]; ionoutc.beta2 = utc->beta[2]; ionoutc.beta3 = utc->beta[3];
     ionoutc.A0 = utc->A0; ionoutc.A1 = utc->A1; ionoutc.dtls = utc->dtls; ionoutc.tot = utc->tot; ionoutc.wnt = utc->wnt;
     memset(eph, 0, sizeof eph);
-    for (sv = 0; sv < MAX_SAT; sv++)
-        if (eph_set[sv].vflg) load_full_eph(&eph[0][sv], &eph_set[sv]);
+    for (int k = 0; k < nsets; k++)
+        for (sv = 0; sv < MAX_SAT; sv++)
+            if (eph_sets[k * MAX_SAT + sv].vflg) load_full_eph(&eph[k][sv], &eph_sets[k * MAX_SAT + sv]);
 
     for (i = 0; i < MAX_CHAN; i++) chan[i].prn = 0;                 /* gps.c:2664-2665 */
     for (sv = 0; sv < MAX_SAT; sv++) allocatedSat[sv] = -1;         /* gps.c:2668-2669 */
@@ -506,6 +507,7 @@ int ref_run_host(const gpsiq_rinex_eph_t *eph_set, const gpsiq_nav_utc_t *utc, i
         }
 #include "ref_igrx.inc"              /* gps.c:2870 */
 #include "ref_navroll.inc"           /* gps.c:2878-2885 */
+#include "ref_ephrefresh.inc"        /* gps.c:2889-2906 switch to the next ephemeris set, new subframes */
             i = allocateChannel(chan, alm, eph[ieph], ionoutc, grx, xyz[0], elvmask);   /* gps.c:2909 */
             if (nsat && ncalls < max_nsat) nsat[ncalls] = i;
             ncalls++;
@@ -513,6 +515,7 @@ int ref_run_host(const gpsiq_rinex_eph_t *eph_set, const gpsiq_nav_utc_t *utc, i
         grx = incGpsTime(grx, 0.1);                                 /* gps.c:2932 */
     }
     (void) path_loss; (void) ant_gain; (void) ibs;
+    if (ieph_end) *ieph_end = ieph;
     return ncalls;
 }
 

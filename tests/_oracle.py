@@ -206,25 +206,27 @@ class Ref:
             raise RuntimeError(rc)
         return out, carr
 
-    def run_host(self, eph_set, utc, week, sec, xyz, nchan, sdr_type=1):
+    def run_host(self, eph_sets, ieph, utc, week, sec, xyz, nchan, sdr_type=1):
         """The reference's host side of the block loop with channel allocation in it
-        (allocateChannel at the start and at every 30 s refresh, gps.c:2663-2675, 2731-2765, 2870,
-        2878-2885, 2909).  eph_set: gpsiq_rinex_eph_t[32]; xyz [nblocks+1][3].
-        Returns (descriptors [nblocks][nchan], nsat of every allocateChannel call)."""
-        eph_set = np.ascontiguousarray(eph_set, dtype=RINEX_EPH_DTYPE)
+        (allocateChannel at the start and at every 30 s refresh, the nav-message refresh and the
+        switch to the next ephemeris set: gps.c:2663-2675, 2731-2765, 2870, 2878-2909).
+        eph_sets: gpsiq_rinex_eph_t[nsets][32], ieph the set to start with; xyz [nblocks+1][3].
+        Returns (descriptors [nblocks][nchan], nsat of every allocateChannel call, final ieph)."""
+        eph_sets = np.ascontiguousarray(eph_sets, dtype=RINEX_EPH_DTYPE)
         utc = np.ascontiguousarray(utc, dtype=NAV_UTC_DTYPE)
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
-        assert eph_set.shape == (32,)
+        assert eph_sets.ndim == 2 and eph_sets.shape[1] == 32
         nb = len(xyz) - 1
         out = np.zeros((nb, nchan), dtype=CHAN_DTYPE)
         nsat = np.zeros(nb // 300 + 3, dtype=np.int32)
-        self.lib.ref_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                          C.c_void_p, C.c_void_p, C.c_int]
-        rc = self.lib.ref_run_host(_ptr(eph_set), _ptr(utc), int(week), float(sec), _ptr(xyz), nb, int(nchan), sdr_type,
-                                   _ptr(out), _ptr(nsat), len(nsat))
+        ieph_end = C.c_int(-1)
+        self.lib.ref_run_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        rc = self.lib.ref_run_host(_ptr(eph_sets), len(eph_sets), int(ieph), _ptr(utc), int(week), float(sec), _ptr(xyz), nb,
+                                   int(nchan), sdr_type, _ptr(out), _ptr(nsat), len(nsat), C.byref(ieph_end))
         if rc < 0:
             raise RuntimeError(rc)
-        return out, nsat[:rc]
+        return out, nsat[:rc], ieph_end.value
 
     def nav_parity(self, source, nib=False):
         self.lib.ref_nav_parity.restype = C.c_uint

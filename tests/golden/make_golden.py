@@ -212,10 +212,11 @@ def make_alloc_golden():
     r = _oracle.load_ref()
     nblocks, nchan = 1300, 16
     with tempfile.TemporaryDirectory() as td:
-        _, eph, utc, xyz, sec = horizon_scenario(pathlib.Path(td), nblocks, seed=6)
-    desc, nsat = r.run_host(eph[0], utc, WEEK, sec, xyz, nchan)
+        _, eph, ieph, utc, xyz, sec = horizon_scenario(pathlib.Path(td), nblocks, seed=6, sec=269990.0)
+    desc, nsat, ieph_end = r.run_host(eph, ieph, utc, WEEK, sec, xyz, nchan)
+    assert ieph_end == ieph + 1            # the run crosses the switch to the next ephemeris set
     sha = np.stack([np.frombuffer(hashlib.sha256(desc[b].tobytes()).digest(), dtype=np.uint8) for b in range(nblocks)])
-    np.savez_compressed(os.path.join(HERE, "alloc_horizon.npz"), nblocks=nblocks, nchan=nchan, seed=6, nsat=nsat,
+    np.savez_compressed(os.path.join(HERE, "alloc_horizon.npz"), nblocks=nblocks, nchan=nchan, seed=6, sec=sec, nsat=nsat,
                         prn=desc["prn"].astype(np.int8), sha256=sha)
     print("alloc_horizon:", desc.shape, "nsat", list(nsat), "prn changes", int((desc["prn"][1:] != desc["prn"][:-1]).sum()))
 

@@ -131,11 +131,10 @@ def test_multi_epoch_scenario_to_samples_on_gpu(oracle, tmp_path):
     ctx.close(); ctx2.close()
 
 
-def horizon_scenario(tmp_path, nblocks, seed=5):
+def horizon_scenario(tmp_path, nblocks, seed=5, sec=270000.0):
     """9 satellites well above the horizon and 9 within +-0.35 degrees of it at the start time, so
     that allocateChannel() has satellites rising and setting at the 30 s refreshes."""
     from gpsiq.scenario import _elevation_deg, synth_constellation
-    sec = 270000.0
     high = synth_constellation(9, TOKYO, sec, seed=seed, min_elev_deg=15.0)
     near = synth_constellation(60, TOKYO, sec, seed=seed + 100, min_elev_deg=-0.45, max_elev_deg=0.45)
     el0 = np.array([_elevation_deg(e, sec, TOKYO) for e in near])
@@ -150,19 +149,19 @@ def horizon_scenario(tmp_path, nblocks, seed=5):
     ieph = gpsiq.rinex_select(eph, n, WEEK, sec)                 # the set gps_thread_ep would start with (gps.c:2588-2608)
     assert ieph >= 0
     xyz = circle_track(TOKYO, nblocks, radius_m=150.0, period_s=50.0)
-    return path, eph[ieph:ieph + 1], utc, xyz, sec
+    return path, eph[:n], ieph, utc, xyz, sec
 
 
 def test_visibility_matches_reference(ref, tmp_path):
     """gpsiq_sat_visibility == checkSatVisibility (gps.c:2142-2162), through the allocation it drives:
     the number of visible satellites allocateChannel() reports at every call."""
     from gpsiq.pipeline import RunAheadAllocating
-    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, 1300)
-    ra = RunAheadAllocating(eph[0], utc, 12, WEEK, sec, xyz[0])
+    _, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, 1300)
+    ra = RunAheadAllocating(eph, utc, 12, WEEK, sec, xyz[0], ieph=ieph)
     ra.descriptors(xyz[1:])
-    _, nsat = ref.run_host(eph[0], utc, WEEK, sec, xyz, 12)
+    _, nsat, _ = ref.run_host(eph, ieph, utc, WEEK, sec, xyz, 12)
     assert list(nsat) == ra.nsat and len(nsat) == 5
-    vis, azel = gpsiq.sat_visibility(eph[0, 0]["orbit"], WEEK, sec, TOKYO)
+    vis, azel = gpsiq.sat_visibility(eph[ieph, 0]["orbit"], WEEK, sec, TOKYO)
     assert 0.0 <= azel[0] < 2 * np.pi and -np.pi / 2 <= azel[1] <= np.pi / 2 and vis == (azel[1] > 0.0)
 
 
@@ -172,11 +171,11 @@ def test_allocating_pipeline_matches_the_reference_loop(ref, tmp_path, nchan, se
     every block equals the reference's own allocateChannel + refresh + nav-refresh lines."""
     from gpsiq.pipeline import RunAheadAllocating
     nblocks = 1300
-    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=seed)
-    ra = RunAheadAllocating(eph[0], utc, nchan, WEEK, sec, xyz[0])
+    _, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=seed)
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
     desc = ra.descriptors(xyz[1:])
-    want, nsat = ref.run_host(eph[0], utc, WEEK, sec, xyz, nchan)
-    assert list(nsat) == ra.nsat
+    want, nsat, ieph_end = ref.run_host(eph, ieph, utc, WEEK, sec, xyz, nchan)
+    assert list(nsat) == ra.nsat and ieph_end == ra.ieph
     for f in ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd", "carr_phase"):
         assert desc[f].tobytes() == want[f].tobytes(), f
     prn = desc["prn"]
@@ -196,8 +195,8 @@ def test_allocating_scenario_to_samples_on_gpu(oracle, tmp_path):
     from gpsiq.abi import SC16
     from gpsiq.pipeline import RunAheadAllocating
     nblocks, fs, ns = 330, 2.6e6, 260000
-    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6)
-    desc = RunAheadAllocating(eph[0], utc, 16, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    _, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6)
+    desc = RunAheadAllocating(eph, utc, 16, WEEK, sec, xyz[0], ieph=ieph).descriptors(xyz[1:])
     assert (desc["prn"][300] != desc["prn"][299]).any()
     import torch
     ctx = gpsiq.Context(0)
@@ -210,6 +209,21 @@ def test_allocating_scenario_to_samples_on_gpu(oracle, tmp_path):
     ctx.close()
 
 
+def test_switch_to_the_next_ephemeris_set_matches_reference(ref, tmp_path):
+    """Start 10 s before the hour mark of the next set: the second 30 s refresh switches sets
+    (gps.c:2889-2906) — new orbits at once, new subframes in the words from the refresh after."""
+    from gpsiq.pipeline import RunAheadAllocating
+    nblocks, nchan = 1000, 14
+    _, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=9, sec=269990.0)
+    assert ieph == 0 and len(eph) == 2
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
+    desc = ra.descriptors(xyz[1:])
+    want, nsat, ieph_end = ref.run_host(eph, ieph, utc, WEEK, sec, xyz, nchan)
+    assert ieph_end == 1 and ra.ieph == 1 and list(nsat) == ra.nsat
+    for f in ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd", "carr_phase"):
+        assert desc[f].tobytes() == want[f].tobytes(), f
+
+
 def test_golden_allocation_capture(tmp_path):
     """Committed capture of the reference's allocating host loop (runs without /root/reference)."""
     import hashlib
@@ -217,8 +231,8 @@ def test_golden_allocation_capture(tmp_path):
     from gpsiq.pipeline import RunAheadAllocating
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alloc_horizon.npz"))
     nblocks, nchan = int(z["nblocks"]), int(z["nchan"])
-    _, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=int(z["seed"]))
-    ra = RunAheadAllocating(eph[0], utc, nchan, WEEK, sec, xyz[0])
+    _, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=int(z["seed"]), sec=float(z["sec"]))
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
     desc = ra.descriptors(xyz[1:])
     assert ra.nsat == list(z["nsat"])
     assert np.array_equal(desc["prn"], z["prn"])
@@ -236,20 +250,21 @@ def test_c_runahead_program_equals_the_python_pipeline(oracle, tmp_path):
     from gpsiq.pipeline import RunAheadAllocating
     host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-sdr-gps-sim_amd", "host")
     subprocess.run(["make", "-s", "-C", host], check=True)
-    nblocks, nchan, fs, ns = 330, 16, 2.6e6, 260000
-    path, eph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6)
+    nblocks, nchan, fs, ns = 430, 16, 2.6e6, 260000
+    path, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6, sec=269990.0)
     xyz.tofile(str(tmp_path / "xyz.bin"))
     out = str(tmp_path / "iq.bin")
     r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "xyz.bin"),
                         str(nblocks), str(nchan), repr(fs), "1", out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     got = np.fromfile(out, dtype=np.int8).reshape(nblocks, 2 * ns)
-    desc = RunAheadAllocating(eph[0], utc, nchan, WEEK, sec, xyz[0]).descriptors(xyz[1:])
-    assert (desc["prn"][300] != desc["prn"][299]).any()
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
+    desc = ra.descriptors(xyz[1:])
+    assert ra.ieph == ieph + 1, "the run should cross the switch to the next ephemeris set"
     ctx = gpsiq.Context(0)
     want = ctx.generate_batch(desc, ns, fs, SC08)
     ctx.close()
     assert np.array_equal(got, want)
     q = oracle.quantize_blocks(desc, fs, ns)
-    for b in (0, 99, 100, 299, 300, 329):
+    for b in (0, 99, 100, 399, 400, 429):
         assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, SC08)), b
