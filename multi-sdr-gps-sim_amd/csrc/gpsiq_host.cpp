@@ -250,7 +250,7 @@ int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double del
             for (int i = 0; i < j.nchan; ++i) {
                 int rc = quantize_one(j.ch[(size_t) b * j.nchan + i], j.delt, j.nsamp, nullptr, &j.q[(size_t) b * j.nchan + i], nullptr);
                 if (rc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, rc))
-                    std::snprintf(j.err, sizeof j.err, "block %d: %s", b, gpsiq_last_error());
+                    std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error());
             }
     }, &qj);
     if (qj.rc != GPSIQ_OK) return fail(qj.rc, "%s", qj.err);

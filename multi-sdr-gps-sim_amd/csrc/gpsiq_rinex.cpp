@@ -54,7 +54,9 @@ GpsTime to_gps(int y, int m, int d, int hh, int mm, double sec)
     const int ye = y - 1980;
     int lpdays = ye / 4 + 1;
     if ((ye % 4) == 0 && m <= 2) lpdays--;
-    const int de = ye * 365 + doy[m - 1] + d + lpdays - 6;
+    // a damaged record can carry month 0 or > 12: the reference indexes its table with it
+    // (gps.c:331, undefined behaviour); here such a month counts as January
+    const int de = ye * 365 + doy[(m >= 1 && m <= 12) ? m - 1 : 0] + d + lpdays - 6;
     GpsTime g;
     g.week = de / 7;
     g.sec = (double) (de % 7) * kSecDay + hh * kSecHour + mm * kSecMinute + sec;

@@ -40,6 +40,40 @@ def test_fifo_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-2000:]
 
 
+def test_host_half_under_address_and_ub_sanitizers(tmp_path):
+    """The host-only sources of the library (quantiser + worker pool, refresh, nav words, RINEX
+    readers incl. every truncation of a file, fifo hand-off) under ASan + UBSan."""
+    from gpsiq.scenario import llh_to_ecef, synth_rinex_records, write_rinex_nav
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "multi-sdr-gps-sim_amd", "csrc")
+    exe = str(tmp_path / "sanitize_host")
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+             "-I" + os.path.join(root, "include"), "-I" + csrc]
+    objs = []
+    for src in ("gpsiq_host.cpp", "gpsiq_refresh.cpp", "gpsiq_nav.cpp", "gpsiq_rinex.cpp"):
+        o = str(tmp_path / (src + ".o"))
+        b = subprocess.run(["g++", "-std=c++17", *flags, "-c", os.path.join(csrc, src), "-o", o], capture_output=True, text=True)
+        if b.returncode != 0:
+            pytest.skip("no sanitizer toolchain here: " + b.stderr[-200:])
+        objs.append(o)
+    o = str(tmp_path / "drv.o")
+    subprocess.run(["gcc", "-std=c11", *flags, "-c", os.path.join(root, "tests", "sanitize_host.c"), "-o", o], check=True)
+    b = subprocess.run(["g++", "-fsanitize=address,undefined", "-o", exe, o, *objs, "-lpthread", "-lz", "-lm"], capture_output=True, text=True)
+    if b.returncode != 0:
+        pytest.skip("no sanitizer runtime here: " + b.stderr[-200:])
+    pos = llh_to_ecef(35.681298, 139.766247, 10.0)
+    utc = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
+               A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=2190, dtls=18)
+    recs = synth_rinex_records(10, pos, 2190, 270000.0, seed=13, sets=2)
+    for version in (2, 3):
+        path = write_rinex_nav(str(tmp_path / f"in.v{version}"), recs, utc, version)
+        r = subprocess.run([exe, path, str(tmp_path / "cut"), str(version)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        if "Shadow memory range interleaves" in r.stderr or "ReserveShadowMemoryRange failed" in r.stderr:
+            pytest.skip("AddressSanitizer cannot map its shadow memory in this container")
+        assert r.returncode == 0 and r.stdout.strip() == "ok", (r.stdout + r.stderr)[-3000:]
+
+
 def test_fifo_header_matches_reference_api():
     """Same nine entry points and the same struct fields as the reference's fifo.h:19-63."""
     txt = open(os.path.join(HOST, "fifo.h")).read()
