@@ -78,6 +78,23 @@ int main(int argc, char **argv)
                 (void) gpsiq_rinex_read(argv[2], 2, &e2[0][0], &u2);
                 (void) gpsiq_rinex_read(argv[2], 3, &e2[0][0], &u2);
             }
+            for (int it = 0; it < 300; ++it) {            /* random damage: bytes overwritten, lines cut or doubled */
+                static char mut[1 << 20];
+                memcpy(mut, text, len);
+                size_t mlen = len;
+                for (int k = 0; k < 1 + (int) (rnd() % 12); ++k) {
+                    const size_t at = rnd() % len;
+                    switch (rnd() % 4) {
+                    case 0: mut[at] = (char) (rnd() & 0xff); break;
+                    case 1: mut[at] = '\n'; break;
+                    case 2: mut[at] = "0123456789.-+DEed "[rnd() % 18]; break;
+                    default: if (at + 200 < mlen) { memmove(mut + at, mut + at + 1 + rnd() % 150, mlen - at - 160); mlen -= 160; } break;
+                    }
+                }
+                FILE *o = fopen(argv[2], "wb"); CHECK(o); fwrite(mut, 1, mlen, o); fclose(o);
+                static gpsiq_rinex_eph_t e2[GPSIQ_EPHEM_SETS][GPSIQ_MAX_SAT]; gpsiq_nav_utc_t u2;
+                (void) gpsiq_rinex_read(argv[2], version, &e2[0][0], &u2);
+            }
             CHECK(gpsiq_rinex_read(argv[1], version, &eph[0][0], &utc) == nsets);
         }
         const int week = eph[0][0].vflg ? eph[0][0].nav.toe_week : 2190;
