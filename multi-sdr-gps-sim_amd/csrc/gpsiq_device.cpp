@@ -3,6 +3,7 @@
 // There is deliberately no CPU path here: without a GPU gpsiq_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
@@ -15,7 +16,7 @@
 namespace gpsiq {
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream, int max_active);
+                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude);
 }
 
 using namespace gpsiq;
@@ -30,6 +31,7 @@ struct gpsiq_ctx {
     int            nblocks = 0, nchan = 0;
     uint64_t       max_code_step = 0;
     int            max_active = 0;      // most active channels in any resident block
+    long           max_amplitude = 0;   // largest sum over a block's channels of (int)(250*|gain|): bound on |I|, |Q|
     gpsiq_qchan_t *h_desc = nullptr;   // page-locked staging of the compacted descriptors
     size_t         h_desc_cap = 0;
     // staging for the synchronous entry points
@@ -178,16 +180,18 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     // Device copy is compacted per block: active channels first, unused slots (zeroed)
     // after them.  The sum over channels is commutative modulo 2^16, so slot order is free.
     // Validation + compaction run on host threads straight into the page-locked staging buffer.
-    struct PJob { const gpsiq_qchan_t *q; gpsiq_qchan_t *out; int nchan; uint64_t mx; int max_active; int rc; size_t bad; };
-    PJob pj = {q, c->h_desc, nchan, 0, 0, GPSIQ_OK, 0};
+    struct PJob { const gpsiq_qchan_t *q; gpsiq_qchan_t *out; int nchan; uint64_t mx; int max_active; long max_amp; int rc; size_t bad; };
+    PJob pj = {q, c->h_desc, nchan, 0, 0, 0, GPSIQ_OK, 0};
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
     parallel_for(nblocks, 0, 128, [](void *p, int b0, int b1) {
         PJob &j = *static_cast<PJob *>(p);
         uint64_t mx = 0;
         int max_active = 0;
+        long max_amp = 0;
         for (int b = b0; b < b1; ++b) {
             int na = 0;
+            long amp = 0;
             for (int s = 0; s < j.nchan; ++s) {
                 const size_t i = (size_t) b * j.nchan + s;
                 const gpsiq_qchan_t &d = j.q[i];
@@ -198,13 +202,16 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
                     continue;
                 }
                 if (d.code_step > mx) mx = d.code_step;
+                amp += (long) (250.0 * std::fabs(d.gain));           // |(int)(table*gain)| <= (int)(250*|gain|), gps.c:2781-2782
                 j.out[(size_t) b * j.nchan + na++] = d;
             }
             for (int s = na; s < j.nchan; ++s) std::memset(&j.out[(size_t) b * j.nchan + s], 0, sizeof(gpsiq_qchan_t));
             if (na > max_active) max_active = na;
+            if (amp > max_amp) max_amp = amp;
         }
         for (uint64_t cur = j.mx; mx > cur && !__sync_bool_compare_and_swap(&j.mx, cur, mx); cur = j.mx) {}
         for (int cur = j.max_active; max_active > cur && !__sync_bool_compare_and_swap(&j.max_active, cur, max_active); cur = j.max_active) {}
+        for (long cur = j.max_amp; max_amp > cur && !__sync_bool_compare_and_swap(&j.max_amp, cur, max_amp); cur = j.max_amp) {}
     }, &pj);
     if (pj.rc != GPSIQ_OK) return fail(pj.rc, "descriptor %zu outside the NCO format (prn %u)", pj.bad, q[pj.bad].prn);
     const uint64_t mx = pj.mx;
@@ -218,7 +225,7 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
             std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %.2f ms\n",
                          nblocks, t1 - t0, wall_ms() - t1);
     }
-    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx; c->max_active = max_active;
+    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx; c->max_active = max_active; c->max_amplitude = pj.max_amp;
     return GPSIQ_OK;
 }
 
@@ -230,7 +237,7 @@ int gpsiq_launch(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int sample_
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t) hip_stream;
     HIP_TRY(launch_variant(pick_variant(c, variant), c->d_desc, c->nchan, nsamp, sample_size, dst,
-                           block_stride_bytes, block0, nblocks, c->d_tab, s, c->max_active));
+                           block_stride_bytes, block0, nblocks, c->d_tab, s, c->max_active, c->max_amplitude));
     return GPSIQ_OK;
 }
 
@@ -258,7 +265,7 @@ int gpsiq_time_launches(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int 
     HIP_TRY(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) {
         hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, block_stride_bytes,
-                                      block0, nblocks, c->d_tab, s, c->max_active);
+                                      block0, nblocks, c->d_tab, s, c->max_active, c->max_amplitude);
         if (e != hipSuccess) {
             (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
             return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));

@@ -395,7 +395,14 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
 //   * H = 2 ("segh"): one window per HALF row (32 lanes), so a row may span up to 63 chips
 //     and the kernel works down to one chip per sample (1.023 Msps); lanes 32..63 read the
 //     second window of their row (two LDS addresses per wave read instead of one).
-template <int FMT, int NCH, int ROWS, int H>
+//   * FAST (chosen by the host when no sum over the channels of a block can leave the int16
+//     range, i.e. sum of (int)(250*|gain|) <= 32767): the LUT entry is the single integer
+//     I + 65536*Q, the channel sum is a plain 32-bit add (exact: it cannot overflow), and the chip
+//     sign is applied as half a carrier cycle: the carrier table is antisymmetric
+//     (table[k+256] == -table[k], so is (int)(table*gain)), hence adding the sign bit to the top
+//     index bit of the phase word selects the negated entry.  The shifted window's higher bits land
+//     in the five spare bits above the index.  lshr, lshl_add, add replace bfe, or, pk_mad.
+template <int FMT, int NCH, int ROWS, int H, bool FAST>
 __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
     size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block,
@@ -437,7 +444,8 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
             // int8 output keeps bits 4..11 of each 16-bit sum (gps.c:2845): with the entries
             // pre-shifted by 4 (still modulo 2^16) those bits are bytes 1 and 3 of the packed sum
             constexpr int kPre = FMT == GPSIQ_SC08 ? 4 : 0;
-            lut[c][tid] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
+            if (FAST) lut[c][tid] = (uint32_t) (tc + ts * 65536);          // one integer; |tc|, |ts| <= 32767 here
+            else      lut[c][tid] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
         }
     }
     for (int e = tid; e < NCH * kPrnExtWords; e += kRowsThreads) {
@@ -504,25 +512,43 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     uint32_t *w_dst = &win[wave][wg][wc];
 
     auto row_body = [&](int r, uint32_t n_chunk, bool check) {
-        s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
+        uint32_t iq;                                             // (I & 0xffff) | Q << 16, what the int16 store keeps
+        if (FAST) {
+            uint32_t sum = 0;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const uint32_t w = w_row[r * (H * NCH) + c];
-            const uint32_t b = (uint32_t) (Q[c] >> 56);
-            const uint32_t m = (uint32_t) __builtin_amdgcn_sbfe((int) w, b, 1u);
-            const uint32_t sgn = m | 0x00010001u;
-            const uint32_t a = (uint32_t) (P[c] >> 48) & 0x7fcu;
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
-            if (c & 1) acc1 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc1;
-            else       acc0 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc0;
-            P[c] += dP[c];
-            Q[c] += dQ[c];
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t w = w_row[r * (H * NCH) + c];
+                const uint32_t t = w >> ((uint32_t) (Q[c] >> 56) & 31u);        // bit 0 = chip ^ nav bit of this lane
+                const uint32_t x = (t << 26) + (uint32_t) (P[c] >> 32);          // + half a cycle when that bit is set
+                const uint32_t a = (x >> 16) & 0x7fcu;
+                sum += *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+                P[c] += dP[c];
+                Q[c] += dQ[c];
+            }
+            iq = sum + ((sum & 0x8000u) << 1);                    // I + 65536*Q -> packed halves (a negative I borrowed from Q)
+        } else {
+            s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t w = w_row[r * (H * NCH) + c];
+                const uint32_t b = (uint32_t) (Q[c] >> 56);
+                const uint32_t m = (uint32_t) __builtin_amdgcn_sbfe((int) w, b, 1u);
+                const uint32_t sgn = m | 0x00010001u;
+                const uint32_t a = (uint32_t) (P[c] >> 48) & 0x7fcu;
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+                if (c & 1) acc1 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc1;
+                else       acc0 = __builtin_bit_cast(s16x2, v) * __builtin_bit_cast(s16x2, sgn) + acc0;
+                P[c] += dP[c];
+                Q[c] += dQ[c];
+            }
+            iq = __builtin_bit_cast(uint32_t, acc0 + acc1);
         }
         const uint32_t n = n_chunk + (uint32_t) lane + (uint32_t) r * 64u;
         if (!check || n < (uint32_t) nsamp) {
-            const uint32_t iq = __builtin_bit_cast(uint32_t, acc0 + acc1);
             if (FMT == GPSIQ_SC16)
                 *reinterpret_cast<uint32_t *>(blk_dst + n * 4u) = iq;                     // gps.c:2842
+            else if (FAST)                                                               // (signed char)(x >> 4), gps.c:2845
+                *reinterpret_cast<uint16_t *>(blk_dst + n * 2u) = (uint16_t) __builtin_amdgcn_perm(iq >> 12, iq >> 4, 0x0c0c0500u);
             else                                                                         // bytes 1 and 3, see the LUT build
                 *reinterpret_cast<uint16_t *>(blk_dst + n * 2u) = (uint16_t) __builtin_amdgcn_perm(iq, iq, 0x0c0c0301u);
         }
@@ -564,12 +590,12 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         int rows = wave_rows - row0;                         // the wave's last chunk may be partial
         rows = rows < ROWS ? rows : ROWS;
         if (n_chunk + (uint32_t) rows * 64u <= (uint32_t) nsamp) {
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int r = 0; r < rows; ++r) row_body(r, n_chunk, false);
         } else {                                             // the block ends inside this chunk
             const int in_block = (int) (((uint32_t) nsamp - n_chunk + 63u) >> 6);
             rows = rows < in_block ? rows : in_block;
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int r = 0; r < rows; ++r) row_body(r, n_chunk, true);
         }
         // the next chunk overwrites this wave's windows: all lanes must be done reading
@@ -588,15 +614,17 @@ struct SegPolicy {
     double setup_rows;      // per-workgroup set-up, in row-times (measured: tile vs seg = 4 %)
     double drain_rounds;    // time lost while the grid drains, in workgroup durations
     double resident_wgs;    // 256 CUs x 2 workgroups (67 KB LDS each)
+    bool   allow_fast;      // GPSIQ_NO_FAST=1 forces the packed-multiply kernels (A/B experiments, tests)
 };
 static const SegPolicy &seg_policy()
 {
     static const SegPolicy pol = [] {
-        SegPolicy p = {512, 512, 3.5, 0.3, 512.0};
+        SegPolicy p = {512, 512, 3.5, 0.3, 512.0, true};
         if (const char *e = std::getenv("GPSIQ_SEG_TAIL_WGS")) p.tail_wgs = std::atoi(e);
         if (const char *e = std::getenv("GPSIQ_SEG_MAX_WAVE_ROWS")) p.max_wave_rows = std::atoi(e);
         if (const char *e = std::getenv("GPSIQ_SEG_SETUP_ROWS")) p.setup_rows = std::atof(e);
         if (const char *e = std::getenv("GPSIQ_SEG_DRAIN")) p.drain_rounds = std::atof(e);
+        if (const char *e = std::getenv("GPSIQ_NO_FAST")) p.allow_fast = std::atoi(e) == 0;
         return p;
     }();
     return pol;
@@ -604,7 +632,7 @@ static const SegPolicy &seg_policy()
 
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream, int max_active)
+                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude)
 {
     if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
     uint8_t *d = static_cast<uint8_t *>(dst);
@@ -642,8 +670,11 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
         const int big_blocks = nblocks - tail_blocks;
         const int big_wgs = tiles * big_blocks;
         dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kRowsThreads);
-#define GPSIQ_LAUNCH_T(F, N) do { if (half) hipLaunchKernelGGL((synth_tile<F, N, 32, 2>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1); \
-                                  else hipLaunchKernelGGL((synth_tile<F, N, 64, 1>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1); } while (0)
+        // no channel sum of any resident block can leave the int16 range: plain-add kernel
+        const bool fast = max_amplitude <= 32767 && seg_policy().allow_fast;
+#define GPSIQ_LAUNCH_T4(F, N, R, HH, FA) hipLaunchKernelGGL((synth_tile<F, N, R, HH, FA>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1)
+#define GPSIQ_LAUNCH_T(F, N) do { if (half) { if (fast) GPSIQ_LAUNCH_T4(F, N, 32, 2, true); else GPSIQ_LAUNCH_T4(F, N, 32, 2, false); } \
+                                  else      { if (fast) GPSIQ_LAUNCH_T4(F, N, 64, 1, true); else GPSIQ_LAUNCH_T4(F, N, 64, 1, false); } } while (0)
         const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
         if (sample_size == GPSIQ_SC16) {
             if (slots == 4) GPSIQ_LAUNCH_T(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_T(GPSIQ_SC16, 8);
@@ -653,6 +684,7 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
             else if (slots == 12) GPSIQ_LAUNCH_T(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_T(GPSIQ_SC08, 16);
         }
 #undef GPSIQ_LAUNCH_T
+#undef GPSIQ_LAUNCH_T4
     } else if (variant == kRowsX) {
         const int tiles = (nsamp + kRowsTile - 1) / kRowsTile;
         dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);

@@ -387,6 +387,50 @@ def test_quantised_descriptor_fuzz_long_blocks(ctx, oracle, seed):
                 assert np.array_equal(got[b], want[ss][b]), (variant, ss, b, ns, nc)
 
 
+@pytest.mark.parametrize("variant", ["tile", "seg", "segh"])
+@pytest.mark.parametrize("gain,expect_wrap", [(8.19, False), (8.3, True), (-8.19, False), (131.0, True)])
+def test_amplitude_bound_and_the_plain_add_kernels(ctx, oracle, variant, gain, expect_wrap):
+    """The tile kernels sum the channels with plain 32-bit adds (entry = I + 65536*Q, chip sign as
+    half a carrier cycle) whenever no block's sum of (int)(250*|gain|) exceeds 32767, and with packed
+    16-bit multiply-adds otherwise.  16 identical channels make every sample the worst case:
+    16 * 2047 = 32752 stays inside int16 (plain adds), 16 * 2075 = 33200 wraps like the reference's
+    (short) cast (packed path); both equal the oracle in both formats."""
+    fs, ns = 2.6e6, 40000
+    d = synth_blocks(2, 16, seed=123)
+    for f in ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "carr_phase", "code_phase", "dwrd"):
+        d[f][:, 1:] = d[f][:, :1]
+    d["gain"] = gain
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    ctx.set_descriptors(q)
+    want16 = [oracle.block_fixed(q[b], ns, SC16) for b in range(2)]
+    peak = max(int(np.abs(w.astype(np.int32)).max()) for w in want16)
+    assert (peak > 32752) == expect_wrap or expect_wrap            # the wrapped cases reach the int16 limits
+    got16 = run_device(ctx, q, ns, SC16, variant)
+    got8 = run_device(ctx, q, ns, SC08, variant)
+    for b in range(2):
+        assert np.array_equal(got16[b], want16[b])
+        assert np.array_equal(got8[b], oracle.block_fixed(q[b], ns, SC08))
+    if not expect_wrap:
+        assert peak == 16 * 2047                                   # the largest sum the plain-add kernels may see
+
+
+def test_mixed_gains_next_to_the_amplitude_bound(ctx, oracle):
+    """One block just under the bound and one just over in the same launch: the whole launch takes
+    the packed path; relaunching only the small block takes the plain-add path; same bytes."""
+    fs, ns = 2.6e6, 30000
+    d = synth_blocks(2, 16, seed=321)
+    d["gain"][0] = 32767.0 / 250.0 / 16.0 - 1e-3           # 16 * 2047 = 32752 <= 32767
+    d["gain"][1] = 32767.0 / 250.0 / 16.0 + 0.2            # 16 * 2097 > 32767
+    q, _ = gpsiq.quantize_blocks(d, fs, ns)
+    ctx.set_descriptors(q)
+    both = run_device(ctx, q, ns, SC16, "auto")
+    ctx.set_descriptors(q[:1])
+    small = run_device(ctx, q[:1], ns, SC16, "auto")
+    assert np.array_equal(both[0], small[0])
+    for b in range(2):
+        assert np.array_equal(both[b], oracle.block_fixed(q[b], ns, SC16))
+
+
 def test_empty_and_maximum_block_sizes(ctx, oracle):
     """Empty launches are no-ops; the longest block the descriptor format allows (32 nav bits
     = 0.62 s of signal) is exact from the first to the last sample; one sample more is an error."""
