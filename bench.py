@@ -312,6 +312,10 @@ def main():
         samples_step = nblocks * nsamp * world
         value = samples_step * args.steps / t_max / 1e6
         alg_bytes = nblocks * blk_bytes                 # algorithmic: 2 or 4 B per complex sample, reads ~0
+        # which tile kernel ran: plain adds when no block's sum of (int)(250*|gain|) exceeds 32767
+        forced_packed = os.environ.get("GPSIQ_NO_FAST", "0") not in ("", "0")
+        plain_add = int(np.floor(250.0 * np.abs(q["gain"])).sum(axis=1).max()) <= 32767 and not forced_packed
+        core_cycles = 23.85 if plain_add else 26.7
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -334,14 +338,17 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
-            # informational: the limiter actually hit.  The row-kernel core is
-            # 5 four-cycle + 2 two-cycle VALU instructions per (channel, 64-sample row) per SIMD
-            # (profiles/r01_ubench_valu_encodings.txt) = 26.5 issue cycles; peak = every SIMD of
-            # 256 CUs issuing only that core at the 2.4 GHz maximum clock.
-            "issue_roofline": {"bound": "valu-issue", "unit": "Gchannel-samples/s",
+            # informational: the limiter actually hit.  Per (channel, 64-sample row)
+            # and SIMD the row-kernel core costs, with the single-instruction rates measured on this
+            # chip (profiles/r01_ubench_valu_encodings.txt: 4.3 nominal cycles for SGPR-operand / VOP3 /
+            # SDWA / packed forms, 4.4 for v_lshl_add_u64, 2.5 for plain VOP2),
+            #   plain-add kernels (all sums inside int16): 3 x 4.3 + 4.3 / 2 + 2 x 4.4 = 23.85 cycles
+            #   packed kernels (larger gains):             3 x 4.3 + 2 x 2.5 + 2 x 4.4 = 26.7 cycles
+            # peak = every SIMD of 256 CUs issuing only that core at the 2.4 GHz maximum clock.
+            "issue_roofline": {"bound": "valu-issue", "unit": "Gchannel-samples/s", "core_cycles": core_cycles,
                                "achieved": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / 1e9, 1),
-                               "peak": round(256 * 4 * 64 * 2.4e9 / 26.5 / 1e9, 1),
-                               "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / 26.5), 4)},
+                               "peak": round(256 * 4 * 64 * 2.4e9 / core_cycles / 1e9, 1),
+                               "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / core_cycles), 4)},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
