@@ -312,9 +312,9 @@ def main():
         samples_step = nblocks * nsamp * world
         value = samples_step * args.steps / t_max / 1e6
         alg_bytes = nblocks * blk_bytes                 # algorithmic: 2 or 4 B per complex sample, reads ~0
-        # which tile kernel ran: plain adds when no block's sum of (int)(250*|gain|) exceeds 32767
+        # which tile kernel ran: plain adds for int8 always, for int16 when no block's sum of (int)(250*|gain|) exceeds 32767
         forced_packed = os.environ.get("GPSIQ_NO_FAST", "0") not in ("", "0")
-        plain_add = int(np.floor(250.0 * np.abs(q["gain"])).sum(axis=1).max()) <= 32767 and not forced_packed
+        plain_add = (ss == 1 or int(np.floor(250.0 * np.abs(q["gain"])).sum(axis=1).max()) <= 32767) and not forced_packed
         core_cycles = 23.85 if plain_add else 26.7
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic = None

@@ -395,9 +395,10 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
 //   * H = 2 ("segh"): one window per HALF row (32 lanes), so a row may span up to 63 chips
 //     and the kernel works down to one chip per sample (1.023 Msps); lanes 32..63 read the
 //     second window of their row (two LDS addresses per wave read instead of one).
-//   * FAST (chosen by the host when no sum over the channels of a block can leave the int16
-//     range, i.e. sum of (int)(250*|gain|) <= 32767): the LUT entry is the single integer
-//     I + 65536*Q, the channel sum is a plain 32-bit add (exact: it cannot overflow), and the chip
+//   * FAST (int16 output: chosen by the host when no sum over the channels of a block can leave the
+//     int16 range, i.e. sum of (int)(250*|gain|) <= 32767; int8 output: always): the LUT entry is the
+//     single integer I + 65536*Q (int8: two 12-bit fields), the channel sum is a plain 32-bit add
+//     (exact: it cannot overflow / the fields cannot collide), and the chip
 //     sign is applied as half a carrier cycle: the carrier table is antisymmetric
 //     (table[k+256] == -table[k], so is (int)(table*gain)), hence adding the sign bit to the top
 //     index bit of the phase word selects the negated entry.  The shifted window's higher bits land
@@ -444,7 +445,13 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
             // int8 output keeps bits 4..11 of each 16-bit sum (gps.c:2845): with the entries
             // pre-shifted by 4 (still modulo 2^16) those bits are bytes 1 and 3 of the packed sum
             constexpr int kPre = FMT == GPSIQ_SC08 ? 4 : 0;
-            if (FAST) lut[c][tid] = (uint32_t) (tc + ts * 65536);          // one integer; |tc|, |ts| <= 32767 here
+            if (FAST && FMT == GPSIQ_SC08)
+                // the int8 output keeps bits 4..11 of I and Q only: 12-bit fields, I at bits 4..15 (its
+                // carries spill into bits 16..19, 16 channels x 12 bits), Q at bits 20..31; the output
+                // bytes are bytes 1 and 3 of the plain 32-bit sum, for any gain
+                lut[c][tid] = (((uint32_t) tc & 0xfffu) << 4) | ((uint32_t) ts << 20);
+            else if (FAST)
+                lut[c][tid] = (uint32_t) (tc + ts * 65536);                  // one integer; |tc|, |ts| <= 32767 here
             else      lut[c][tid] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
         }
     }
@@ -514,7 +521,8 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     auto row_body = [&](int r, uint32_t n_chunk, bool check) {
         uint32_t iq;                                             // (I & 0xffff) | Q << 16, what the int16 store keeps
         if (FAST) {
-            uint32_t sum = 0;
+            // int16: start from 0x8000 so that I + 32768 >= 0 never borrows from the Q half
+            uint32_t sum = FMT == GPSIQ_SC16 ? 0x8000u : 0u;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const uint32_t w = w_row[r * (H * NCH) + c];
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
                 P[c] += dP[c];
                 Q[c] += dQ[c];
             }
-            iq = sum + ((sum & 0x8000u) << 1);                    // I + 65536*Q -> packed halves (a negative I borrowed from Q)
+            iq = FMT == GPSIQ_SC16 ? sum ^ 0x8000u : sum;         // take the bias off again: (I & 0xffff) | Q << 16
         } else {
             s16x2 acc0 = (s16x2) (0), acc1 = (s16x2) (0);
 #pragma unroll
@@ -547,8 +555,6 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         if (!check || n < (uint32_t) nsamp) {
             if (FMT == GPSIQ_SC16)
                 *reinterpret_cast<uint32_t *>(blk_dst + n * 4u) = iq;                     // gps.c:2842
-            else if (FAST)                                                               // (signed char)(x >> 4), gps.c:2845
-                *reinterpret_cast<uint16_t *>(blk_dst + n * 2u) = (uint16_t) __builtin_amdgcn_perm(iq >> 12, iq >> 4, 0x0c0c0500u);
             else                                                                         // bytes 1 and 3, see the LUT build
                 *reinterpret_cast<uint16_t *>(blk_dst + n * 2u) = (uint16_t) __builtin_amdgcn_perm(iq, iq, 0x0c0c0301u);
         }
@@ -671,7 +677,8 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
         const int big_wgs = tiles * big_blocks;
         dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kRowsThreads);
         // no channel sum of any resident block can leave the int16 range: plain-add kernel
-        const bool fast = max_amplitude <= 32767 && seg_policy().allow_fast;
+        // (the int8 kernels keep 12-bit fields and are exact for any gain)
+        const bool fast = (sample_size == GPSIQ_SC08 || max_amplitude <= 32767) && seg_policy().allow_fast;
 #define GPSIQ_LAUNCH_T4(F, N, R, HH, FA) hipLaunchKernelGGL((synth_tile<F, N, R, HH, FA>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1)
 #define GPSIQ_LAUNCH_T(F, N) do { if (half) { if (fast) GPSIQ_LAUNCH_T4(F, N, 32, 2, true); else GPSIQ_LAUNCH_T4(F, N, 32, 2, false); } \
                                   else      { if (fast) GPSIQ_LAUNCH_T4(F, N, 64, 1, true); else GPSIQ_LAUNCH_T4(F, N, 64, 1, false); } } while (0)
