@@ -29,6 +29,19 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+_LIB = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "gpsiq", "libgpsiq.so")
+if not os.path.exists(_LIB):
+    # fresh checkout: build the HIP extension first (there is no other path to run); local rank 0
+    # builds, the other ranks of the node wait for the file
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")], check=True)
+    else:
+        for _ in range(600):
+            if os.path.exists(_LIB):
+                break
+            time.sleep(0.5)
+        time.sleep(1.0)
 
 PREHEAT_LAUNCHES = 12   # untimed, before the warm-up steps: clock ramp (see main)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)

@@ -11,6 +11,12 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library yet: compile the HIP extension (hipcc cross-compiles
+    # without a GPU).  This builds the product, it is not a fallback: without libgpsiq.so nothing runs.
+    lib = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "gpsiq", "libgpsiq.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")], check=True)
 
 
 @pytest.fixture(scope="session")
