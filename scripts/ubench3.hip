@@ -20,7 +20,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void ub(uint32_t *out, int iters, uint64_t s0, uint64_t s1, uint32_t mask)
 {
     uint64_t P0 = threadIdx.x * 0x9e3779b97f4a7c15ull, Q0 = P0 * 3, P1 = P0 * 5, Q1 = P0 * 7, P2 = P0 * 9, Q2 = P0 * 11, P3 = P0 * 13, Q3 = P0 * 15;
-    uint32_t acc = 0, w = threadIdx.x * 2654435761u, a, k, m;
+    uint32_t acc = 0, w = threadIdx.x * 2654435761u, a = 0, k = 0, m;
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {           // the full core, 4 channels x 2
 #define ONE(Pn, Qn) asm volatile( \
@@ -48,6 +48,17 @@ __global__ __launch_bounds__(256) void ub(uint32_t *out, int iters, uint64_t s0,
             : [ph] "v"((uint32_t) (Pn >> 32)), [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [mask] "s"(mask));
             FIVE(P0, Q0) FIVE(P1, Q1) FIVE(P2, Q2) FIVE(P3, Q3) FIVE(P0, Q0) FIVE(P1, Q1) FIVE(P2, Q2) FIVE(P3, Q3)
             P0 += acc;             // keep the inputs loop-carried
+        } else if (MODE == 4) {    // the plain-add core: window >> chip byte, sign into the phase, address, add3 per two channels
+#define PA(Pn, Qn, T) asm volatile( \
+            "v_lshrrev_b32_sdwa " T ", %[qh], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n" \
+            "v_lshl_add_u32 " T ", " T ", 26, %[ph]\n" \
+            "v_and_b32_sdwa " T ", " T ", %[mask] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n" \
+            "v_lshl_add_u64 %[p], %[p], 0, %[sp]\n" \
+            "v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" \
+            : [p] "+v"(Pn), [q] "+v"(Qn), [a] "+v"(a), [k] "+v"(k) \
+            : [ph] "v"((uint32_t) (Pn >> 32)), [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [mask] "s"(mask), [sp] "s"(s0), [sq] "s"(s1));
+#define PA2(Pa, Qa, Pb, Qb) PA(Pa, Qa, "%[a]") PA(Pb, Qb, "%[k]") asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(k));
+            PA2(P0, Q0, P1, Q1) PA2(P2, Q2, P3, Q3) PA2(P0, Q0, P1, Q1) PA2(P2, Q2, P3, Q3)
         } else if (MODE == 3) {    // NCO adds with VGPR steps instead of SGPR pairs
             uint64_t v0 = s0 + threadIdx.x, v1 = s1 + threadIdx.x;
 #define TWOV(Pn, Qn) asm volatile("v_lshl_add_u64 %[p], %[p], 0, %[sp]\n v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" : [p] "+v"(Pn), [q] "+v"(Qn) : [sp] "v"(v0), [sq] "v"(v1));
@@ -89,6 +100,7 @@ int main()
         run<1>("2x v_lshl_add_u64 (SGPR-pair step)", w, 2);
         run<3>("2x v_lshl_add_u64 (VGPR-pair step)", w, 2);
         run<2>("sdwa,lshr,bfe,or,pk_mad", w, 5);
+        run<4>("plain-add core: sdwa lshr,lshl_add,sdwa and,1/2 add3,2x lshl_add_u64", w, 5);
     }
     return 0;
 }
