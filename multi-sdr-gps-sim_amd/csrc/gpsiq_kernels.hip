@@ -596,8 +596,9 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         int rows = wave_rows - row0;                         // the wave's last chunk may be partial
         rows = rows < ROWS ? rows : ROWS;
         if (n_chunk + (uint32_t) rows * 64u <= (uint32_t) nsamp) {
+            const int rows_s = __builtin_amdgcn_readfirstlane(rows);       // the trip count is wave-uniform: keep it scalar
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (int r = 0; r < rows; ++r) row_body(r, n_chunk, false);
+            for (int r = 0; r < rows_s; ++r) row_body(r, n_chunk, false);
         } else {                                             // the block ends inside this chunk
             const int in_block = (int) (((uint32_t) nsamp - n_chunk + 63u) >> 6);
             rows = rows < in_block ? rows : in_block;
