@@ -451,7 +451,9 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
                 // bytes are bytes 1 and 3 of the plain 32-bit sum, for any gain
                 lut[c][tid] = (((uint32_t) tc & 0xfffu) << 4) | ((uint32_t) ts << 20);
             else if (FAST)
-                lut[c][tid] = (uint32_t) (tc + ts * 65536);                  // one integer; |tc|, |ts| <= 32767 here
+                // one integer; |tc|, |ts| <= 32767 here.  Slot 0 also carries the +0x8000 that keeps
+                // I + 32768 >= 0 in the sum (so a negative I never borrows from the Q half)
+                lut[c][tid] = (uint32_t) (tc + ts * 65536) + (c == 0 ? 0x8000u : 0u);
             else      lut[c][tid] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
         }
     }
@@ -521,8 +523,7 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     auto row_body = [&](int r, uint32_t n_chunk, bool check) {
         uint32_t iq;                                             // (I & 0xffff) | Q << 16, what the int16 store keeps
         if (FAST) {
-            // int16: start from 0x8000 so that I + 32768 >= 0 never borrows from the Q half
-            uint32_t sum = FMT == GPSIQ_SC16 ? 0x8000u : 0u;
+            uint32_t sum = 0u;                                    // int16: slot 0's entries carry a +0x8000 bias
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const uint32_t w = w_row[r * (H * NCH) + c];
