@@ -564,51 +564,56 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     for (int row0 = 0; row0 < wave_rows; row0 += ROWS) {
         const uint32_t n_chunk = n_wave + (uint32_t) row0 * 64u;
         // windows of this chunk (the builder state carries over from the previous chunk).
-        // A nav-bit edge comes by once in 20 ms (about 800 rows): when no lane of the wave gets near one
-        // within this chunk, the edge counter and the nav word need no per-window attention.
-        const uint32_t reach = (uint32_t) kRun * (w_dint + 1u) + 32u;      // chips this lane can advance + one window
-        if (__builtin_amdgcn_ballot_w64((uint32_t) w_e1 <= reach) == 0) {
-            const uint32_t nrot0 = w_nrot;
-            const uint32_t d0 = (uint32_t) ((int32_t) w_nrev >> 31);
-#pragma unroll 4
-            for (int i = 0; i < kRun; ++i) {
-                const uint32_t lo = ext[wc][w_k >> 5], hi = ext[wc][(w_k >> 5) + 1];
-                const uint32_t S = __builtin_amdgcn_alignbit(hi, lo, w_k) ^ d0;
-                if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_amdgcn_alignbit(S, S, w_nrot);
-                w_fr += w_dfr;
-                const uint32_t adv = w_dint + (uint32_t) (w_fr >> GPSIQ_CODE_FRAC_BITS);
-                w_fr &= kCodeFracMask;
-                w_nrot -= adv;
-                const uint32_t k2 = w_k + adv;
-                w_k = k2 - GPSIQ_CA_SEQ_LEN < k2 ? k2 - GPSIQ_CA_SEQ_LEN : k2;
-            }
-            w_e1 -= (int32_t) (nrot0 - w_nrot);                    // chips advanced in this chunk
-        } else {
-#pragma unroll 4
-            for (int i = 0; i < kRun; ++i) {
-                const uint32_t lo = ext[wc][w_k >> 5], hi = ext[wc][(w_k >> 5) + 1];
-                uint32_t S = __builtin_amdgcn_alignbit(hi, lo, w_k);   // 32 chips from chip k (shift uses k & 31)
-                S ^= (uint32_t) ((int32_t) w_nrev >> 31);
-                // the window holds the start of the next nav bit when fewer than 32 chips of the
-                // current one are left: 0.16 % of the windows, so the whole wave skips the correction
-                // unless some lane needs it
-                const bool edge = (uint32_t) w_e1 < 31u;
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(edge) != 0, 0)) {
-                    if (edge && ((w_nrev ^ (w_nrev << 1)) >> 31)) S ^= 0xfffffffeu << w_e1;
+        // A nav-bit edge comes by once in 20 ms (about 800 rows) per channel: a group of four windows
+        // during which no lane of the wave gets near one needs no attention to the edge counter and the
+        // nav word (with 16 channels about two groups in three).
+        constexpr int kGrp = 4;
+        static_assert(kRun % kGrp == 0, "window groups");
+        const uint32_t reach = (uint32_t) kGrp * (w_dint + 1u) + 32u;      // chips a lane can advance in a group + one window
+#pragma unroll 1
+        for (int i0 = 0; i0 < kRun; i0 += kGrp) {
+            if (__builtin_amdgcn_ballot_w64((uint32_t) w_e1 <= reach) == 0) {
+                const uint32_t nrot0 = w_nrot;
+                const uint32_t d0 = (uint32_t) ((int32_t) w_nrev >> 31);
+#pragma unroll
+                for (int i = i0; i < i0 + kGrp; ++i) {
+                    const uint32_t lo = ext[wc][w_k >> 5], hi = ext[wc][(w_k >> 5) + 1];
+                    const uint32_t S = __builtin_amdgcn_alignbit(hi, lo, w_k) ^ d0;   // 32 chips from chip k (shift uses k & 31)
+                    // rotate left by A mod 32 (alignbit rotates right by its low 5 bits); an unused slot
+                    // needs no masking: its LUT entries are all zero
+                    if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_amdgcn_alignbit(S, S, w_nrot);
+                    w_fr += w_dfr;
+                    const uint32_t adv = w_dint + (uint32_t) (w_fr >> GPSIQ_CODE_FRAC_BITS);
+                    w_fr &= kCodeFracMask;
+                    w_nrot -= adv;
+                    const uint32_t k2 = w_k + adv;                        // adv < 1023: one period wrap at most
+                    w_k = k2 - GPSIQ_CA_SEQ_LEN < k2 ? k2 - GPSIQ_CA_SEQ_LEN : k2;
                 }
-                // rotate left by A mod 32 (alignbit rotates right by its low 5 bits); an unused slot
-                // needs no masking: its LUT entries are all zero
-                if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_amdgcn_alignbit(S, S, w_nrot);
-                w_fr += w_dfr;
-                const uint32_t adv = w_dint + (uint32_t) (w_fr >> GPSIQ_CODE_FRAC_BITS);
-                w_fr &= kCodeFracMask;
-                w_nrot -= adv;
-                const uint32_t k2 = w_k + adv;                        // adv < 1023: one period wrap at most
-                w_k = k2 - GPSIQ_CA_SEQ_LEN < k2 ? k2 - GPSIQ_CA_SEQ_LEN : k2;
-                const int32_t e = w_e1 - (int32_t) adv;               // adv < 20460: one bit edge at most
-                const int32_t m = e >> 31;
-                w_e1 = e + (m & (int32_t) (20 * GPSIQ_CA_SEQ_LEN));
-                w_nrev <<= (uint32_t) m & 1u;
+                w_e1 -= (int32_t) (nrot0 - w_nrot);                       // chips advanced in this group
+            } else {
+#pragma unroll
+                for (int i = i0; i < i0 + kGrp; ++i) {
+                    const uint32_t lo = ext[wc][w_k >> 5], hi = ext[wc][(w_k >> 5) + 1];
+                    uint32_t S = __builtin_amdgcn_alignbit(hi, lo, w_k);
+                    S ^= (uint32_t) ((int32_t) w_nrev >> 31);
+                    // the window holds the start of the next nav bit when fewer than 32 chips of the
+                    // current one are left
+                    const bool edge = (uint32_t) w_e1 < 31u;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(edge) != 0, 0)) {
+                        if (edge && ((w_nrev ^ (w_nrev << 1)) >> 31)) S ^= 0xfffffffeu << w_e1;
+                    }
+                    if (w_store) w_dst[i * (kGroups * NCH)] = __builtin_amdgcn_alignbit(S, S, w_nrot);
+                    w_fr += w_dfr;
+                    const uint32_t adv = w_dint + (uint32_t) (w_fr >> GPSIQ_CODE_FRAC_BITS);
+                    w_fr &= kCodeFracMask;
+                    w_nrot -= adv;
+                    const uint32_t k2 = w_k + adv;
+                    w_k = k2 - GPSIQ_CA_SEQ_LEN < k2 ? k2 - GPSIQ_CA_SEQ_LEN : k2;
+                    const int32_t e = w_e1 - (int32_t) adv;               // adv < 20460: one bit edge at most
+                    const int32_t m = e >> 31;
+                    w_e1 = e + (m & (int32_t) (20 * GPSIQ_CA_SEQ_LEN));
+                    w_nrev <<= (uint32_t) m & 1u;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
