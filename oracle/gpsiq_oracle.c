@@ -357,3 +357,171 @@ int oracle_chunk_plan(int sink_kind, size_t nelem, int nblocks, size_t *chunk_le
     }
     return n;
 }
+
+/* ------------------------------------------------------------------------- */
+/* The float loop in closed form.  gps.c:2789-2792 and gps.c:2821-2826 advance their phases
+ * with  x += c  in double precision.  While x stays inside one binade [2^(E-1), 2^E) it is
+ * a multiple of that binade's ulp u, and x + c rounds to x + S with one constant
+ * S = rnd(c/u)*u (ties go to even, and from the second addition inside the binade on the
+ * parity is settled, so the tie case is constant too).  The trajectory is therefore
+ * piecewise linear: a handful of pieces per carrier cycle / per code period, and the
+ * state of sample n inside a piece is  (m0 + (n-n0)*dm) * 2^q  in exact integers.
+ * walk() builds the pieces: real double additions at the piece edges (binade crossings,
+ * the  -= 1023.0  and  -/+= 1.0  wraps: these ARE the reference's operations), an integer
+ * jump over the steady run in between.  oracle_block_float_closed() then evaluates every
+ * sample by piece lookup, with no per-sample recurrence; it must equal oracle_block_float
+ * (and the reference) bit for bit, carried carr_phase included. */
+typedef struct { long n0, len; int64_t m0, dm; int q; int wrapped; } fseg_t;
+typedef struct { fseg_t *s; size_t n, cap; } fsegs_t;
+
+static int seg_push(fsegs_t *v, long n0, long len, int64_t m0, int64_t dm, int q, int wrapped)
+{
+    if (v->n == v->cap) {
+        size_t nc = v->cap ? 2 * v->cap : 1024;
+        fseg_t *p = realloc(v->s, nc * sizeof *p);
+        if (!p) return -1;
+        v->s = p; v->cap = nc;
+    }
+    v->s[v->n++] = (fseg_t) {n0, len, m0, dm, q, wrapped};
+    return 0;
+}
+
+/* x >= 0  ->  x = m * 2^q, m < 2^53 (m >= 2^52 unless x == 0) */
+static void split(double x, int64_t *m, int *q)
+{
+    int e;
+    double f = frexp(x, &e);
+    *m = (int64_t) ldexp(f, 53);
+    *q = x == 0.0 ? 0 : e - 53;
+}
+
+/* kind 0: code phase  (y = x + c; if (y >= 1023) y -= 1023, gps.c:2789-2792)
+ * kind 1: carrier     (y = x + c; if (y >= 1) y -= 1; else if (y < 0) y += 1, gps.c:2821-2826) */
+static double fstep(double x, double c, int kind, int *wrapped)
+{
+    double y = x + c;
+    *wrapped = 0;
+    if (kind == 0) {
+        if (y >= (double) GPSIQ_CA_SEQ_LEN) { y -= (double) GPSIQ_CA_SEQ_LEN; *wrapped = 1; }
+    } else {
+        if (y >= 1.0) { y -= 1.0; *wrapped = 1; }
+        else if (y < 0.0) { y += 1.0; *wrapped = 1; }
+    }
+    return y;
+}
+
+static int same_binade(double a, double b)
+{
+    int ea, eb;
+    if (a <= 0.0 || b <= 0.0) return 0;
+    frexp(a, &ea); frexp(b, &eb);
+    return ea == eb;
+}
+
+/* states s_0 .. s_nsamp (s_n is what sample n uses; s_nsamp is what the loop leaves behind) */
+static int walk(double x, double c, int kind, long nsamp, fsegs_t *v, double *x_end)
+{
+    long n = 0;
+    int w0 = 0;                                   /* was s_n produced by a wrap */
+    const double top = kind == 0 ? (double) GPSIQ_CA_SEQ_LEN : 1.0;
+    while (n <= nsamp) {
+        int wy, wz, ww;
+        double y = fstep(x, c, kind, &wy), z = fstep(y, c, kind, &wz), w = fstep(z, c, kind, &ww);
+        if (!wy && !wz && !ww && same_binade(y, z) && same_binade(z, w) && n + 2 <= nsamp) {
+            /* steady from z on: s_{n+2+j} = z + j*S while the value stays inside z's binade and short of the wrap */
+            int64_t mz, mw; int qz, qw;
+            split(z, &mz, &qz); split(w, &mw, &qw);
+            const int64_t dm = mw - mz;            /* same exponent: same binade */
+            long J;
+            if (dm == 0) J = nsamp;                /* the addend is below half an ulp: the phase stands still */
+            else if (dm > 0) {
+                int64_t lim = (int64_t) 1 << 53;    /* next binade */
+                if (ldexp((double) lim, qz) > top) lim = (int64_t) ldexp(top, -qz);   /* the wrap comes first */
+                J = (long) ((lim - 1 - mz) / dm);
+            } else J = (long) ((mz - ((int64_t) 1 << 52)) / -dm);
+            if (n + 2 + J > nsamp) J = nsamp - (n + 2);
+            int64_t mx, my; int qx, qy;
+            split(x, &mx, &qx); split(y, &my, &qy);
+            if (seg_push(v, n, 1, mx, 0, qx, w0) || seg_push(v, n + 1, 1, my, 0, qy, 0) ||
+                seg_push(v, n + 2, J + 1, mz, dm, qz, 0)) return -1;
+            x = ldexp((double) (mz + (int64_t) J * dm), qz);
+            n += 2 + J;
+            w0 = 0;
+            if (n == nsamp) { *x_end = x; return 0; }
+            /* s_n is the last value of the run and is already covered: continue from its successor */
+            x = fstep(x, c, kind, &w0);
+            n++;
+            continue;
+        }
+        int64_t mx; int qx;
+        split(x, &mx, &qx);
+        if (seg_push(v, n, 1, mx, 0, qx, w0)) return -1;
+        if (n == nsamp) { *x_end = x; return 0; }
+        x = y; w0 = wy; n++;
+    }
+    return 0;
+}
+
+/* floor(m * 2^(q + up)) for m >= 0 */
+static int64_t seg_floor(int64_t m, int q, int up)
+{
+    int sh = -(q + up);
+    if (sh <= 0) return m << -sh;
+    return sh >= 63 ? 0 : m >> sh;
+}
+
+int oracle_block_float_closed(const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
+                              int sample_size, void *dst, double *carr_phase_out)
+{
+    if (!ch || !dst || nchan < 0 || nchan > GPSIQ_MAX_CHAN || nsamp < 0)
+        return GPSIQ_E_ARG;
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16)
+        return GPSIQ_E_ARG;
+    const double delt = 1.0 / fs;                                    /* gps.c:2298 */
+    int *acc = calloc(2 * (size_t) (nsamp ? nsamp : 1), sizeof *acc);
+    short *iq = malloc(sizeof(short) * 2 * (size_t) (nsamp ? nsamp : 1));
+    fsegs_t code = {0, 0, 0}, carr = {0, 0, 0};
+    int rc = GPSIQ_OK;
+    if (!acc || !iq) { rc = GPSIQ_E_NOMEM; goto out; }
+    for (int c = 0; c < nchan; c++) {
+        if (carr_phase_out) carr_phase_out[c] = ch[c].carr_phase;
+        if (ch[c].prn <= 0) continue;                                 /* gps.c:2772 */
+        uint8_t ca[GPSIQ_CA_SEQ_LEN];
+        int tc[512], ts[512];
+        if (oracle_codegen(ch[c].prn, ca) != GPSIQ_OK) { rc = GPSIQ_E_ARG; goto out; }
+        gain_lut(ch[c].gain, tc, ts);        /* (int)(+-table*gain) = +-(int)(table*gain): truncation is odd */
+        code.n = carr.n = 0;
+        double code_end, carr_end;
+        if (walk(ch[c].code_phase, ch[c].f_code * delt, 0, nsamp, &code, &code_end) ||
+            walk(ch[c].carr_phase, ch[c].f_carr * delt, 1, nsamp, &carr, &carr_end)) { rc = GPSIQ_E_NOMEM; goto out; }
+        if (carr_phase_out) carr_phase_out[c] = carr_end;
+        int iword = ch[c].iword, ibit = ch[c].ibit, icode = ch[c].icode;
+        int data = (int) ((ch[c].dwrd[iword] >> (29 - ibit)) & 1u);   /* gps.c:2059 */
+        size_t ik = 0, ic = 0;
+        for (long n = 0; n < nsamp; n++) {
+            while (n >= code.s[ik].n0 + code.s[ik].len) ik++;
+            while (n >= carr.s[ic].n0 + carr.s[ic].len) ic++;
+            const fseg_t *sk = &code.s[ik], *sc = &carr.s[ic];
+            if (sk->wrapped && n == sk->n0) {                         /* gps.c:2791-2812, done by the step that produced s_n */
+                if (++icode >= 20) {
+                    icode = 0;
+                    if (++ibit >= 30) {
+                        ibit = 0;
+                        if (++iword >= GPSIQ_N_DWRD) { rc = GPSIQ_E_RANGE; goto out; }
+                    }
+                    data = (int) ((ch[c].dwrd[iword] >> (29 - ibit)) & 1u);
+                }
+            }
+            const int chip = (int) seg_floor(sk->m0 + (int64_t) (n - sk->n0) * sk->dm, sk->q, 0);   /* gps.c:2817 */
+            const int k = (int) seg_floor(sc->m0 + (int64_t) (n - sc->n0) * sc->dm, sc->q, 9);      /* gps.c:2775 */
+            const int pos = ca[chip] == (unsigned) data;              /* dataBit*codeCA == +1 */
+            acc[2 * n] += pos ? tc[k] : -tc[k];
+            acc[2 * n + 1] += pos ? ts[k] : -ts[k];
+        }
+    }
+    for (long k = 0; k < 2 * (long) nsamp; k++) iq[k] = (short) acc[k];   /* gps.c:2834-2835 */
+    pack_elems(iq, 2 * (size_t) nsamp, sample_size, dst);
+out:
+    free(acc); free(iq); free(code.s); free(carr.s);
+    return rc;
+}

@@ -33,6 +33,13 @@ int  oracle_codegen(int prn, uint8_t ca[GPSIQ_CA_SEQ_LEN]);
 int  oracle_block_float(const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
                         int sample_size, void *dst, double *carr_phase_out);
 
+/* The same loop with no per-sample recurrence: both double accumulators are piecewise linear in
+ * exact integers (one piece per binade the phase passes through), built by real double additions
+ * at the piece edges and integer jumps in between; every sample is then evaluated by piece
+ * lookup.  Must equal oracle_block_float / the reference bit for bit, carr_phase_out included. */
+int  oracle_block_float_closed(const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
+                               int sample_size, void *dst, double *carr_phase_out);
+
 /* include/gpsiq.h quantisation rules */
 int  oracle_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
                      gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out);

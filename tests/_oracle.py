@@ -34,6 +34,7 @@ class Oracle:
         L.oracle_cos512.restype = C.c_int
         L.oracle_codegen.argtypes = [C.c_int, C.c_void_p]
         L.oracle_block_float.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_block_float_closed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_quantize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_block_fixed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_block_fixed_seq.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -57,6 +58,16 @@ class Oracle:
         out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
         carr = np.zeros(len(ch), dtype=np.float64)
         rc = self.lib.oracle_block_float(_ptr(ch), len(ch), nsamp, fs, sample_size, _ptr(out), _ptr(carr))
+        if rc:
+            raise ValueError(rc)
+        return out, carr
+
+    def block_float_closed(self, ch, nsamp, fs, sample_size):
+        """The float loop evaluated piecewise in closed form (no per-sample recurrence)."""
+        ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+        out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
+        carr = np.zeros(len(ch), dtype=np.float64)
+        rc = self.lib.oracle_block_float_closed(_ptr(ch), len(ch), nsamp, fs, sample_size, _ptr(out), _ptr(carr))
         if rc:
             raise ValueError(rc)
         return out, carr

@@ -40,6 +40,52 @@ def test_float_restatement_is_bit_exact(oracle, ref, fs, nchan, ss):
         assert (fc == carr[b]).all()
 
 
+def _closed_run(oracle, d, fs, ss):
+    """oracle_block_float_closed over consecutive blocks, carrying carr_phase the way the loop does
+    (re-seeded from the descriptor when a slot's PRN changes, gps.c:2208-2214)."""
+    ns = fs // 10
+    out, carr, prev = [], None, None
+    for b in range(len(d)):
+        db = d[b].copy()
+        if b:
+            keep = (prev == db["prn"]) & (db["prn"] > 0)
+            db["carr_phase"] = np.where(keep, carr, db["carr_phase"])
+        o, carr = oracle.block_float_closed(db, ns, fs, ss)
+        out.append(o)
+        prev = db["prn"].copy()
+    return np.concatenate(out), carr
+
+
+@pytest.mark.parametrize("fs,nchan,ss,nb,seed", [(2600000, 16, SC16, 60, 11), (3000000, 12, SC08, 20, 12),
+                                                 (10000000, 16, SC16, 8, 13), (25000000, 16, SC16, 4, 14),
+                                                 (1500000, 7, SC08, 10, 15)])
+def test_float_loop_in_closed_form_is_the_reference(oracle, ref, fs, nchan, ss, nb, seed):
+    """The reference's double accumulators are piecewise linear in exact integers (one piece per
+    binade); evaluated piece by piece, with no per-sample recurrence, they give the reference's
+    output on every element and its carried carr_phase after every block (whole-run T2 = 0).
+    tests/t2_report.py runs the same check over 299 / 100 blocks per rate."""
+    d = synth_blocks(nb, nchan, seed=seed)
+    want, _, carr = ref.run_blocks(d, fs, ss, SINK_IQFILE)
+    got, carr_end = _closed_run(oracle, d, fs, ss)
+    assert np.array_equal(got, want)
+    assert np.array_equal(carr_end, carr[-1])
+
+
+def test_float_closed_form_edge_cases(oracle):
+    """Zero and negative Doppler, a phase that starts at 0, a step below half an ulp, one chip per
+    sample, very short blocks: closed form == recurrence (both in the oracle; the recurrence is
+    pinned to the reference above)."""
+    d = synth_blocks(1, 8, seed=5)[0]
+    d["f_carr"] = [0.0, -4999.7, 4999.7, 1e-9, -1e-9, 0.25, -1234.5, 3e-14]
+    d["carr_phase"] = [0.0, 0.0, 0.999999999999, 0.5, 0.5, 0.0, 1e-300, 0.75]
+    d["code_phase"][:3] = [0.0, 1022.9999999999, 511.99999999999994]
+    for fs, ns in ((2.6e6, 70001), (1.023e6, 30000), (25e6, 120000), (2.6e6, 1), (2.6e6, 2), (2.6e6, 3)):
+        a, ca = oracle.block_float(d, ns, fs, SC16)
+        b, cb = oracle.block_float_closed(d, ns, fs, SC16)
+        assert np.array_equal(a, b), (fs, ns)
+        assert np.array_equal(ca, cb), (fs, ns)
+
+
 def _explain_mismatch(d, fs, n, drift_steps):
     """True if at sample n some channel's exact (rational) phase lies within the float
     path's own accumulated-rounding bound of a chip or LUT boundary."""
