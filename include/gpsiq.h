@@ -108,6 +108,26 @@ typedef struct gpsiq_qchan {
 
 typedef struct gpsiq_ctx gpsiq_ctx_t;
 
+/* NCO models.  GPSIQ_NCO_FIXED (default): the closed form on integers defined above; every block is
+ * an independent function of its descriptor, so the time axis shards freely.  GPSIQ_NCO_REFERENCE: the
+ * reference's own double accumulators (gps.c:2789-2792, 2821-2826), reproduced exactly: a whole run
+ * equals the reference element for element and carr_phase is handed out as the reference's accumulator
+ * leaves it.  Costs a serial walk of the carrier per channel on the host (a dozen integer steps per
+ * carrier cycle, see csrc/gpsiq_exact.cpp); the device runs the same kernels plus a fix-up of the few
+ * samples per 10^7 where the two models differ. */
+#define GPSIQ_NCO_FIXED      0
+#define GPSIQ_NCO_REFERENCE  1
+
+/* One sample of one channel where the reference's double path takes another LUT entry or sign than the
+ * fixed-point closed form: the device recomputes that sample with (lut, neg) for this channel. */
+typedef struct gpsiq_patch {
+    uint32_t block;   /* index into the resident descriptor timeline */
+    uint32_t sample;  /* 0 .. nsamp-1 */
+    uint8_t  slot;    /* channel, in device order: the block's active channels counted from 0 */
+    uint8_t  neg;     /* 1: dataBit*codeCA == -1 (gps.c:2781-2782) */
+    uint16_t lut;     /* iTable, gps.c:2775 */
+} gpsiq_patch_t;
+
 /* ---- library / tables (no device needed) -------------------------------- */
 const char *gpsiq_version(void);
 /* last error text of the calling thread ("" if none) */
@@ -137,6 +157,16 @@ int gpsiq_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
 int gpsiq_quantize_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp,
                          gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out);
 
+/* GPSIQ_NCO_REFERENCE form of gpsiq_quantize_batch.  Block 0 starts from ch[0][i].carr_phase (the
+ * double the previous call handed out, or allocateChannel's value); later blocks continue the
+ * reference's accumulator and re-seed from their own carr_phase when the slot's PRN changes.  out is
+ * [nblocks][nchan]; patches receives up to max_patches entries sorted by (block, sample, slot),
+ * *npatches their number (GPSIQ_E_RANGE if there is not enough room: call again with *npatches);
+ * carr_phase_out[nchan] (may be NULL) the accumulator after the last block.  Host only. */
+int gpsiq_reference_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp,
+                          gpsiq_qchan_t *out, gpsiq_patch_t *patches, int max_patches, int *npatches,
+                          double *carr_phase_out);
+
 /* Contiguous balanced split of a block timeline over `world` devices/processes:
  * rank r owns [*begin, *end); the first nblocks % world ranks own one block more. */
 int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end);
@@ -146,6 +176,9 @@ int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end);
  * there is no CPU fallback in this library. */
 int  gpsiq_create(gpsiq_ctx_t **ctx, int device);
 void gpsiq_destroy(gpsiq_ctx_t *ctx);
+
+/* Select the NCO model of gpsiq_generate_block / gpsiq_generate_batch (default GPSIQ_NCO_FIXED). */
+int  gpsiq_set_nco_mode(gpsiq_ctx_t *ctx, int mode);
 
 /* Drop-in for one pass of gps.c:2767-2846: synthesise one block of nsamp complex
  * samples from the channel state at gps.c:2766 and write 2*nsamp IQ elements
@@ -187,6 +220,10 @@ void  gpsiq_host_free(void *p);
 /* ---- resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
 /* Copy nblocks*nchan quantised descriptors ([nblocks][nchan]) to the device. */
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
+/* Patches that go with the resident descriptors (gpsiq_reference_batch); every later gpsiq_launch
+ * applies those of the blocks it synthesises, on the same stream, after the kernel.  n = 0 clears
+ * them; gpsiq_set_descriptors clears them too. */
+int gpsiq_set_patches(gpsiq_ctx_t *ctx, const gpsiq_patch_t *patches, int n);
 /* Launch synthesis of blocks [block0, block0+nblocks) of the resident descriptors into
  * the DEVICE buffer dst; block b is written at dst + (b-block0)*block_stride_bytes
  * (block_stride_bytes >= 2*nsamp*sample_size, multiple of 4).  Asynchronous on

@@ -17,6 +17,9 @@ namespace gpsiq {
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
                           const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude);
+hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size, void *dst, size_t block_stride,
+                          int block0, int nblocks, const DeviceTables *tab, const gpsiq_patch_t *patches, int npatch,
+                          hipStream_t stream);
 }
 
 using namespace gpsiq;
@@ -25,18 +28,31 @@ struct gpsiq_ctx {
     int           device = -1;
     hipStream_t   stream = nullptr;
     DeviceTables *d_tab = nullptr;
-    // resident descriptors
-    gpsiq_qchan_t *d_desc = nullptr;
-    size_t         desc_cap = 0;      // in descriptors
+    hipStream_t   copy_stream[2] = {nullptr, nullptr};   // device-to-host copies of the batch calls
+    // resident descriptors, double-buffered: a new set is staged and uploaded into the buffer the
+    // last launch is NOT reading, so gpsiq_set_descriptors never waits for the device to go idle --
+    // only, if it is still in flight, for the launch from two sets ago that used the same buffer
+    struct DescBuf {
+        gpsiq_qchan_t *d = nullptr;  size_t cap = 0;      // device copy, in descriptors
+        gpsiq_qchan_t *h = nullptr;  size_t hcap = 0;     // page-locked staging of the compacted descriptors
+        hipEvent_t     last_use = nullptr;                // recorded after every launch that reads d
+        bool           in_use = false;
+    } buf[2];
+    int            cur = 0;             // buf[cur] holds the resident set
+    gpsiq_qchan_t *d_desc = nullptr;    // == buf[cur].d
     int            nblocks = 0, nchan = 0;
     uint64_t       max_code_step = 0;
     int            max_active = 0;      // most active channels in any resident block
     long           max_amplitude = 0;   // largest sum over a block's channels of (int)(250*|gain|): bound on |I|, |Q|
-    gpsiq_qchan_t *h_desc = nullptr;   // page-locked staging of the compacted descriptors
-    size_t         h_desc_cap = 0;
+    // patches that go with the resident descriptors (GPSIQ_NCO_REFERENCE)
+    gpsiq_patch_t *d_patch = nullptr;
+    size_t         patch_cap = 0;
+    int            npatch = 0;
+    int            nco_mode = GPSIQ_NCO_FIXED;
     // staging for the synchronous entry points
     void          *d_out = nullptr;
     size_t         out_cap = 0;
+    hipEvent_t     chunk_done[2] = {nullptr, nullptr};
     // carrier carry per slot (gpsiq_generate_block)
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     double   handed[GPSIQ_MAX_CHAN] = {};
@@ -56,16 +72,6 @@ static double wall_ms()
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double) ts.tv_sec * 1e3 + (double) ts.tv_nsec * 1e-6;
-}
-
-static int ensure_desc(gpsiq_ctx *c, size_t n)
-{
-    if (n <= c->desc_cap) return GPSIQ_OK;
-    if (c->d_desc) HIP_TRY(hipFree(c->d_desc));
-    c->d_desc = nullptr; c->desc_cap = 0;
-    HIP_TRY(hipMalloc((void **) &c->d_desc, n * sizeof(gpsiq_qchan_t)));
-    c->desc_cap = n;
-    return GPSIQ_OK;
 }
 
 static int ensure_out(gpsiq_ctx *c, size_t bytes)
@@ -92,9 +98,10 @@ static int check_launch(const gpsiq_ctx *c, int block0, int nblocks, int nsamp, 
     if (!c) return fail(GPSIQ_E_ARG, "null context");
     if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
     if (nsamp < 0 || nblocks < 0 || block0 < 0) return fail(GPSIQ_E_ARG, "negative size");
-    if (!c->d_desc || block0 + nblocks > c->nblocks)
-        return fail(GPSIQ_E_STATE, "blocks [%d,%d) not resident (have %d)", block0, block0 + nblocks, c->nblocks);
+    if (!c->d_desc || nblocks > c->nblocks || block0 > c->nblocks - nblocks)        // no int overflow in the sum
+        return fail(GPSIQ_E_STATE, "blocks [%d,+%d) not resident (have %d)", block0, nblocks, c->nblocks);
     if (!dst && nblocks && nsamp) return fail(GPSIQ_E_ARG, "null destination");
+    if ((uintptr_t) dst & 3) return fail(GPSIQ_E_ARG, "destination %p not 4-byte aligned", dst);
     if (stride < (size_t) 2 * (size_t) nsamp * (size_t) sample_size || (stride & 3))
         return fail(GPSIQ_E_ARG, "block stride %zu too small or not a multiple of 4", stride);
     if (variant < 0 || variant >= kNumVariants) return fail(GPSIQ_E_ARG, "unknown variant %d", variant);
@@ -124,6 +131,11 @@ int gpsiq_create(gpsiq_ctx_t **out, int device)
     if (!h) { delete c; return fail(GPSIQ_E_NOMEM, "out of memory"); }
     build_device_tables(h);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->buf[i].last_use, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc((void **) &c->d_tab, sizeof(DeviceTables));
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, h, sizeof(DeviceTables), hipMemcpyHostToDevice);
     delete h;
@@ -139,11 +151,17 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
 {
     if (!c) return;
     if (c->device >= 0) (void) hipSetDevice(c->device);
-    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    (void) hipDeviceSynchronize();
     if (c->d_tab) (void) hipFree(c->d_tab);
-    if (c->d_desc) (void) hipFree(c->d_desc);
     if (c->d_out) (void) hipFree(c->d_out);
-    if (c->h_desc) (void) hipHostFree(c->h_desc);
+    if (c->d_patch) (void) hipFree(c->d_patch);
+    for (int i = 0; i < 2; ++i) {
+        if (c->buf[i].d) (void) hipFree(c->buf[i].d);
+        if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
+        if (c->buf[i].last_use) (void) hipEventDestroy(c->buf[i].last_use);
+        if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
+        if (c->copy_stream[i]) (void) hipStreamDestroy(c->copy_stream[i]);
+    }
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -169,19 +187,22 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t) nblocks * (size_t) nchan;
-    int rc = ensure_desc(c, n ? n : 1);
-    if (rc) return rc;
-    if (n > c->h_desc_cap) {
-        if (c->h_desc) HIP_TRY(hipHostFree(c->h_desc));
-        c->h_desc = nullptr; c->h_desc_cap = 0;
-        HIP_TRY(hipHostMalloc((void **) &c->h_desc, n * sizeof(gpsiq_qchan_t), hipHostMallocDefault));
-        c->h_desc_cap = n;
+    gpsiq_ctx::DescBuf &nb = c->buf[c->cur ^ 1];        // the set not being read by the latest launches
+    // the launch from two sets ago may still be reading this buffer (and its staging may still be
+    // the source of an upload): wait for exactly that, not for the whole device
+    if (nb.in_use) { HIP_TRY(hipEventSynchronize(nb.last_use)); nb.in_use = false; }
+    if (n > nb.hcap) {
+        if (nb.h) HIP_TRY(hipHostFree(nb.h));
+        nb.h = nullptr; nb.hcap = 0;
+        HIP_TRY(hipHostMalloc((void **) &nb.h, n * sizeof(gpsiq_qchan_t), hipHostMallocDefault));
+        nb.hcap = n;
     }
     // Device copy is compacted per block: active channels first, unused slots (zeroed)
     // after them.  The sum over channels is commutative modulo 2^16, so slot order is free.
-    // Validation + compaction run on host threads straight into the page-locked staging buffer.
+    // Validation + compaction run on host threads straight into the page-locked staging buffer,
+    // BEFORE anything resident is touched: a rejected set leaves the previous one in place.
     struct PJob { const gpsiq_qchan_t *q; gpsiq_qchan_t *out; int nchan; uint64_t mx; int max_active; long max_amp; int rc; size_t bad; };
-    PJob pj = {q, c->h_desc, nchan, 0, 0, 0, GPSIQ_OK, 0};
+    PJob pj = {q, nb.h, nchan, 0, 0, 0, GPSIQ_OK, 0};
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
     parallel_for(nblocks, 0, 128, [](void *p, int b0, int b1) {
@@ -214,18 +235,80 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
         for (long cur = j.max_amp; max_amp > cur && !__sync_bool_compare_and_swap(&j.max_amp, cur, max_amp); cur = j.max_amp) {}
     }, &pj);
     if (pj.rc != GPSIQ_OK) return fail(pj.rc, "descriptor %zu outside the NCO format (prn %u)", pj.bad, q[pj.bad].prn);
-    const uint64_t mx = pj.mx;
-    const int max_active = pj.max_active;
+    const size_t need = n ? n : 1;
+    if (need > nb.cap) {
+        if (nb.d) HIP_TRY(hipFree(nb.d));
+        nb.d = nullptr; nb.cap = 0;
+        HIP_TRY(hipMalloc((void **) &nb.d, need * sizeof(gpsiq_qchan_t)));
+        nb.cap = need;
+    }
     if (n) {
-        // make sure no launch still reads the previous descriptors
-        HIP_TRY(hipDeviceSynchronize());
         const double t1 = trace ? wall_ms() : 0.0;
-        HIP_TRY(hipMemcpy(c->d_desc, c->h_desc, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice));
+        // on the context's own (non-blocking) stream: overlaps whatever the caller's streams are doing
+        hipError_t e = hipMemcpyAsync(nb.d, nb.h, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "descriptor upload: %s", hipGetErrorString(e));
         if (trace)
             std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %.2f ms\n",
                          nblocks, t1 - t0, wall_ms() - t1);
     }
-    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = mx; c->max_active = max_active; c->max_amplitude = pj.max_amp;
+    c->cur ^= 1;
+    c->d_desc = nb.d;
+    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = pj.mx; c->max_active = pj.max_active; c->max_amplitude = pj.max_amp;
+    c->npatch = 0;
+    return GPSIQ_OK;
+}
+
+int gpsiq_set_patches(gpsiq_ctx_t *c, const gpsiq_patch_t *patches, int n)
+{
+    if (!c || (n > 0 && !patches) || n < 0) return fail(GPSIQ_E_ARG, "bad patch list");
+    HIP_TRY(hipSetDevice(c->device));
+    c->npatch = 0;
+    if (n == 0) return GPSIQ_OK;
+    for (int i = 0; i < n; ++i) {
+        const gpsiq_patch_t &p = patches[i];
+        if ((int64_t) p.block >= c->nblocks || p.slot >= c->nchan || p.lut > 511 || p.neg > 1)
+            return fail(GPSIQ_E_RANGE, "patch %d (block %u, slot %u, lut %u) outside the resident descriptors", i, p.block, p.slot, p.lut);
+        if (i && (patches[i - 1].block > p.block || (patches[i - 1].block == p.block && patches[i - 1].sample > p.sample)))
+            return fail(GPSIQ_E_ARG, "patches not sorted by (block, sample) at %d", i);
+    }
+    // the launches that may still read the previous list were issued on caller streams this context
+    // does not track beyond the descriptor events: wait for those
+    for (int i = 0; i < 2; ++i)
+        if (c->buf[i].in_use) HIP_TRY(hipEventSynchronize(c->buf[i].last_use));
+    if ((size_t) n > c->patch_cap) {
+        if (c->d_patch) HIP_TRY(hipFree(c->d_patch));
+        c->d_patch = nullptr; c->patch_cap = 0;
+        HIP_TRY(hipMalloc((void **) &c->d_patch, (size_t) n * sizeof(gpsiq_patch_t)));
+        c->patch_cap = (size_t) n;
+    }
+    HIP_TRY(hipMemcpy(c->d_patch, patches, (size_t) n * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice));
+    c->npatch = n;
+    return GPSIQ_OK;
+}
+
+int gpsiq_set_nco_mode(gpsiq_ctx_t *c, int mode)
+{
+    if (!c) return fail(GPSIQ_E_ARG, "null context");
+    if (mode != GPSIQ_NCO_FIXED && mode != GPSIQ_NCO_REFERENCE) return fail(GPSIQ_E_ARG, "unknown NCO mode %d", mode);
+    if (mode != c->nco_mode)
+        for (int i = 0; i < GPSIQ_MAX_CHAN; ++i) { c->carry_prn[i] = 0; c->carry[i] = 0; c->handed[i] = 0.0; }
+    c->nco_mode = mode;
+    return GPSIQ_OK;
+}
+
+// kernel + patches of blocks [block0, block0+nblocks) on stream s; marks the descriptor buffer as in use
+static int launch_on(gpsiq_ctx *c, int v, int block0, int nblocks, int nsamp, int sample_size, void *dst, size_t stride, hipStream_t s)
+{
+    hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, s,
+                                  c->max_active, c->max_amplitude);
+    if (e == hipSuccess && c->npatch)
+        e = launch_patches(c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, c->d_patch, c->npatch, s);
+    if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
+    if (nblocks > 0 && nsamp > 0) {
+        HIP_TRY(hipEventRecord(c->buf[c->cur].last_use, s));
+        c->buf[c->cur].in_use = true;
+    }
     return GPSIQ_OK;
 }
 
@@ -235,10 +318,7 @@ int gpsiq_launch(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int sample_
     int rc = check_launch(c, block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, variant);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t) hip_stream;
-    HIP_TRY(launch_variant(pick_variant(c, variant), c->d_desc, c->nchan, nsamp, sample_size, dst,
-                           block_stride_bytes, block0, nblocks, c->d_tab, s, c->max_active, c->max_amplitude));
-    return GPSIQ_OK;
+    return launch_on(c, pick_variant(c, variant), block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, (hipStream_t) hip_stream);
 }
 
 int gpsiq_synchronize(gpsiq_ctx_t *c, void *hip_stream)
@@ -259,23 +339,20 @@ int gpsiq_time_launches(gpsiq_ctx_t *c, int block0, int nblocks, int nsamp, int 
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t) hip_stream;
     const int v = pick_variant(c, variant);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) {
-        hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, block_stride_bytes,
-                                      block0, nblocks, c->d_tab, s, c->max_active, c->max_amplitude);
-        if (e != hipSuccess) {
-            (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-            return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
-        }
-    }
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    for (int i = 0; i < iters && e == hipSuccess && rc == GPSIQ_OK; ++i)
+        rc = launch_on(c, v, block0, nblocks, nsamp, sample_size, dst, block_stride_bytes, s);
+    if (e == hipSuccess && rc == GPSIQ_OK) e = hipEventRecord(e1, s);
+    if (e == hipSuccess && rc == GPSIQ_OK) e = hipEventSynchronize(e1);
+    if (e == hipSuccess && rc == GPSIQ_OK) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void) hipEventDestroy(e0);                  // on every path
+    if (e1) (void) hipEventDestroy(e1);
+    if (rc != GPSIQ_OK) return rc;
+    if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "timing: %s", hipGetErrorString(e));
     *ms_per_launch = ms / (float) iters;
     return GPSIQ_OK;
 }
@@ -298,46 +375,117 @@ const char *gpsiq_variant_name(int v)
 
 // ---- synchronous drop-in entry points ---------------------------------------
 
+// Blocks per piece of a host-destination batch: the kernel of piece k+1 runs while piece k crosses
+// PCIe (two copy streams, so consecutive copies queue back to back).  GPSIQ_D2H_CHUNK_BLOCKS overrides;
+// 0 = one kernel, then one copy (the round-1 behaviour, kept for A/B measurements).
+static int d2h_chunk_blocks(size_t stride)
+{
+    static const int forced = [] { const char *e = std::getenv("GPSIQ_D2H_CHUNK_BLOCKS"); return e ? std::atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    const size_t target = (size_t) 32 << 20;                 // ~32 MiB per piece: >= 0.5 ms on the link, a few hundred workgroups
+    const size_t n = (target + stride - 1) / stride;
+    return (int) (n < 8 ? 8 : n);
+}
+
 static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nblocks, int nchan,
-                                 int nsamp, int sample_size, void *dst, int dst_is_device)
+                                 int nsamp, int sample_size, void *dst, int dst_is_device,
+                                 const std::vector<gpsiq_patch_t> *patches = nullptr)
 {
     const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
     const size_t stride = (blk_bytes + 15) & ~(size_t) 15;
     int rc = gpsiq_set_descriptors(c, q, nblocks, nchan);
     if (rc) return rc;
+    if (patches && !patches->empty()) {
+        rc = gpsiq_set_patches(c, patches->data(), (int) patches->size());
+        if (rc) return rc;
+    }
     if (!nblocks || !nsamp) return GPSIQ_OK;
-    if (dst_is_device && stride == blk_bytes) {
+    if (dst_is_device && stride == blk_bytes && !((uintptr_t) dst & 3)) {
         rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, dst, stride, c->stream, kAuto);
         if (rc) return rc;
         return gpsiq_synchronize(c, c->stream);
     }
     rc = ensure_out(c, stride * (size_t) nblocks);
     if (rc) return rc;
-    rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, c->d_out, stride, c->stream, kAuto);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks,
-                             dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    const hipMemcpyKind kind = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const int chunk = d2h_chunk_blocks(stride);
+    if (dst_is_device || chunk <= 0 || nblocks <= chunk) {
+        rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, c->d_out, stride, c->stream, kAuto);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks, kind, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return GPSIQ_OK;
+    }
+    // pieces: kernel on c->stream, copy of piece k on copy_stream[k & 1] once its kernel has finished
+    int k = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += chunk, ++k) {
+        const int nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+        uint8_t *piece = static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
+        rc = gpsiq_launch(c, b0, nb, nsamp, sample_size, piece, stride, c->stream, kAuto);
+        if (rc) return rc;
+        hipStream_t cs = c->copy_stream[k & 1];
+        HIP_TRY(hipEventRecord(c->chunk_done[k & 1], c->stream));
+        HIP_TRY(hipStreamWaitEvent(cs, c->chunk_done[k & 1], 0));
+        HIP_TRY(hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, piece, stride, blk_bytes,
+                                 (size_t) nb, kind, cs));
+    }
+    HIP_TRY(hipStreamSynchronize(c->copy_stream[0]));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream[1]));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return GPSIQ_OK;
+}
+
+static int check_gen_args(const gpsiq_ctx *c, const void *ch, const void *dst, int nblocks, int nchan, int nsamp, double fs, int sample_size)
+{
+    if (!c || (!ch && nblocks) || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
+    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    return GPSIQ_OK;
+}
+
+// GPSIQ_NCO_REFERENCE form of both drop-in calls: the carrier is the caller's double, walked exactly
+static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
+                              int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
+{
+    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    const double t0 = trace ? wall_ms() : 0.0;
+    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+    std::vector<gpsiq_patch_t> patches;
+    double carr_end[GPSIQ_MAX_CHAN];
+    int last_prn[GPSIQ_MAX_CHAN];
+    int rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), &patches, carr_end, last_prn);
+    if (rc) return rc;
+    const double t1 = trace ? wall_ms() : 0.0;
+    rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device, &patches);
+    if (rc) return rc;
+    if (trace)
+        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks: carrier walk + candidates %.2f ms (%zu patches), device %.2f ms\n",
+                     nblocks, t1 - t0, patches.size(), wall_ms() - t1);
+    if (carr_phase_out)
+        for (int i = 0; i < nchan; ++i)
+            carr_phase_out[i] = last_prn[i] ? carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
     return GPSIQ_OK;
 }
 
 int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
                          int sample_size, void *dst, double *carr_phase_out)
 {
-    if (!c || !ch || !dst) return fail(GPSIQ_E_ARG, "null argument");
-    if (nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "nchan %d outside 1..%d", nchan, GPSIQ_MAX_CHAN);
-    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
-    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    if (!dst) return fail(GPSIQ_E_ARG, "null argument");
+    int rc = check_gen_args(c, ch, dst, 1, nchan, nsamp, fs, sample_size);
+    if (rc) return rc;
+    if (c->nco_mode == GPSIQ_NCO_REFERENCE)
+        return generate_reference(c, ch, 1, nchan, nsamp, fs, sample_size, dst, 0, carr_phase_out);
     std::vector<gpsiq_qchan_t> q((size_t) nchan);
     uint64_t next[GPSIQ_MAX_CHAN] = {};
     const double delt = 1.0 / fs;
     for (int i = 0; i < nchan; ++i) {
         // continue the exact phase only if the caller hands back what we handed out
         const bool cont = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
-        int rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[(size_t) i], &next[i]);
+        rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[(size_t) i], &next[i]);
         if (rc) return rc;
     }
-    int rc = run_to_host_or_device(c, q.data(), 1, nchan, nsamp, sample_size, dst, 0);
+    rc = run_to_host_or_device(c, q.data(), 1, nchan, nsamp, sample_size, dst, 0);
     if (rc) return rc;
     for (int i = 0; i < nchan; ++i) {
         c->carry_prn[i] = ch[i].prn > 0 ? ch[i].prn : 0;
@@ -351,10 +499,8 @@ int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int 
 int gpsiq_generate_quantized(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp,
                              int sample_size, void *dst, int dst_is_device)
 {
-    if (!c || (!q && nblocks) || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
-    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
-    if (nsamp < 0) return fail(GPSIQ_E_ARG, "bad nsamp %d", nsamp);
-    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    int rc = check_gen_args(c, q, dst, nblocks, nchan, nsamp, 1.0, sample_size);
+    if (rc) return rc;
     if (nblocks == 0) return GPSIQ_OK;
     return run_to_host_or_device(c, q, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
 }
@@ -362,11 +508,11 @@ int gpsiq_generate_quantized(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks
 int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp,
                          double fs, int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
 {
-    if (!c || (!ch && nblocks) || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
-    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
-    if (nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g", nsamp, fs);
-    if (sample_size != GPSIQ_SC08 && sample_size != GPSIQ_SC16) return fail(GPSIQ_E_ARG, "bad sample size %d", sample_size);
+    int rc = check_gen_args(c, ch, dst, nblocks, nchan, nsamp, fs, sample_size);
+    if (rc) return rc;
     if (nblocks == 0) return GPSIQ_OK;                    // an empty batch leaves the carried phases alone
+    if (c->nco_mode == GPSIQ_NCO_REFERENCE)
+        return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out);
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
@@ -379,18 +525,17 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     int qrc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
     if (qrc) return qrc;
     const double t2 = trace ? wall_ms() : 0.0;
-    int rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+    rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
     if (rc) return rc;
     if (trace)
         std::fprintf(stderr, "[gpsiq trace] batch %d blocks: quantise + carrier prefix %.2f ms, upload+kernel%s %.2f ms\n",
                      nblocks, t2 - t0, dst_is_device ? "" : "+D2H", wall_ms() - t2);
-    if (nblocks > 0)
-        for (int i = 0; i < nchan; ++i) {
-            c->carry_prn[i] = prev_prn[i];
-            c->carry[i] = carry[i];
-            c->handed[i] = prev_prn[i] ? carr_phase_to_double(carry[i]) : 0.0;
-            if (carr_phase_out) carr_phase_out[i] = c->handed[i];
-        }
+    for (int i = 0; i < nchan; ++i) {
+        c->carry_prn[i] = prev_prn[i];
+        c->carry[i] = carry[i];
+        c->handed[i] = prev_prn[i] ? carr_phase_to_double(carry[i]) : 0.0;
+        if (carr_phase_out) carr_phase_out[i] = c->handed[i];
+    }
     return GPSIQ_OK;
 }
 

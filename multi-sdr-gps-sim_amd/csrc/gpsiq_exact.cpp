@@ -1,0 +1,314 @@
+// gpsiq_exact.cpp — GPSIQ_NCO_REFERENCE: the reference's double-precision NCOs, reproduced exactly.
+//
+// The reference advances code_phase and carr_phase by sequential double additions
+// (gps.c:2789-2792, gps.c:2821-2826).  The library's default model is the closed form on integers of
+// include/gpsiq.h; given the same block-start state the two differ in a few samples per 10^7, where a
+// phase sits within the double path's accumulated rounding drift of a chip or LUT boundary.  This file
+// finds exactly those samples on the host and describes them as patches for the device, and it
+// carries carr_phase from block to block as the reference's own accumulator would leave it, so that a
+// whole run equals the reference element for element.
+//
+// How, without stepping 260 000 additions per channel and block:
+//   * x += c in double is piecewise linear.  While x stays inside one binade it is a multiple of the
+//     binade's ulp u and the addition adds the constant S = rnd(c/u)*u (ties to even: constant from the
+//     second addition inside the binade on, when the parity has settled).  Nco::advance() does the
+//     reference's own operation (a real double addition, then the wrap rule) at binade crossings and
+//     wraps and jumps over the steady run in between with one integer division: about a dozen pieces
+//     per carrier cycle or code period.
+//   * Only samples whose fixed-point phase lies within the drift bound of a boundary can differ:
+//     |double path - real arithmetic| <= n * 2^-54 cycle (carrier, values < 1) or n * 2^-44 chip (code,
+//     values < 1024), the fixed-point path is within (n/2 + 1) units of its last place of real arithmetic.
+//     Those candidates are the n with (a + n*b) mod 2^k inside a narrow window: found with a
+//     Euclid-style descent in O(log) per hit (first_in_window), typically none or one per channel and block.
+//   * At every candidate both paths are evaluated exactly; where (LUT index, sign) differ, a patch
+//     {block, sample, slot, index, sign} is emitted.  The device runs the fixed-point kernels unchanged
+//     and then recomputes the patched samples (apply_patches in gpsiq_kernels.hip).
+// The carrier chain is serial per channel (block k starts where the double accumulator left block k-1);
+// channels run on host threads, and everything but the carrier walk is parallel over blocks.
+#include "gpsiq_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace gpsiq {
+
+namespace {
+
+typedef unsigned __int128 u128;
+
+inline uint64_t bits_of(double x) { uint64_t b; std::memcpy(&b, &x, 8); return b; }
+inline double from_bits(uint64_t b) { double x; std::memcpy(&x, &b, 8); return x; }
+constexpr uint64_t kMant = (UINT64_C(1) << 52) - 1;
+
+// One double accumulator of the reference loop.  kind 0: code phase (wrap at 1023 chips,
+// gps.c:2789-2792); kind 1: carrier phase (wrap into [0,1), gps.c:2821-2826).
+struct Nco {
+    double x, c;      // state used by sample n; the addend
+    long   n, wraps;  // wraps: number of wraps on the way to sample n (code: code periods completed)
+    int    kind;
+
+    inline double step(double v, int *wrapped) const
+    {
+        double y = v + c;
+        *wrapped = 0;
+        if (kind == 0) {
+            if (y >= (double) GPSIQ_CA_SEQ_LEN) { y -= (double) GPSIQ_CA_SEQ_LEN; *wrapped = 1; }
+        } else {
+            if (y >= 1.0) { y -= 1.0; *wrapped = 1; }
+            else if (y < 0.0) { y += 1.0; *wrapped = 1; }
+        }
+        return y;
+    }
+
+    // Move to sample `target` (>= n).
+    void advance(long target)
+    {
+        while (n < target) {
+            int wy;
+            const double y = step(x, &wy);
+            const uint64_t bx = bits_of(x), by = bits_of(y);
+            if (wy || (bx >> 52) != (by >> 52) || (bx >> 52) == 0) {     // a wrap, a binade crossing, zero/subnormal: one step
+                x = y; ++n; wraps += wy;
+                continue;
+            }
+            // y came out of an addition inside the binade: the step is steady from y on
+            if (n + 1 == target) { x = y; ++n; return; }
+            int wz;
+            const double z = step(y, &wz);
+            const uint64_t bz = bits_of(z);
+            if (wz || (bz >> 52) != (by >> 52)) { x = z; n += 2; wraps += wz; continue; }
+            const int64_t my = (int64_t) ((by & kMant) | (kMant + 1)), mz = (int64_t) ((bz & kMant) | (kMant + 1));
+            const int64_t dm = mz - my;
+            long run = target - (n + 1);                    // samples n+1 .. n+1+run all of the form y + j*S
+            if (dm > 0) {
+                int64_t lim = (int64_t) 1 << 53;            // first mantissa of the next binade
+                // the wrap comes before the binade ends only in the code phase's top binade [512, 1024):
+                // 1023 = 1023 * 2^43 ulps there (the carrier's top binade [0.5, 1) ends exactly at its wrap)
+                if (kind == 0 && (by >> 52) == 1023 + 9) lim = (int64_t) GPSIQ_CA_SEQ_LEN << 43;
+                const int64_t j = (lim - 1 - my) / dm;
+                if (j < run) run = (long) j;
+            } else if (dm < 0) {
+                const int64_t j = (my - ((int64_t) 1 << 52)) / -dm;
+                if (j < run) run = (long) j;
+            }
+            x = from_bits((by & ~kMant) | ((uint64_t) (my + (int64_t) run * dm) & kMant));
+            n += 1 + run;
+        }
+    }
+};
+
+// Smallest x >= 0 with L <= (A*x mod M) <= R, for 0 <= L <= R < M and 0 <= A < M; kNone if there is none.
+constexpr u128 kNone = ~(u128) 0;
+u128 first_in_range(uint64_t A, uint64_t M, uint64_t L, uint64_t R)
+{
+    if (L == 0) return 0;
+    if (A == 0) return kNone;
+    if (A > M - A) {                 // 2A > M: count downwards instead
+        A = M - A;
+        const uint64_t l = M - R, r = M - L;
+        L = l; R = r;
+    }
+    const uint64_t k = (L + A - 1) / A;
+    if ((u128) k * A <= R) return k;
+    // no multiple of A inside [L, R]: after y wraps of M the window is at M*y + [L, R]; it holds a
+    // multiple of A iff ((-M mod A) * y) mod A lies in [L mod A, R mod A]
+    const u128 y = first_in_range((A - M % A) % A, A, L % A, R % A);
+    if (y == kNone) return kNone;
+    return ((u128) M * y + L + A - 1) / A;
+}
+
+// All n in [0, nsamp) with (a + n*b) mod 2^k within w of 0 (either side), ascending; false if there
+// are more than `cap` (the caller then looks at every sample).
+bool candidates(uint64_t a, uint64_t b, int k, uint64_t w, long nsamp, size_t cap, std::vector<long> *out)
+{
+    const uint64_t M = UINT64_C(1) << k, mask = M - 1;
+    if (2 * w + 1 >= M) return false;
+    const uint64_t W = 2 * w + 1;                    // shifted by w the window is [0, W)
+    b &= mask;
+    long base = 0;
+    while (base < nsamp) {
+        const uint64_t cur = (uint64_t) (((u128) a + w + (u128) b * (uint64_t) base) & mask);
+        long hit;
+        if (cur < W) hit = base;
+        else {
+            const u128 x = first_in_range(b, M, M - cur, M - cur + W - 1);
+            if (x == kNone || x >= (u128) (nsamp - base)) break;
+            hit = base + (long) x;
+        }
+        if (out->size() >= cap) return false;
+        out->push_back(hit);
+        base = hit + 1;
+    }
+    return true;
+}
+
+inline unsigned nav_bit(const gpsiq_chan_t &ch, long bit)     // the data bit `bit` nav-bit periods after the block's first
+{
+    const long pos = (long) ch.ibit + bit;
+    const long w = (long) ch.iword + pos / 30;
+    if (w >= GPSIQ_N_DWRD) return 0;                            // the float loop would run past dwrd[] too; quantize_one rejects it
+    return (ch.dwrd[w] >> (29 - (int) (pos % 30))) & 1u;
+}
+
+}  // namespace
+
+// Patches of one channel of one block.  ch.carr_phase is the double the block starts from; q is its
+// quantised form (quantize_one without carry_in, i.e. seeded from that double).
+static void block_patches(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double delt, int nsamp, int block, int slot,
+                          const uint8_t *ca, std::vector<gpsiq_patch_t> *out)
+{
+    const long ns = nsamp;
+    if (ns <= 0) return;
+    const double carr_inc = ch.f_carr * delt, code_inc = ch.f_code * delt;
+    // drift bounds at the end of the block, in units of the fixed-point formats (see the header)
+    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
+    const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
+    std::vector<long> t_carr, t_code, targets;
+    constexpr size_t kCap = 256;
+    bool every = false;
+    if (carr_inc != 0.0)          // a zero addend leaves both paths constant and equal
+        every |= !candidates(q.carr_phase, (uint64_t) q.carr_step, GPSIQ_CARR_FRAC_BITS - 9, w_carr, ns, kCap, &t_carr);
+    every |= !candidates(q.code_frac, q.code_step, GPSIQ_CODE_FRAC_BITS, w_code, ns, kCap, &t_code);
+    if (every) {
+        targets.resize((size_t) ns);
+        for (long n = 0; n < ns; ++n) targets[(size_t) n] = n;
+    } else {
+        targets.resize(t_carr.size() + t_code.size());
+        std::merge(t_carr.begin(), t_carr.end(), t_code.begin(), t_code.end(), targets.begin());
+        targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+    }
+    if (targets.empty()) return;
+    Nco carr = {ch.carr_phase, carr_inc, 0, 0, 1}, code = {ch.code_phase, code_inc, 0, 0, 0};
+    const bool walk_code = every || !t_code.empty();
+    for (long n : targets) {
+        // fixed-point path (include/gpsiq.h)
+        const uint64_t P = (q.carr_phase + (uint64_t) q.carr_step * (uint64_t) n) & ((UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1);
+        const unsigned idx_f = (unsigned) (P >> (GPSIQ_CARR_FRAC_BITS - 9));
+        const u128 T = (u128) q.code_frac + (u128) q.code_step * (uint64_t) n;
+        const uint64_t A = (uint64_t) q.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+        const unsigned chip_f = (unsigned) (A % GPSIQ_CA_SEQ_LEN);
+        const long per_f = (long) (A / GPSIQ_CA_SEQ_LEN);
+        const unsigned neg_f = ca[chip_f] ^ nav_bit(ch, ((long) ch.icode + per_f) / 20);
+        // double path
+        carr.advance(n);
+        unsigned idx_d = (unsigned) (int) std::floor(carr.x * 512.0);              // gps.c:2775
+        if (idx_d > 511u) idx_d = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
+        unsigned neg_d = neg_f;
+        if (walk_code) {
+            code.advance(n);
+            const unsigned chip_d = (unsigned) (int) code.x;                         // gps.c:2817
+            neg_d = ca[chip_d] ^ nav_bit(ch, ((long) ch.icode + code.wraps) / 20);   // gps.c:2791-2811
+        }
+        if (idx_d != idx_f || neg_d != neg_f) {
+            gpsiq_patch_t p;
+            p.block = (uint32_t) block; p.sample = (uint32_t) n;
+            p.slot = (uint8_t) slot; p.neg = (uint8_t) neg_d; p.lut = (uint16_t) idx_d;
+            out->push_back(p);
+        }
+    }
+}
+
+// The carrier phase the reference's accumulator holds after nsamp samples.
+static double carrier_after(double carr_phase, double carr_inc, int nsamp)
+{
+    Nco carr = {carr_phase, carr_inc, 0, 0, 1};
+    carr.advance(nsamp);
+    return carr.x;
+}
+
+int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
+                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn)
+{
+    // pass 1: the carrier chain, serial per channel (gps.c:2821 carries chan[i].carr_phase from block to
+    // block; allocateChannel re-initialises it when the slot gets another satellite, gps.c:2208-2214)
+    std::vector<double> start((size_t) nblocks * (size_t) nchan, 0.0);
+    struct CJob { const gpsiq_chan_t *ch; int nblocks, nchan, nsamp; double delt; double *start, *end; int *last; };
+    std::vector<double> end((size_t) nchan, 0.0);
+    std::vector<int> last((size_t) nchan, 0);
+    CJob cj = {ch, nblocks, nchan, nsamp, delt, start.data(), end.data(), last.data()};
+    parallel_for(nchan, nchan, 1, [](void *p, int i0, int i1) {
+        CJob &j = *static_cast<CJob *>(p);
+        for (int i = i0; i < i1; ++i) {
+            double carr = 0.0;
+            int prev = 0;
+            for (int b = 0; b < j.nblocks; ++b) {
+                const gpsiq_chan_t &d = j.ch[(size_t) b * j.nchan + i];
+                if (d.prn <= 0) { prev = 0; carr = 0.0; continue; }
+                if (b == 0 || prev != d.prn) carr = d.carr_phase;
+                j.start[(size_t) b * j.nchan + i] = carr;
+                if (carr >= 0.0 && carr < 1.0 && std::fabs(d.f_carr * j.delt) < 0.5)     // else quantize_one reports it below
+                    carr = carrier_after(carr, d.f_carr * j.delt, j.nsamp);
+                prev = d.prn;
+            }
+            j.end[i] = carr; j.last[i] = prev;
+        }
+    }, &cj);
+    // pass 2: quantise every block from its own start phase and look for the samples that differ
+    struct PJob { const gpsiq_chan_t *ch; gpsiq_qchan_t *q; const double *start; int nchan, nsamp; double delt;
+                  std::vector<gpsiq_patch_t> *out; pthread_mutex_t mu; int rc; char err[320]; };
+    PJob pj = {ch, q, start.data(), nchan, nsamp, delt, patches, PTHREAD_MUTEX_INITIALIZER, GPSIQ_OK, ""};
+    parallel_for(nblocks, 0, 4, [](void *p, int b0, int b1) {
+        PJob &j = *static_cast<PJob *>(p);
+        std::vector<gpsiq_patch_t> mine;
+        uint8_t ca[GPSIQ_CA_SEQ_LEN];
+        for (int b = b0; b < b1; ++b) {
+            int slot = 0;                                   // device order: active channels first (gpsiq_set_descriptors)
+            for (int i = 0; i < j.nchan; ++i) {
+                gpsiq_chan_t d = j.ch[(size_t) b * j.nchan + i];
+                gpsiq_qchan_t &qq = j.q[(size_t) b * j.nchan + i];
+                d.carr_phase = j.start[(size_t) b * j.nchan + i];
+                const int rc = quantize_one(d, j.delt, j.nsamp, nullptr, &qq, nullptr);
+                if (rc != GPSIQ_OK) {
+                    pthread_mutex_lock(&j.mu);
+                    if (j.rc == GPSIQ_OK) { j.rc = rc; std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error()); }
+                    pthread_mutex_unlock(&j.mu);
+                    continue;
+                }
+                if (d.prn <= 0) continue;
+                ca_code(d.prn, ca);
+                block_patches(d, qq, j.delt, j.nsamp, b, slot, ca, &mine);
+                ++slot;
+            }
+        }
+        if (!mine.empty()) {
+            pthread_mutex_lock(&j.mu);
+            j.out->insert(j.out->end(), mine.begin(), mine.end());
+            pthread_mutex_unlock(&j.mu);
+        }
+    }, &pj);
+    if (pj.rc != GPSIQ_OK) return fail(pj.rc, "%s", pj.err);
+    std::sort(patches->begin(), patches->end(), [](const gpsiq_patch_t &a, const gpsiq_patch_t &b) {
+        if (a.block != b.block) return a.block < b.block;
+        if (a.sample != b.sample) return a.sample < b.sample;
+        return a.slot < b.slot;
+    });
+    for (int i = 0; i < nchan; ++i) {
+        if (carr_end) carr_end[i] = end[(size_t) i];
+        if (last_prn) last_prn[i] = last[(size_t) i];
+    }
+    return GPSIQ_OK;
+}
+
+}  // namespace gpsiq
+
+using namespace gpsiq;
+
+extern "C" int gpsiq_reference_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp,
+                                     gpsiq_qchan_t *q, gpsiq_patch_t *patches, int max_patches, int *npatches,
+                                     double *carr_phase_out)
+{
+    if ((!ch || !q) && nblocks) return fail(GPSIQ_E_ARG, "null descriptor pointer");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0 || !(fs > 0.0) || max_patches < 0 || !npatches || (max_patches && !patches))
+        return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g / patch buffer", nsamp, fs);
+    std::vector<gpsiq_patch_t> v;
+    int rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q, &v, carr_phase_out, nullptr);
+    if (rc) return rc;
+    *npatches = (int) v.size();
+    if (v.size() > (size_t) max_patches)
+        return fail(GPSIQ_E_RANGE, "%zu patches, room for %d", v.size(), max_patches);
+    if (!v.empty()) std::memcpy(patches, v.data(), v.size() * sizeof(gpsiq_patch_t));
+    return GPSIQ_OK;
+}

@@ -5,6 +5,10 @@
 #include "../../include/gpsiq.h"
 #include "gpsiq_tables.h"
 
+#include <pthread.h>
+#include <cstdio>
+#include <vector>
+
 namespace gpsiq {
 
 int  fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -22,6 +26,12 @@ int  quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t
 int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
                       const bool *cont0, const uint64_t *carry0, gpsiq_qchan_t *q,
                       uint64_t *carry_end, int *last_prn);
+
+// GPSIQ_NCO_REFERENCE (gpsiq_exact.cpp): quantise a timeline with every block seeded from the carrier
+// phase the reference's double accumulator holds at its start, and list the samples where the double
+// path differs from the closed form.  carr_end / last_prn (may be null): state after the last block.
+int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
+                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn);
 
 // Run fn(ctx, begin, end) over [0, n) on up to nthreads host threads (<= 0: one per online
 // CPU, but at least `grain` items per thread).  Returns after all parts are done.

@@ -12,7 +12,8 @@ import numpy as np
 
 from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,  # noqa: F401
                   SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype, EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE,
-                  NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE, NAV_STATE_DTYPE, RINEX_EPH_DTYPE)
+                  NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE, NAV_STATE_DTYPE, RINEX_EPH_DTYPE, PATCH_DTYPE,
+                  NCO_FIXED, NCO_REFERENCE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
@@ -72,6 +73,9 @@ _generate_block = _sig("gpsiq_generate_block", _i, _vp, _vp, _i, _i, _d, _i, _vp
 _generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i, _vp)
 _generate_quantized = _sig("gpsiq_generate_quantized", _i, _vp, _vp, _i, _i, _i, _i, _vp, _i)
 _quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp)
+_reference_batch = _sig("gpsiq_reference_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _i, C.POINTER(C.c_int), _vp)
+_set_patches = _sig("gpsiq_set_patches", _i, _vp, _vp, _i)
+_set_nco_mode = _sig("gpsiq_set_nco_mode", _i, _vp, _i)
 _shard_range = _sig("gpsiq_shard_range", _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _set_descriptors = _sig("gpsiq_set_descriptors", _i, _vp, _vp, _i, _i)
 _launch = _sig("gpsiq_launch", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i)
@@ -142,6 +146,26 @@ def quantize_blocks(desc, fs, nsamp, carry0=None):
     cout = np.zeros(nc, dtype=np.uint64)
     _check(_quantize_batch(_p(desc), nb, nc, float(fs), int(nsamp), _p(q), None if cin is None else _p(cin), _p(cout)))
     return q, cout
+
+
+def reference_blocks(desc, fs, nsamp):
+    """GPSIQ_NCO_REFERENCE form of quantize_blocks: (q, patches, carr_phase_end).  Every block is seeded from
+    the carrier phase the reference's double accumulator holds at its start; patches lists the samples where
+    the double path differs from the closed form."""
+    desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+    nb, nc = desc.shape
+    q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+    carr = np.zeros(nc, dtype=np.float64)
+    n = C.c_int(0)
+    cap = 64 + 8 * nb
+    while True:
+        pt = np.zeros(cap, dtype=PATCH_DTYPE)
+        rc = _reference_batch(_p(desc), nb, nc, float(fs), int(nsamp), _p(q), _p(pt), cap, C.byref(n), _p(carr))
+        if rc == -2 and n.value > cap:           # GPSIQ_E_RANGE: not enough room
+            cap = n.value
+            continue
+        _check(rc)
+        return q, pt[: n.value].copy(), carr
 
 
 def shard_range(nblocks, rank, world):
@@ -237,6 +261,14 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_nco_mode(self, mode):
+        """NCO_FIXED (default) or NCO_REFERENCE for generate_block / generate_batch."""
+        _check(_set_nco_mode(self._h, int(mode)))
+
+    def set_patches(self, patches):
+        patches = np.ascontiguousarray(patches, dtype=PATCH_DTYPE)
+        _check(_set_patches(self._h, _p(patches) if len(patches) else None, len(patches)))
 
     # -- drop-in entry points (host buffers) --
     def generate_block(self, ch, nsamp, fs, sample_size, host_ptr=None):

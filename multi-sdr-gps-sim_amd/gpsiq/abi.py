@@ -25,6 +25,11 @@ QCHAN_DTYPE = np.dtype([
 ], align=True)
 assert QCHAN_DTYPE.itemsize == 48
 
+# gpsiq_patch_t (GPSIQ_NCO_REFERENCE)
+PATCH_DTYPE = np.dtype([("block", "<u4"), ("sample", "<u4"), ("slot", "u1"), ("neg", "u1"), ("lut", "<u2")], align=True)
+assert PATCH_DTYPE.itemsize == 12
+NCO_FIXED, NCO_REFERENCE = 0, 1
+
 
 def elem_dtype(sample_size):
     return np.int8 if sample_size == SC08 else np.int16

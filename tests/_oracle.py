@@ -283,6 +283,40 @@ class Ref:
         return out[0]
 
 
+def apply_patches(orc, q, out, patches, sample_size):
+    """CPU stand-in for the device fix-up of GPSIQ_NCO_REFERENCE (apply_patches in gpsiq_kernels.hip):
+    q = one block's quantised descriptors, out = its 2*nsamp fixed-point elements (modified in place),
+    patches = that block's gpsiq_patch_t entries.  Every patched sample is recomputed whole from the
+    closed form of include/gpsiq.h with the patched channels' (lut, neg) substituted."""
+    sin512, cos512 = orc.tables()
+    active = [c for c in range(len(q)) if q[c]["prn"] > 0]           # device order: active channels first
+
+    def s16(v):
+        v &= 0xFFFF
+        return v - 65536 if v >= 32768 else v
+
+    for n in sorted(set(int(p["sample"]) for p in patches)):
+        acc_i = acc_q = 0
+        for slot, c in enumerate(active):
+            d = q[c]
+            idx = ((int(d["carr_phase"]) + int(d["carr_step"]) * n) % (1 << 59)) >> 50
+            a = int(d["chip0"]) + ((int(d["code_frac"]) + int(d["code_step"]) * n) >> 56)
+            neg = int(orc.codegen(int(d["prn"]))[a % 1023]) ^ ((int(d["nav_bits"]) >> ((int(d["icode"]) + a // 1023) // 20)) & 1)
+            for p in patches:
+                if int(p["sample"]) == n and int(p["slot"]) == slot:
+                    idx, neg = int(p["lut"]), int(p["neg"])
+            tc, ts = int(int(cos512[idx]) * float(d["gain"])), int(int(sin512[idx]) * float(d["gain"]))
+            acc_i += -tc if neg else tc
+            acc_q += -ts if neg else ts
+        for k, v in ((2 * n, acc_i), (2 * n + 1, acc_q)):
+            v = s16(v)
+            if sample_size == SC08:
+                v = (v >> 4) & 0xFF
+                v = v - 256 if v >= 128 else v
+            out[k] = v
+    return out
+
+
 def load_oracle():
     path = os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path):

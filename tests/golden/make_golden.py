@@ -40,6 +40,11 @@ CASES = [
     ("wrap8_3M_16ch_sc08", 3000000, 16, SC08, 1, 106, "loud"),  # |sum| > 2047: int8 wraps (gps.c:2845)
     ("navedge_3M_8ch_sc16", 3000000, 8, SC16, 2, 107, "navedge"),  # icode=19, ibit=29: word/bit roll-over
     ("realloc_3M_8ch_sc08", 3000000, 8, SC08, 3, 108, "realloc"),  # slot emptied / re-allocated
+    # blocks on which the fixed-point closed form and the reference's double accumulators are KNOWN to differ
+    # (t1_mismatch > 0; the differing element indices and the reference's values there are stored):
+    # GPSIQ_NCO_REFERENCE must reproduce the SHA-256, GPSIQ_NCO_FIXED must differ exactly there
+    ("t1diff_25M_16ch_sc16", 25000000, 16, SC16, 2, 104, None),
+    ("t1diff_25M_16ch_sc08", 25000000, 16, SC08, 2, 3032, None),
 ]
 
 
@@ -64,19 +69,22 @@ def main():
     o, r = _oracle.load_oracle(), _oracle.load_ref()
     assert r is not None, "oracle/_ref/libgpsref.so missing"
 
-    s, c = r.tables()
-    prn = np.stack([np.packbits(r.codegen(p), bitorder="little") for p in range(1, 33)])
-    np.savez_compressed(os.path.join(HERE, "tables.npz"), sin512=s.astype(np.int16), cos512=c.astype(np.int16),
-                        prn_packed=prn)
-
+    only = set(a for a in sys.argv[1:] if not a.startswith("--"))     # optional: names of the cases to (re)write
+    if not only:
+        s, c = r.tables()
+        prn = np.stack([np.packbits(r.codegen(p), bitorder="little") for p in range(1, 33)])
+        np.savez_compressed(os.path.join(HERE, "tables.npz"), sin512=s.astype(np.int16), cos512=c.astype(np.int16),
+                            prn_packed=prn)
     for name, fs, nchan, ss, nb, seed, kind in CASES:
+        if only and name not in only:
+            continue
         desc = tweak(synth_blocks(nb, nchan, seed=seed), kind)
         ns = fs // 10
         out, chunks, carr = r.run_blocks(desc, fs, ss, SINK_IQFILE)
         assert len(out) == 2 * ns * nb and (chunks == 2 * ns).all()
         sha = [hashlib.sha256(out[b * 2 * ns:(b + 1) * 2 * ns].tobytes()).hexdigest() for b in range(nb)]
         head = np.stack([out[b * 2 * ns: b * 2 * ns + HEAD] for b in range(nb)])
-        t1 = []
+        t1, t1_block, t1_elem, t1_ref = [], [], [], []
         for b in range(nb):
             db = desc[b].copy()
             if b > 0:
@@ -84,12 +92,19 @@ def main():
                 db["carr_phase"] = np.where(keep, carr[b - 1], db["carr_phase"])
             q, _ = o.quantize(db, fs, ns)
             fx = o.block_fixed(q, ns, ss, seq=True)
-            t1.append(int(np.count_nonzero(fx != out[b * 2 * ns:(b + 1) * 2 * ns])))
+            bad = np.nonzero(fx != out[b * 2 * ns:(b + 1) * 2 * ns])[0]
+            t1.append(len(bad))
+            t1_block += [b] * len(bad)
+            t1_elem += [int(k) for k in bad]
+            t1_ref += [int(out[b * 2 * ns + k]) for k in bad]
         np.savez_compressed(os.path.join(HERE, name + ".npz"), desc=desc.view(np.uint8).reshape(nb, nchan, -1),
                             fs=fs, nsamp=ns, sample_size=ss, sha256=np.array(sha), head=head, carr_out=carr,
-                            t1_mismatch=np.array(t1))
+                            t1_mismatch=np.array(t1), t1_block=np.array(t1_block, dtype=np.int32),
+                            t1_elem=np.array(t1_elem, dtype=np.int64), t1_ref=np.array(t1_ref, dtype=np.int32))
         print(f"{name}: {nb} blocks x {ns} samples, T1 mismatching elements per block = {t1}")
 
+    if only:
+        return
     # fifo chunking (gps.c:2847-2856): HackRF 262144-element buffers, partial buffer carried over
     desc = synth_blocks(3, 4, seed=109)
     out, chunks, _ = r.run_blocks(desc, 3000000, SC08, SINK_HACKRF)
@@ -232,6 +247,8 @@ if __name__ == "__main__":
         make_refresh_golden()
     elif "--nav-only" in sys.argv:
         make_nav_golden()
+    elif any(not a.startswith("--") for a in sys.argv[1:]):
+        main()                                   # only the named block cases
     else:
         main()
         make_nav_golden()

@@ -1,0 +1,167 @@
+"""GPSIQ_NCO_REFERENCE on the GPU: the HIP path reproduces the reference's double-accumulator loop
+element for element over whole runs -- compared DIRECTLY with the reference's own compiled lines
+(oracle/_ref/libgpsref.so travels to the GPU box), with the oracle's restatement of them, and with
+the committed captures, incl. the t1diff_* blocks on which the fixed-point model is known to differ."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import gpsiq
+from gpsiq.abi import NCO_FIXED, NCO_REFERENCE, SC08, SC16, SINK_IQFILE
+from gpsiq.scenario import synth_blocks
+from test_golden import CASES, check_fixed_block_against_golden, load_case, start_state
+from test_gpu_parity import VARIANTS, run_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rctx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no CPU path in libgpsiq"
+    c = gpsiq.Context(0)
+    c.set_nco_mode(NCO_REFERENCE)
+    yield c
+    c.close()
+
+
+def float_run(oracle, d, fs, ss):
+    """The reference loop over consecutive blocks via the oracle's restatement (pinned to the reference
+    in test_oracle_vs_ref.py): used where oracle/_ref is absent."""
+    ns = int(fs) // 10
+    out, carr, prev = [], None, None
+    for b in range(len(d)):
+        db = d[b].copy()
+        if b:
+            keep = (prev == db["prn"]) & (db["prn"] > 0)
+            db["carr_phase"] = np.where(keep, carr, db["carr_phase"])
+        o, carr = oracle.block_float(db, ns, fs, ss)
+        out.append(o)
+        prev = db["prn"].copy()
+    return np.stack(out), carr
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_blocks_reference_nco(rctx, name):
+    """Every committed capture as ONE batch from the captured descriptors alone: the library carries the
+    carrier like the reference's accumulator, so all blocks hash to the reference's bytes -- also the
+    t1diff_* blocks, where the fixed-point model differs in the recorded elements."""
+    g = load_case(name)
+    carr = np.zeros(g["desc"].shape[1])
+    got = rctx.generate_batch(g["desc"], g["nsamp"], g["fs"], g["ss"], carr_out=carr)
+    for b in range(len(g["sha"])):
+        assert hashlib.sha256(got[b].tobytes()).hexdigest() == g["sha"][b], (name, b)
+    act = g["desc"][-1]["prn"] > 0
+    assert (carr[act] == g["carr"][-1][act]).all()
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c.startswith("t1diff_")])
+def test_known_mismatch_blocks_fixed_nco(rctx, name):
+    """The same captures in the default model: GPU == reference except exactly at the recorded elements."""
+    g = load_case(name)
+    rctx.set_nco_mode(NCO_FIXED)
+    for b in range(len(g["sha"])):
+        q, _ = gpsiq.quantize(start_state(g, b), g["fs"], g["nsamp"])
+        rctx.set_descriptors(q[None, :])
+        check_fixed_block_against_golden(g, b, run_device(rctx, q[None, :], g["nsamp"], g["ss"], "auto")[0])
+
+
+@pytest.mark.parametrize("fs,nchan,ss,nb,seed", [(2600000, 16, SC08, 299, 20250215),     # BASELINE config 1 length
+                                                 (2600000, 12, SC16, 60, 7),
+                                                 (3000000, 12, SC08, 40, 8),
+                                                 (10000000, 16, SC16, 24, 9),
+                                                 (25000000, 16, SC16, 12, 10),
+                                                 (25000000, 16, SC08, 12, 11)])
+def test_whole_run_equals_the_reference_itself(rctx, ref, fs, nchan, ss, nb, seed):
+    """T2 = 0: a whole run through gpsiq_generate_batch against the reference's own loop run here on the
+    host (carrier carried by the reference's double accumulator), every element of every block."""
+    d = synth_blocks(nb, nchan, seed=seed)
+    want, _, carr_ref = ref.run_blocks(d, fs, ss, SINK_IQFILE)
+    carr = np.zeros(nchan)
+    got = rctx.generate_batch(d, fs // 10, float(fs), ss, carr_out=carr)
+    assert np.array_equal(got.reshape(-1), want)
+    assert np.array_equal(carr, carr_ref[-1])
+
+
+def test_block_at_a_time_equals_the_reference_loop(rctx, oracle):
+    """The drop-in pattern: gpsiq_generate_block once per 0.1 s block, the carr_phase it hands out passed
+    back in (what the patched gps thread does) == the float loop; slots going out of view and being
+    re-allocated re-seed from the descriptor like allocateChannel (gps.c:2208-2214)."""
+    fs, nb, nc = 2.6e6, 12, 10
+    d = synth_blocks(nb, nc, seed=61)
+    d["prn"][4:, 3] = 0
+    d["prn"][7:, 5] = 29
+    d["carr_phase"][7:, 5] = 0.3125
+    for ss in (SC08, SC16):
+        want, carr_want = float_run(oracle, d, fs, ss)
+        carr, prev = None, None
+        for b in range(nb):
+            db = d[b].copy()
+            if b:
+                keep = (prev == db["prn"]) & (db["prn"] > 0)
+                db["carr_phase"] = np.where(keep, carr, db["carr_phase"])
+            out, carr = rctx.generate_block(db, int(fs) // 10, fs, ss)
+            assert np.array_equal(out, want[b]), (ss, b)
+            prev = db["prn"].copy()
+        act = d[-1]["prn"] > 0
+        assert np.array_equal(carr[act], carr_want[act])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_patches_on_the_resident_path_every_kernel(rctx, oracle, variant):
+    """gpsiq_reference_batch -> gpsiq_set_descriptors + gpsiq_set_patches -> gpsiq_launch (any kernel
+    variant, also a sub-range of the blocks) == the float loop."""
+    fs, nb, nc, ss = 25000000, 4, 16, SC16
+    d = synth_blocks(nb, nc, seed=3032)
+    q, patches, _ = gpsiq.reference_blocks(d, fs, fs // 10)
+    assert len(patches) >= 2
+    want, _ = float_run(oracle, d, float(fs), ss)
+    rctx.set_descriptors(q)
+    rctx.set_patches(patches)
+    got = run_device(rctx, q, fs // 10, ss, variant)
+    assert np.array_equal(got, want)
+    sub = run_device(rctx, q, fs // 10, ss, variant, block0=1, nblocks=2)
+    assert np.array_equal(sub, want[1:3])
+    rctx.set_patches(patches[:0])                                   # cleared: back to the plain closed form
+    plain = run_device(rctx, q, fs // 10, ss, variant)
+    assert np.array_equal(plain, np.stack([oracle.block_fixed(q[b], fs // 10, ss, seq=True) for b in range(nb)]))
+    assert not np.array_equal(plain, want)
+
+
+def test_reference_nco_edge_cases(rctx, oracle):
+    """Zero / tiny / negative Doppler, phases on boundaries, unused slots, short and ragged blocks."""
+    d = synth_blocks(3, 8, seed=5)
+    d["f_carr"][:] = [0.0, -4999.7, 4999.7, 1e-9, -1e-9, 0.25, -1234.5, 3e-14]
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    d["carr_phase"][:] = [0.0, 0.0, 0.999999999999, 0.5, 0.5, 0.0, 1e-300, 0.75]
+    d["code_phase"][0, :3] = [0.0, 1022.9999999999, 511.99999999999994]
+    d["prn"][:, 6] = 0
+    for fs, ns in ((2.6e6, 70001), (25e6, 120000), (2.6e6, 1), (2.6e6, 65), (1.023e6, 30000)):
+        want, carr, prev = [], None, None
+        for b in range(3):
+            db = d[b].copy()
+            if b:
+                db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+            o, carr = oracle.block_float(db, ns, fs, SC16)
+            want.append(o)
+            prev = db["prn"].copy()
+        got = rctx.generate_batch(d, ns, fs, SC16)
+        assert np.array_equal(got, np.stack(want)), (fs, ns)
+
+
+def test_mode_switch_and_patch_validation(rctx):
+    d = synth_blocks(2, 4, seed=9)
+    q, patches, _ = gpsiq.reference_blocks(d, 2.6e6, 1000)
+    rctx.set_descriptors(q)
+    bad = np.zeros(1, dtype=patches.dtype)
+    bad["block"] = 5
+    with pytest.raises(gpsiq.GpsiqError):
+        rctx.set_patches(bad)
+    bad["block"], bad["lut"] = 0, 600
+    with pytest.raises(gpsiq.GpsiqError):
+        rctx.set_patches(bad)
+    with pytest.raises(gpsiq.GpsiqError):
+        rctx.set_nco_mode(7)
+    rctx.set_nco_mode(NCO_FIXED)
+    rctx.set_nco_mode(NCO_REFERENCE)
