@@ -171,6 +171,24 @@ int gpsiq_reference_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double
  * rank r owns [*begin, *end); the first nblocks % world ranks own one block more. */
 int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end);
 
+/* Sharding the HOST side too (GPSIQ_NCO_FIXED): a rank quantises only its own blocks,
+ *   gpsiq_quantize_batch(ch_own, n_own, ..., carry_in = NULL)      block 0 seeded from its own carr_phase,
+ *   gpsiq_shard_carry(q_own, ...)  -> 16 x 32 bytes                what its range does to each slot's carrier,
+ *   (all ranks exchange those records: an all-gather of 512 bytes, setup only, not on the data path)
+ *   gpsiq_shard_seed(q_own, ..., all_records, rank)                adds the exact prefix of the ranks before it,
+ * after which q_own equals the same rows of gpsiq_quantize_batch over the whole timeline. */
+typedef struct gpsiq_shard_carry {
+    uint64_t end_phase;   /* carrier phase after the range's last block, with block 0 seeded from its own carr_phase */
+    uint64_t advance;     /* sum of nsamp*carr_step over the range, mod 2^59 (meaningful while the slot keeps one PRN) */
+    int32_t  first_prn, last_prn;   /* PRN in the first / last block of the range (0 = unused slot) */
+    int32_t  reseeded;    /* the slot changed PRN inside the range: end_phase does not depend on the ranks before */
+    int32_t  nblocks;     /* 0: an empty range, transparent to the chain */
+} gpsiq_shard_carry_t;
+
+int gpsiq_shard_carry(const gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp, gpsiq_shard_carry_t *out /* [nchan] */);
+int gpsiq_shard_seed(gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp,
+                     const gpsiq_shard_carry_t *all /* [world][nchan], rank-major */, int rank);
+
 /* ---- device context ------------------------------------------------------ */
 /* device = HIP device ordinal.  Fails (GPSIQ_E_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */

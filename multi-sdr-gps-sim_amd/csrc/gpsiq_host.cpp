@@ -335,6 +335,62 @@ int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end)
     return GPSIQ_OK;
 }
 
+int gpsiq_shard_carry(const gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp, gpsiq_shard_carry_t *out)
+{
+    if ((!q && nblocks) || !out) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN || nsamp < 0) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d / nsamp %d", nblocks, nchan, nsamp);
+    for (int i = 0; i < nchan; ++i) {
+        gpsiq_shard_carry_t &o = out[i];
+        std::memset(&o, 0, sizeof o);
+        o.nblocks = nblocks;
+        int prev = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            const gpsiq_qchan_t &d = q[(size_t) b * nchan + i];
+            if (b == 0) o.first_prn = d.prn;
+            else if (d.prn != prev) o.reseeded = 1;
+            o.advance = (o.advance + (uint64_t) d.carr_step * (uint64_t) nsamp) & kCarrMask;
+            o.end_phase = d.prn ? (d.carr_phase + (uint64_t) d.carr_step * (uint64_t) nsamp) & kCarrMask : 0;
+            prev = d.prn;
+        }
+        o.last_prn = prev;
+    }
+    return GPSIQ_OK;
+}
+
+int gpsiq_shard_seed(gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp, const gpsiq_shard_carry_t *all, int rank)
+{
+    if ((!q && nblocks) || !all) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN || nsamp < 0 || rank < 0) return fail(GPSIQ_E_ARG, "bad shard arguments");
+    for (int i = 0; i < nchan && nblocks; ++i) {
+        const int prn = q[i].prn;
+        if (!prn) continue;
+        // the phase the ranks before this one leave behind for the slot: walk back while the slot keeps this
+        // PRN through whole ranges, to the range that seeded it (a re-allocation inside it, another PRN in
+        // front of it, or rank 0), whose end_phase is absolute; then add the advances on the way forward
+        uint64_t adv = 0;
+        int r = rank - 1;
+        bool found = false;
+        for (; r >= 0; --r) {
+            const gpsiq_shard_carry_t &s = all[(size_t) r * nchan + i];
+            if (s.nblocks == 0) continue;
+            if (s.last_prn != prn) break;                         // the slot held something else: this rank seeds itself
+            if (s.reseeded || s.first_prn != prn || r == 0) { adv = (adv + s.end_phase) & kCarrMask; found = true; break; }
+            // the whole of range r kept this PRN and continues its predecessor -- unless that one ended on another PRN
+            int rp = r - 1;
+            while (rp >= 0 && all[(size_t) rp * nchan + i].nblocks == 0) --rp;
+            if (rp < 0 || all[(size_t) rp * nchan + i].last_prn != prn) { adv = (adv + s.end_phase) & kCarrMask; found = true; break; }
+            adv = (adv + s.advance) & kCarrMask;
+        }
+        if (!found) continue;
+        const uint64_t delta = (adv - q[i].carr_phase) & kCarrMask;   // true start minus the self-seeded start
+        for (int b = 0; b < nblocks && q[(size_t) b * nchan + i].prn == prn; ++b) {
+            gpsiq_qchan_t &d = q[(size_t) b * nchan + i];
+            d.carr_phase = (d.carr_phase + delta) & kCarrMask;
+        }
+    }
+    return GPSIQ_OK;
+}
+
 int gpsiq_chunker_init(gpsiq_chunker_t *ck, int sink_kind, int sample_size,
                        gpsiq_iq_buf_t *(*acquire)(void *), void (*enqueue)(void *, gpsiq_iq_buf_t *),
                        void *user)

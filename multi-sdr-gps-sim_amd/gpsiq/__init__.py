@@ -13,7 +13,7 @@ import numpy as np
 from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,  # noqa: F401
                   SINK_PLUTOSDR, HACKRF_CHUNK, MAX_CHAN, elem_dtype, EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE,
                   NAV_EPH_DTYPE, NAV_UTC_DTYPE, NAV_ALM_DTYPE, NAV_STATE_DTYPE, RINEX_EPH_DTYPE, PATCH_DTYPE,
-                  NCO_FIXED, NCO_REFERENCE)
+                  NCO_FIXED, NCO_REFERENCE, SHARD_CARRY_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
@@ -76,6 +76,8 @@ _quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp
 _reference_batch = _sig("gpsiq_reference_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _i, C.POINTER(C.c_int), _vp)
 _set_patches = _sig("gpsiq_set_patches", _i, _vp, _vp, _i)
 _set_nco_mode = _sig("gpsiq_set_nco_mode", _i, _vp, _i)
+_shard_carry = _sig("gpsiq_shard_carry", _i, _vp, _i, _i, _i, _vp)
+_shard_seed = _sig("gpsiq_shard_seed", _i, _vp, _i, _i, _i, _vp, _i)
 _shard_range = _sig("gpsiq_shard_range", _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _set_descriptors = _sig("gpsiq_set_descriptors", _i, _vp, _vp, _i, _i)
 _launch = _sig("gpsiq_launch", _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i)
@@ -166,6 +168,24 @@ def reference_blocks(desc, fs, nsamp):
             continue
         _check(rc)
         return q, pt[: n.value].copy(), carr
+
+
+def shard_carry(q, nsamp):
+    """gpsiq_shard_carry: what this rank's (self-seeded) block range does to each slot's carrier."""
+    q = np.ascontiguousarray(q, dtype=QCHAN_DTYPE)
+    nb, nc = q.shape
+    out = np.zeros(nc, dtype=SHARD_CARRY_DTYPE)
+    _check(_shard_carry(_p(q), nb, nc, int(nsamp), _p(out)))
+    return out
+
+
+def shard_seed(q, nsamp, all_carry, rank):
+    """gpsiq_shard_seed: add the exact carrier prefix of the ranks before `rank` to q (in place)."""
+    assert q.dtype == QCHAN_DTYPE and q.flags.c_contiguous
+    nb, nc = q.shape
+    allc = np.ascontiguousarray(all_carry, dtype=SHARD_CARRY_DTYPE).reshape(-1, nc)
+    _check(_shard_seed(_p(q), nb, nc, int(nsamp), _p(allc), int(rank)))
+    return q
 
 
 def shard_range(nblocks, rank, world):

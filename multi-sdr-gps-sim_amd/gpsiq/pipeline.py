@@ -64,6 +64,29 @@ class RunAhead:
         self.carr_phase0 = self.trk["carr_phase"].copy()
         self.blocks_done = 0
 
+    def _roll(self, t_roll):
+        for i in range(len(self.svs)):                                        # gps.c:2878-2885
+            nav_message(self.sbf[i], self.week, t_roll, False, self.nav[i:i + 1])
+            self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
+            self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+
+    def seek(self, block, xyz_prev):
+        """Put the host state where the loop has it just before block `block`, without refreshing the
+        blocks in front of it: a rank of a time-sharded run starts here.  The navigation words are rolled
+        at every 30 s edge passed (cheap: one generateNavMsg per channel and edge); the previous block's
+        pseudorange (chan.rho0, gps.c:2063) is recomputed at its time and position xyz_prev -- a block's
+        range depends on nothing but time and position, so this is what the refresh would have left."""
+        assert self.blocks_done == 0 and block >= 0
+        if block == 0:
+            return
+        for _, b1, roll in epoch_plan(self.sec, block):
+            if roll:
+                self._roll(gps_time_after(self.sec, b1))
+        carr = self.trk["carr_phase"].copy()
+        track_init(self.orbit, self.iono, self.week, gps_time_after(self.sec, block), np.asarray(xyz_prev, dtype=np.float64), self.trk)
+        self.trk["carr_phase"] = carr                    # the loop's state, not the host model's (gps.c:2821)
+        self.blocks_done = block
+
     def descriptors(self, xyz, carr_phase=None, gain_x2=False, nthreads=0):
         """Channel state at gps.c:2766 for the next len(xyz) blocks (xyz[k] = ECEF position of
         block k).  carr_phase: what the previous Context.generate_batch call handed out
@@ -77,11 +100,7 @@ class RunAhead:
             out.append(d)
             self.blocks_done += b1 - b0
             if roll:                                                          # gps.c:2878-2885
-                t_roll = gps_time_after(self.sec, self.blocks_done)
-                for i in range(len(self.svs)):
-                    nav_message(self.sbf[i], self.week, t_roll, False, self.nav[i:i + 1])
-                    self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
-                    self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+                self._roll(gps_time_after(self.sec, self.blocks_done))
         desc = np.concatenate(out) if out else np.zeros((0, len(self.svs)), dtype=CHAN_DTYPE)
         # the loop's own state (gps.c:2821), not the host model's
         desc["carr_phase"] = (self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64))[None, :]

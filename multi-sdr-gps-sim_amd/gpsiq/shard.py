@@ -4,19 +4,49 @@ Each 0.1 s block depends only on its descriptor; the one piece of state the refe
 hands from block to block is the carrier phase (gps.c:2821), and in the fixed-point model
 it has the exact prefix  p_k = p_0 + sum_{j<k} nsamp*step_j (mod 2^59).  So rank r takes
 the contiguous blocks [r*B/N, (r+1)*B/N) of the timeline, seeded from that prefix; the
-data path needs no collective (RCCL is only used for the bench's barrier / max-time).
+data path needs no collective.  The host side shards too: a rank refreshes and quantises only
+its own blocks and learns its carrier seed from 32 bytes per channel that every rank publishes
+about its own range (one all-gather at set-up, gpsiq_shard_carry / gpsiq_shard_seed).
 """
 import numpy as np
 
-from . import quantize_blocks, shard_range  # noqa: F401  (shard_range: the C-ABI's contiguous balanced split)
+from . import quantize_blocks, shard_carry, shard_range, shard_seed  # noqa: F401
+from .abi import SHARD_CARRY_DTYPE
 
 
 def shard_descriptors(desc_all, fs, nsamp, rank, world):
-    """Quantise the whole timeline (host cost: microseconds per block) and return this
-    rank's slice, so every shard starts from the exact carried carrier phase."""
+    """Quantise the WHOLE timeline on this rank and return its slice (the simple recipe: host cost is
+    microseconds per block, but every rank repeats it)."""
     q_all, _ = quantize_blocks(desc_all, fs, nsamp)
     b0, b1 = shard_range(len(desc_all), rank, world)
     return np.ascontiguousarray(q_all[b0:b1]), (b0, b1)
+
+
+def quantize_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes):
+    """Quantise ONLY this rank's blocks (desc_own = its rows of the timeline) and seed its carrier from
+    the ranks before it.  all_gather_bytes(bytes) -> [bytes of rank 0, ..., bytes of rank world-1] is the
+    one exchange needed (32 bytes per channel and rank; torch.distributed, MPI, a pipe -- anything).
+    The result equals shard_descriptors() of the whole timeline."""
+    q, _ = quantize_blocks(desc_own, fs, nsamp)               # block 0 seeded from its own carr_phase
+    mine = shard_carry(q, nsamp)
+    parts = all_gather_bytes(mine.tobytes())
+    assert len(parts) == world
+    allc = np.stack([np.frombuffer(p, dtype=SHARD_CARRY_DTYPE) for p in parts])
+    return shard_seed(np.ascontiguousarray(q), nsamp, allc, rank)
+
+
+def torch_all_gather_bytes(dist, device="cpu"):
+    """all_gather_bytes over a torch.distributed process group (gloo on CPU tensors, RCCL on GPU tensors)."""
+    import torch
+
+    def gather(b):
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return [b]
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(device)
+        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, t)
+        return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+    return gather
 
 
 def max_over_ranks(seconds, dist=None, device=None):

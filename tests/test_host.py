@@ -252,3 +252,40 @@ def test_chunker_matches_reference_capture():
     blocks = [rng.integers(-100, 100, size=nelem).astype(np.int8) for _ in range(nb)]
     enq = run_chunker(SINK_HACKRF, SC08, blocks, 262144)
     assert [len(x) for x in enq] == list(z["chunk_len"])
+
+
+def test_a_rank_quantises_only_its_own_blocks():
+    """gpsiq_shard_carry / gpsiq_shard_seed: every rank quantises its own rows, learns its carrier seed from
+    32 bytes per channel and rank, and ends up with exactly the rows of the whole-timeline quantiser --
+    with satellites setting, slots re-allocated, unused slots, empty ranks."""
+    import gpsiq
+    from gpsiq import quantize_blocks, shard_carry, shard_range, shard_seed
+    from gpsiq.shard import quantize_own_shard
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        nb, nc, world, ns = int(rng.integers(1, 40)), int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 5000))
+        d = synth_blocks(nb, nc, seed=trial)
+        for _ in range(int(rng.integers(0, 6))):
+            b, c = int(rng.integers(0, nb)), int(rng.integers(0, nc))
+            d["prn"][b:, c] = int(rng.integers(0, 33))
+            d["carr_phase"][b:, c] = rng.random()
+        whole, _ = quantize_blocks(d, 2.6e6, ns)
+        own, carry = [], []
+        for r in range(world):
+            b0, b1 = shard_range(nb, r, world)
+            q = quantize_blocks(d[b0:b1], 2.6e6, ns)[0] if b1 > b0 else np.zeros((0, nc), dtype=whole.dtype)
+            own.append(np.ascontiguousarray(q))
+            carry.append(shard_carry(q, ns))
+        for r in range(world):
+            b0, b1 = shard_range(nb, r, world)
+            if b1 > b0:
+                shard_seed(own[r], ns, np.stack(carry), r)
+                assert np.array_equal(own[r], whole[b0:b1]), (trial, r, world, nb)
+    # the recipe as one call, with a stand-in for the exchange
+    d = synth_blocks(9, 5, seed=3)
+    whole, _ = quantize_blocks(d, 2.6e6, 777)
+    recs = [shard_carry(quantize_blocks(d[slice(*shard_range(9, r, 3))], 2.6e6, 777)[0], 777).tobytes() for r in range(3)]
+    for r in range(3):
+        b0, b1 = shard_range(9, r, 3)
+        got = quantize_own_shard(d[b0:b1], 2.6e6, 777, r, 3, lambda mine: recs)
+        assert np.array_equal(got, whole[b0:b1])

@@ -75,6 +75,22 @@ def test_multi_epoch_descriptors_match_the_reference_loop(ref, tmp_path, sec, mo
     assert len(svs) == 12 and (desc["iword"] < 60).all()
 
 
+@pytest.mark.parametrize("sec,moving", [(270020.0, False), (270000.0, True)])
+def test_a_rank_can_start_anywhere(tmp_path, sec, moving):
+    """Host-side sharding: RunAhead.seek(b0) + descriptors(its range) == the same rows of the full run,
+    for starts before, on and after the 30 s navigation-message refreshes."""
+    nblocks = 700
+    path, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving)
+    full = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    edges = [e for _, e, roll in epoch_plan(sec, nblocks) if roll]
+    for b0 in (0, 1, 57, edges[0] - 1, edges[0], edges[0] + 1, edges[1], 650):
+        b1 = min(nblocks, b0 + 40)
+        ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+        ra.seek(b0, xyz[b0])                       # xyz[b0] is the position of block b0-1 (xyz[0]: the start position)
+        part = ra.descriptors(xyz[1 + b0:1 + b1])
+        assert part.tobytes() == full[b0:b1].tobytes(), b0
+
+
 def test_golden_multi_epoch_capture(tmp_path):
     """Committed capture of the reference loop incl. its nav refresh (runs without /root/reference):
     every block's descriptors by SHA-256, the blocks either side of each refresh byte for byte."""
