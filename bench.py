@@ -3,25 +3,36 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (one gpsiq_launch through the C-ABI) over one
-batch of --blocks 0.1 s blocks of synthetic channel descriptors, with the
-quantised descriptors already resident in HBM; the IQ output goes to a device ring of
-blocks*block_bytes (>= 2 GiB by default, far beyond the 256 MiB Infinity Cache) so
-that the writes really reach HBM.  Workload = BASELINE.json metric: 2.6 Msps, int8,
-16 channels.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the time
-axis is sharded: rank r owns blocks [r*B, (r+1)*B) of one N*B-block timeline, its
-carrier phases seeded by the exact closed-form prefix; no collective touches the data
-path (weak scaling: per-GPU work is fixed).
+Launch: with N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks
+(torch.distributed.run, one per GPU, rendezvous on 127.0.0.1); under torchrun it checks
+WORLD_SIZE == N.  Fewer visible GPUs than ranks, or a WORLD_SIZE that disagrees with --gpus, is an
+error (non-zero exit), never a silent 1-GPU run.
+
+A "step" is one pass of the hot path over one batch of synthetic input: --launches
+gpsiq_launch calls (C-ABI) over --blocks 0.1 s blocks each, i.e. launches*blocks DISTINCT blocks of
+one timeline whose quantised descriptors are resident in HBM; the IQ output goes to a device ring of
+blocks*block_bytes (>= 2 GiB by default, far beyond the 256 MiB Infinity Cache) that every launch
+of the step rewrites, so the writes really reach HBM.  Workload = BASELINE.json metric: 2.6 Msps,
+int8, 16 channels.  With N > 1 the time axis is sharded: rank r owns blocks [r*B, (r+1)*B) of one
+N*B-block timeline; it builds and quantises ONLY those blocks and learns its carrier seed from 32
+bytes per channel that every rank publishes about its own range (gpsiq_shard_carry/_seed: one
+all-gather at set-up).  No collective touches the data path (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     — algorithmic IQ bytes per launch / mean launch duration (HIP events on
-                 the launch stream) against the 8 TB/s HBM peak,
-  cpu_baseline — the reference's own loop (oracle/_ref, kind "reference") or our port
-                 of it (oracle/, kind "port") timed on this host, 1 core, bounded sample.
+  roofline     — algorithmic IQ bytes per launch / mean launch duration (HIP events on the launch
+                 stream) against the 8 TB/s HBM peak,
+  cpu_baseline — the reference's own loop (oracle/_ref, kind "reference") or our port of it
+                 (oracle/, kind "port") timed on this host, 1 core, bounded sample (N = 1 only),
+  end_to_end   — the same per-GPU block count from scratch on every rank: host refresh of its own
+                 blocks (gpsiq_refresh_batch) -> quantise -> carrier seed exchange -> upload -> kernel,
+  extra        — short legs for the other BASELINE configs (each with its own roofline), the
+                 host-destination and single-block drop-in calls, GPSIQ_NCO_REFERENCE, first-launch times.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,21 +41,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
 _LIB = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "gpsiq", "libgpsiq.so")
-if not os.path.exists(_LIB):
-    # fresh checkout: build the HIP extension first (there is no other path to run); local rank 0
-    # builds, the other ranks of the node wait for the file
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        import subprocess
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")], check=True)
-    else:
-        for _ in range(600):
-            if os.path.exists(_LIB):
-                break
-            time.sleep(0.5)
-        time.sleep(1.0)
 
 PREHEAT_LAUNCHES = 12   # untimed, before the warm-up steps: clock ramp (see main)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TOKYO_LLH = (35.681298, 139.766247, 10.0)   # BASELINE configs 1/2: static position
+WEEK, SEC0 = 2190, 270000.0
 
 
 def parse():
@@ -55,12 +56,16 @@ def parse():
     ap.add_argument("--fs", type=float, default=2.6e6)
     ap.add_argument("--nchan", type=int, default=16)
     ap.add_argument("--sample-size", type=int, default=1, choices=(1, 2), help="1 = int8 IQ, 2 = int16 IQ")
-    ap.add_argument("--blocks", type=int, default=0, help="0.1 s blocks per step per GPU (0: enough for a 2 GiB ring)")
+    ap.add_argument("--blocks", type=int, default=0, help="0.1 s blocks per launch per GPU (0: enough for a 2 GiB ring)")
+    ap.add_argument("--launches", type=int, default=18, help="launches (of --blocks distinct blocks each) per step")
     ap.add_argument("--variant", type=str, default="auto")
     ap.add_argument("--seed", type=int, default=20250215)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (other configs, drop-in calls)")
     ap.add_argument("--cpu-blocks", type=int, default=299, help="blocks of the CPU baseline sample (299 = 30 s, config 1)")
     ap.add_argument("--sweep", action="store_true", help="also time every kernel variant (extra stderr lines)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="host side only (launch logic, rendezvous, sharded refresh/quantise, seed exchange); no device, value null")
     return ap.parse_args()
 
 
@@ -78,6 +83,40 @@ def effective_cpus():
     except (OSError, ValueError):
         pass
     return n
+
+
+def self_launch(args):
+    """python bench.py --gpus N without a launcher: become the launcher."""
+    if not args.dry_run and os.environ.get("GPSIQ_BENCH_SHARE_GPU", "0") in ("", "0"):
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+            return 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def ensure_built():
+    if os.path.exists(_LIB):
+        return
+    # fresh checkout: build the HIP extension first (there is no other path to run); local rank 0
+    # builds, the other ranks of the node wait for the file
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")], check=True)
+    else:
+        for _ in range(600):
+            if os.path.exists(_LIB):
+                break
+            time.sleep(0.5)
+        time.sleep(1.0)
 
 
 def cpu_baseline(desc, fs, nsamp, sample_size, nblocks, passes=3):
@@ -135,201 +174,211 @@ def _cpu_worker(a):
     return len(d)
 
 
+def roofline_obj(alg_bytes, launch_ms, traffic=None):
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
+
+
+class Scenario:
+    """BASELINE config 1/2 geometry for the end-to-end leg: static receiver, synthetic RINEX v2 file with
+    nchan satellites in view -> ephemeris -> the host chain of gpsiq/pipeline.py."""
+
+    def __init__(self, nchan, tmpdir):
+        import gpsiq
+        from gpsiq.scenario import llh_to_ecef, synth_rinex_records, write_rinex_nav
+        self.pos = llh_to_ecef(*TOKYO_LLH)
+        utc = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
+                   A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=WEEK, dtls=18)
+        path = write_rinex_nav(os.path.join(tmpdir, f"bench_{os.getpid()}.21n"),
+                               synth_rinex_records(nchan, self.pos, WEEK, SEC0, seed=35, sets=2), utc, 2)
+        self.eph, self.utc, nset = gpsiq.rinex_read(path, 2)
+        self.ieph = gpsiq.rinex_select(self.eph, nset, WEEK, SEC0)
+        self.svs = [sv for sv in range(32) if self.eph[self.ieph, sv]["vflg"]][:nchan]
+
+    def descriptors(self, b0, b1, nthreads=0):
+        """gpsiq_chan_t rows [b0, b1) of the run, computing only those (RunAhead.seek)."""
+        from gpsiq.pipeline import RunAhead
+        ra = RunAhead(self.eph[self.ieph], self.utc, self.svs, WEEK, SEC0, self.pos)
+        ra.seek(b0, self.pos)
+        xyz = np.repeat(self.pos[None, :], b1 - b0, axis=0)
+        return ra.descriptors(xyz, nthreads=nthreads)
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world) if env_world is not None else 1
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run a different job than asked for", file=sys.stderr)
+        sys.exit(2)
+    ensure_built()
+    dry = args.dry_run
+
+    fs, nchan, ss = args.fs, args.nchan, args.sample_size
+    nsamp = int(round(fs / 10))                      # NUM_IQ_SAMPLES, reference sdr.h:26
+    blk_bytes = 2 * nsamp * ss
+    stride = (blk_bytes + 15) & ~15
+    nblocks = args.blocks or -(-(2 << 30) // stride)  # per launch; ring >= 2 GiB
+    L = max(1, args.launches)
+    B = nblocks * L                                   # blocks per GPU per step
 
     # CPU baseline first (rank 0, N = 1 only): it forks worker processes for the all-cores
     # figure, which must happen before this process holds a GPU context
     cpu_base = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not dry:
         from gpsiq.scenario import synth_blocks as _sb
-        nsamp_c = int(round(args.fs / 10))
-        pat = _sb(64, args.nchan, seed=args.seed)
+        pat = _sb(64, nchan, seed=args.seed)
         d_cpu = np.concatenate([pat] * (-(-args.cpu_blocks // 64)))[: args.cpu_blocks]
-        cpu_base = cpu_baseline(d_cpu, args.fs, nsamp_c, args.sample_size, args.cpu_blocks)
+        cpu_base = cpu_baseline(d_cpu, fs, nsamp, ss, args.cpu_blocks)
 
     import torch
     import gpsiq
     from gpsiq.scenario import synth_blocks
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (libgpsiq has no CPU path)"
-    # one rank per GPU; the modulo only matters when the multi-rank path is exercised on a box
-    # with fewer GPUs than ranks (GPSIQ_BENCH_BACKEND=gloo, see scripts/gpu_validate.sh)
-    dev = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev)
+    from gpsiq.shard import max_over_ranks, quantize_own_shard, shard_range, torch_all_gather_bytes
+    dev = 0
+    if not dry:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU (libgpsiq has no CPU path)")
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and os.environ.get("GPSIQ_BENCH_SHARE_GPU", "0") in ("", "0"):
+            print(f"bench.py: rank {rank} (local {local_rank}) has no GPU of its own: {ndev} visible", file=sys.stderr)
+            sys.exit(3)
+        dev = local_rank % ndev                       # the modulo only under GPSIQ_BENCH_SHARE_GPU=1 (scripts/gpu_validate.sh)
+        torch.cuda.set_device(dev)
     dist = None
-    backend = os.environ.get("GPSIQ_BENCH_BACKEND", "nccl")    # nccl == RCCL on ROCm
+    backend = "gloo" if dry else os.environ.get("GPSIQ_BENCH_BACKEND", "nccl")    # nccl == RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
-
-    fs, nchan, ss = args.fs, args.nchan, args.sample_size
-    nsamp = int(round(fs / 10))                      # NUM_IQ_SAMPLES, reference sdr.h:26
-    blk_bytes = 2 * nsamp * ss
-    stride = (blk_bytes + 15) & ~15
-    nblocks = args.blocks or -(-(2 << 30) // stride)  # ring >= 2 GiB
+    xdev = "cuda" if (backend == "nccl" and not dry) else "cpu"
+    gather = torch_all_gather_bytes(dist, xdev)
     variant = gpsiq.variants()[args.variant]
 
-    # one global timeline of world*nblocks blocks; this rank's shard is [rank*nblocks, ...)
-    # Descriptors: distinct code/Doppler state per block for a short pattern, tiled over
-    # the timeline (host generation cost only), then quantised with the exact carrier prefix.
-    from gpsiq.shard import max_over_ranks, shard_descriptors
-    pattern = synth_blocks(min(64, nblocks), nchan, seed=args.seed)
-    reps = -(-nblocks * world // len(pattern))
-    desc_all = np.concatenate([pattern] * reps)[: nblocks * world]
-    q, (b0, b1) = shard_descriptors(desc_all, fs, nsamp, rank, world)
-    assert b1 - b0 == nblocks
+    # one global timeline of world*B blocks; this rank builds, quantises and seeds ONLY its own rows.
+    # Descriptors: distinct code/Doppler state per block for a 64-block pattern tiled over the timeline.
+    b0, b1 = shard_range(B * world, rank, world)
+    assert b1 - b0 == B
+    pattern = synth_blocks(64, nchan, seed=args.seed)
+    t_q = time.perf_counter()
+    desc_own = pattern[(b0 + np.arange(B)) % len(pattern)]
+    q = quantize_own_shard(desc_own, fs, nsamp, rank, world, gather)
+    t_q = time.perf_counter() - t_q
 
-    ctx = gpsiq.Context(dev)
-    ctx.set_descriptors(q)
-    ring = torch.empty(nblocks * stride, dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    ctx = ring = stream = None
+    first = {}
+    if not dry:
+        ctx = gpsiq.Context(dev)
+        ctx.set_descriptors(q)
+        ring = torch.empty(nblocks * stride, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        if rank == 0:
+            # cold figures, before anything warms the device up: the very first launch (module load, clock
+            # ramp) and the mean of the next five -- what a caller that launches once in a while sees
+            torch.cuda.synchronize()
+            first["first_launch_ms"] = round(ctx.time_launches(0, nblocks, nsamp, ss, ring.data_ptr(), stride, 1, stream=stream, variant=variant), 3)
+            first["next5_launch_ms"] = round(ctx.time_launches(nblocks % B, nblocks, nsamp, ss, ring.data_ptr(), stride, 5, stream=stream, variant=variant), 3)
 
     def step():
-        ctx.launch(0, nblocks, nsamp, ss, ring.data_ptr(), stride, stream=stream, variant=variant)
+        for k in range(L):
+            ctx.launch(k * nblocks, nblocks, nsamp, ss, ring.data_ptr(), stride, stream=stream, variant=variant)
 
     def sync_all():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
 
-    # The GPU needs ~25 ms of load to reach its sustained clock (per-dispatch durations in
-    # profiles/r01_final_kernel_trace_stats.txt fall from 4.35 ms to 3.54 ms over the first seven
-    # launches), so the device is brought to that state before the W warm-up steps; untimed.
-    for _ in range(PREHEAT_LAUNCHES):
-        step()
-    for _ in range(args.warmup):
-        step()
+    launch_ms = float("nan")
+    if not dry:
+        # The GPU needs ~25 ms of load to reach its sustained clock (per-dispatch durations in
+        # profiles/r01_final_kernel_trace_stats.txt fall from 4.35 ms to 3.54 ms over the first seven
+        # launches), so the device is brought to that state before the W warm-up steps; untimed.
+        for k in range(PREHEAT_LAUNCHES):
+            ctx.launch((k % L) * nblocks, nblocks, nsamp, ss, ring.data_ptr(), stride, stream=stream, variant=variant)
+        for _ in range(args.warmup):
+            step()
     sync_all()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
+    if not dry:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
         torch.cuda.synchronize()
-    t_max = max_over_ranks(t_local, dist, device="cuda" if backend == "nccl" else "cpu")
-    launch_ms = e0.elapsed_time(e1) / args.steps       # HIP events on the launch stream
+    t_local = time.perf_counter() - t0
+    sync_all()
+    t_max = max_over_ranks(t_local, dist, device=xdev)
+    if not dry:
+        launch_ms = e0.elapsed_time(e1) / (args.steps * L)       # HIP events on the launch stream
 
-    if args.sweep and rank == 0:
-        for name, v in gpsiq.variants().items():
-            if name == "auto":
-                continue
-            try:
-                ms = min(ctx.time_launches(0, nblocks, nsamp, ss, ring.data_ptr(), stride, 5, stream=stream, variant=v)
-                         for _ in range(3))
-                print(f"[sweep] variant {name}: {ms:.3f} ms/launch, {nblocks * nsamp / ms / 1e6:.1f} Gsamples/s",
-                      file=sys.stderr)
-            except gpsiq.GpsiqError as e:
-                print(f"[sweep] variant {name}: {e}", file=sys.stderr)
+    # ---- end to end: the same per-GPU block count from nothing, host side sharded as well ---------------
+    import tempfile
+    e2e = None
+    with tempfile.TemporaryDirectory() as td:
+        scen = Scenario(nchan, td)
+        nb_e = nblocks
+        g0, g1 = shard_range(nb_e * world, rank, world)
+        best = None
+        for _ in range(2):                                # the second pass has warm thread pools and buffers
+            sync_all()
+            ta = time.perf_counter()
+            d_e = scen.descriptors(g0, g1)
+            tb = time.perf_counter()
+            q_e = quantize_own_shard(d_e, fs, nsamp, rank, world, gather)
+            tc = time.perf_counter()
+            if not dry:
+                ctx.set_descriptors(q_e)
+                td_ = time.perf_counter()
+                ctx.launch(0, nb_e, nsamp, ss, ring.data_ptr(), stride, stream=stream, variant=variant)
+                torch.cuda.synchronize()
+            else:
+                td_ = time.perf_counter()
+            te = time.perf_counter()
+            parts = (tb - ta, tc - tb, td_ - tc, te - td_)
+            tot = max_over_ranks(te - ta, dist, device=xdev)
+            if best is None or tot < best[0]:
+                best = (tot, [max_over_ranks(p, dist, device=xdev) for p in parts])
+        tot, parts = best
+        e2e = {"value": None if dry else round(nb_e * world * nsamp / tot / 1e6, 1), "unit": "Msamples/s",
+               "blocks_per_gpu": nb_e, "channels": len(scen.svs), "seconds": round(tot, 5),
+               "x_realtime": None if dry else round(nb_e * world * 0.1 / tot, 1),
+               "host_refresh_ms": round(parts[0] * 1e3, 2), "quantise_and_seed_exchange_ms": round(parts[1] * 1e3, 2),
+               "validate_upload_ms": round(parts[2] * 1e3, 2), "kernel_ms": round(parts[3] * 1e3, 2),
+               "host_cpus": effective_cpus(),
+               "what": "static receiver (BASELINE config 1/2 geometry), RINEX-derived ephemeris; per rank: RunAhead.seek to its first block, "
+                       "gpsiq_refresh_batch of its own blocks only, gpsiq_quantize_batch, 32 B/channel carrier-seed all-gather, "
+                       "gpsiq_set_descriptors, one gpsiq_launch; slowest rank, best of 2 passes"}
+        if not dry:
+            ctx.set_descriptors(q)
 
-    if args.sweep and rank == 0:
-        # the drop-in path with HOST destination buffers (gpsiq_generate_batch: quantise,
-        # H2D descriptors, kernel, D2H samples): PCIe-bound, reported separately, never `value`
-        nb_h = min(256, nblocks)
-        pinned = torch.empty(nb_h * blk_bytes, dtype=torch.uint8).pin_memory()
-        ctx.generate_batch(desc_all[:nb_h], nsamp, fs, ss, host_ptr=pinned.data_ptr())
-        t1 = time.perf_counter()
-        ctx.generate_batch(desc_all[:nb_h], nsamp, fs, ss, host_ptr=pinned.data_ptr())
-        dt = time.perf_counter() - t1
-        print(f"[host-dst] gpsiq_generate_batch -> pinned host memory: {nb_h} blocks in {dt * 1e3:.1f} ms = "
-              f"{nb_h * nsamp / dt / 1e6:.0f} Msamples/s, {nb_h * blk_bytes / dt / 1e9:.1f} GB/s over PCIe", file=sys.stderr)
-        ctx.set_descriptors(q)
-
-    if args.sweep and rank == 0:
-        # the real-time drop-in call: ONE block per call into a page-locked host buffer, as the
-        # patched gps thread would issue it every 0.1 s (quantise, H2D, kernel, D2H, sync)
-        lat = []
-        for k in range(60):
-            ch1 = desc_all[k % len(desc_all)]
-            t1 = time.perf_counter()
-            ctx.generate_block(ch1, nsamp, fs, ss, host_ptr=pinned.data_ptr())
-            lat.append(time.perf_counter() - t1)
-        lat = sorted(lat[10:])
-        print(f"[block] gpsiq_generate_block -> pinned host memory: median {lat[len(lat) // 2] * 1e6:.0f} us, "
-              f"max {lat[-1] * 1e6:.0f} us per 0.1 s block ({0.1 / lat[len(lat) // 2]:.0f}x real time, one call at a time)",
-              file=sys.stderr)
-        ctx.set_descriptors(q)
-
-    if args.sweep and rank == 0:
-        # the whole drop-in batch call with a DEVICE destination: host quantiser + descriptor
-        # upload + kernel (no D2H) -- shows what the host side of gpsiq_generate_batch costs
-        nb_d = min(nblocks, len(desc_all))
-        ctx.generate_batch(desc_all[:nb_d], nsamp, fs, ss, device_ptr=ring.data_ptr())
-        dt = float("inf")
-        for _ in range(5):
-            t1 = time.perf_counter()
-            ctx.generate_batch(desc_all[:nb_d], nsamp, fs, ss, device_ptr=ring.data_ptr())
-            dt = min(dt, time.perf_counter() - t1)
-        print(f"[device-dst] gpsiq_generate_batch -> device memory: {nb_d} blocks in {dt * 1e3:.1f} ms = "
-              f"{nb_d / dt / 1e3:.0f} kblocks/s = {nb_d * 0.1 / dt:.0f}x real time (kernel alone {launch_ms:.1f} ms)", file=sys.stderr)
-        ctx.set_descriptors(q)
-
-    if args.sweep and rank == 0:
-        # the whole run-ahead chain of INTEGRATION.md section 3 on a BASELINE config-4 shaped scenario:
-        # RINEX file -> subframes -> nav words -> per-block refresh with the 30 s nav refreshes
-        # (host, gpsiq/pipeline.py) -> IQ in device memory (one gpsiq_generate_batch)
-        import tempfile
-        from gpsiq.pipeline import RunAhead
-        from gpsiq.scenario import circle_track, llh_to_ecef, synth_rinex_records, write_rinex_nav
-        pos = llh_to_ecef(35.681298, 139.766247, 10.0)
-        utc = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
-                   A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=2190, dtls=18)
-        with tempfile.TemporaryDirectory() as td:
-            path = write_rinex_nav(os.path.join(td, "cfg4.21n"), synth_rinex_records(12, pos, 2190, 270000.0, seed=35, sets=2), utc, 2)
-            nb4 = min(5999, (ring.numel() // (4 * nsamp)))          # 600 s when the ring holds it (int16 output)
-            xyz = circle_track(pos, nb4)
-            t1 = time.perf_counter()
-            eph4, utc4, nset = gpsiq.rinex_read(path, 2)
-            ieph = gpsiq.rinex_select(eph4, nset, 2190, 270000.0)
-            svs = [sv for sv in range(32) if eph4[ieph, sv]["vflg"]]
-            ra = RunAhead(eph4[ieph], utc4, svs, 2190, 270000.0, xyz[0])
-            d4 = ra.descriptors(xyz[1:])
-            t2 = time.perf_counter()
-            ctx.generate_batch(d4, nsamp, fs, 2, device_ptr=ring.data_ptr())
-            t3 = time.perf_counter()
-        print(f"[pipeline] RINEX -> {nb4} blocks x {len(svs)} ch, circle track, int16 @ {fs / 1e6:g} Msps: host chain "
-              f"{(t2 - t1) * 1e3:.1f} ms + gpsiq_generate_batch {(t3 - t2) * 1e3:.1f} ms = {nb4 * 0.1 / (t3 - t1):.0f}x real time "
-              f"end to end ({nb4 * 0.1:.0f} s of signal)", file=sys.stderr)
-        ctx.set_descriptors(q)
-
-    if args.sweep and rank == 0:
-        # the host refresh that feeds the kernel (gpsiq_refresh_batch, reference gps.c:2731-2765):
-        # blocks per second on this host, 1 thread and all threads
-        from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks
-        pos = llh_to_ecef(35.681298, 139.766247, 10.0)
-        eph = synth_constellation(nchan, pos, 270000.0, seed=3)
-        xyz = circle_track(pos, 200000)
-        for nt in (1, 0):
-            trk = synth_tracks(nchan, 2190, 270000.0)
-            gpsiq.track_init(eph, synth_iono(), 2190, 270000.0, xyz[0], trk)
-            t1 = time.perf_counter()
-            gpsiq.refresh_batch(eph, synth_iono(), 2190, 270000.0, xyz[1:], trk, nthreads=nt)
-            dt = time.perf_counter() - t1
-            print(f"[refresh] gpsiq_refresh_batch {nchan} ch, {len(xyz) - 1} blocks, threads={'all' if nt == 0 else nt}: "
-                  f"{(len(xyz) - 1) / dt / 1e3:.1f} kblocks/s = {(len(xyz) - 1) * 0.1 / dt:.0f}x real time", file=sys.stderr)
+    extra = {}
+    if not dry and rank == 0 and world == 1 and not args.no_extra:
+        extra = extra_legs(ctx, ring, stream, args, first)
+    if not dry and args.sweep and rank == 0:
+        sweep_legs(ctx, ring, stream, args, q, nblocks, nsamp, ss, stride)
 
     if rank == 0:
-        samples_step = nblocks * nsamp * world
-        value = samples_step * args.steps / t_max / 1e6
+        samples_step = B * nsamp * world
+        value = None if dry else samples_step * args.steps / t_max / 1e6
         alg_bytes = nblocks * blk_bytes                 # algorithmic: 2 or 4 B per complex sample, reads ~0
         # which tile kernel ran: plain adds for int8 always, for int16 when no block's sum of (int)(250*|gain|) exceeds 32767
         forced_packed = os.environ.get("GPSIQ_NO_FAST", "0") not in ("", "0")
         plain_add = (ss == 1 or int(np.floor(250.0 * np.abs(q["gain"])).sum(axis=1).max()) <= 32767) and not forced_packed
         core_cycles = 23.85 if plain_add else 26.7
-        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -339,18 +388,22 @@ def main():
                 traffic = None
         out = {
             "metric": "IQ Msamples/s @16ch int8" if (nchan == 16 and ss == 1) else f"IQ Msamples/s @{nchan}ch int{8 * ss}",
-            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value": None if dry else round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"{fs / 1e6:g} Msps int{8 * ss} IQ, {nchan} channels, {nblocks} x 0.1 s blocks per GPU per step "
-                                   f"({nblocks * 0.1:.1f} s of signal, {nblocks * stride / 2**30:.2f} GiB ring), time-sharded x{world}",
-                       "fs_hz": fs, "channels": nchan, "sample_bytes": ss, "blocks_per_gpu": nblocks,
-                       "samples_per_block": nsamp, "variant": args.variant, "preheat_launches": PREHEAT_LAUNCHES,
-                       "x_realtime": round(value * 1e6 / fs, 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+            "config": {"workload": f"{fs / 1e6:g} Msps int{8 * ss} IQ, {nchan} channels, {L} launches x {nblocks} distinct 0.1 s blocks per GPU per step "
+                                   f"({B * 0.1:.0f} s of signal per GPU and step, {nblocks * stride / 2**30:.2f} GiB ring), time-sharded x{world}",
+                       "fs_hz": fs, "channels": nchan, "sample_bytes": ss, "blocks_per_launch": nblocks, "launches_per_step": L,
+                       "blocks_per_gpu_per_step": B, "samples_per_block": nsamp, "variant": args.variant,
+                       "preheat_launches": PREHEAT_LAUNCHES, "x_realtime": None if dry else round(value * 1e6 / fs, 1),
+                       "host_quantise_own_shard_ms": round(t_q * 1e3, 1)},
+            "end_to_end": e2e,
+        }
+        if dry:
+            out["dry_run"] = True
+        else:
+            out["roofline"] = roofline_obj(alg_bytes, launch_ms, traffic)
             # informational: the limiter actually hit.  Per (channel, 64-sample row)
             # and SIMD the row-kernel core costs, with the single-instruction rates measured on this
             # chip (profiles/r01_ubench_valu_encodings.txt: 4.3 nominal cycles for SGPR-operand / VOP3 /
@@ -358,17 +411,143 @@ def main():
             #   plain-add kernels (all sums inside int16): 3 x 4.3 + 4.3 / 2 + 2 x 4.4 = 23.85 cycles
             #   packed kernels (larger gains):             3 x 4.3 + 2 x 2.5 + 2 x 4.4 = 26.7 cycles
             # peak = every SIMD of 256 CUs issuing only that core at the 2.4 GHz maximum clock.
-            "issue_roofline": {"bound": "valu-issue", "unit": "Gchannel-samples/s", "core_cycles": core_cycles,
-                               "achieved": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / 1e9, 1),
-                               "peak": round(256 * 4 * 64 * 2.4e9 / core_cycles / 1e9, 1),
-                               "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / core_cycles), 4)},
-        }
+            out["issue_roofline"] = {"bound": "valu-issue", "unit": "Gchannel-samples/s", "core_cycles": core_cycles,
+                                     "achieved": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / 1e9, 1),
+                                     "peak": round(256 * 4 * 64 * 2.4e9 / core_cycles / 1e9, 1),
+                                     "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / core_cycles), 4)}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extra_legs(ctx, ring, stream, args, first):
+    """Short legs outside the timed headline (rank 0, N = 1): every other rate this repository quotes,
+    measured in the driver's own run."""
+    import torch
+    import gpsiq
+    from gpsiq.abi import NCO_FIXED, NCO_REFERENCE
+    from gpsiq.scenario import synth_blocks
+    ex = dict(first)
+    ring_bytes = ring.numel()
+
+    def kernel_leg(fs, nchan, ss, note):
+        nsamp = int(round(fs / 10))
+        blk = 2 * nsamp * ss
+        stride = (blk + 15) & ~15
+        nb = ring_bytes // stride
+        pat = synth_blocks(min(64, nb), nchan, seed=args.seed)
+        d = pat[np.arange(nb) % len(pat)]
+        qq, _ = gpsiq.quantize_blocks(d, fs, nsamp)
+        ctx.set_descriptors(qq)
+        ctx.time_launches(0, nb, nsamp, ss, ring.data_ptr(), stride, 2, stream=stream)
+        ms = min(ctx.time_launches(0, nb, nsamp, ss, ring.data_ptr(), stride, 5, stream=stream) for _ in range(2))
+        return {"workload": f"{fs / 1e6:g} Msps int{8 * ss}, {nchan} ch, {nb} blocks per launch ({note})",
+                "value": round(nb * nsamp / ms / 1e3, 1), "unit": "Msamples/s", "x_realtime": round(nb * 0.1 / (ms * 1e-3), 1),
+                "roofline": roofline_obj(nb * blk, ms)}
+
+    ex["cfg2_2M6_int8_12ch"] = kernel_leg(2.6e6, 12, 1, "BASELINE config 2")
+    ex["cfg4_2M6_int16_16ch"] = kernel_leg(2.6e6, 16, 2, "BASELINE config 4 format")
+    ex["cfg3_10M_int16_16ch"] = kernel_leg(10e6, 16, 2, "BASELINE config 3")
+    ex["cfg5_25M_int16_16ch"] = kernel_leg(25e6, 16, 2, "BASELINE config 5, one GPU's share")
+
+    # the drop-in calls (host destination): PCIe-bound, never `value`
+    fs, nchan, ss = args.fs, args.nchan, args.sample_size
+    nsamp = int(round(fs / 10))
+    blk = 2 * nsamp * ss
+    nb_h = 512
+    pat = synth_blocks(64, nchan, seed=args.seed)
+    d_h = pat[np.arange(nb_h) % 64]
+    pinned = torch.empty(nb_h * blk, dtype=torch.uint8).pin_memory()
+    for label, chunk in (("host_dst_batch", None), ("host_dst_batch_unchunked", "0")):
+        if chunk is None:
+            os.environ.pop("GPSIQ_D2H_CHUNK_BLOCKS", None)
+        else:
+            os.environ["GPSIQ_D2H_CHUNK_BLOCKS"] = chunk
+        ctx.generate_batch(d_h, nsamp, fs, ss, host_ptr=pinned.data_ptr())
+        dt = float("inf")
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ctx.generate_batch(d_h, nsamp, fs, ss, host_ptr=pinned.data_ptr())
+            dt = min(dt, time.perf_counter() - t1)
+        ex[label] = {"what": f"gpsiq_generate_batch -> page-locked host memory, {nb_h} blocks ({'kernel of piece k+1 overlaps the copy of piece k' if chunk is None else 'one kernel, then one copy'})",
+                     "value": round(nb_h * nsamp / dt / 1e6, 1), "unit": "Msamples/s", "pcie_GBps": round(nb_h * blk / dt / 1e9, 2),
+                     "x_realtime": round(nb_h * 0.1 / dt, 1)}
+    os.environ.pop("GPSIQ_D2H_CHUNK_BLOCKS", None)
+
+    for label, mode in (("block_call", NCO_FIXED), ("block_call_reference_nco", NCO_REFERENCE)):
+        ctx.set_nco_mode(mode)
+        lat, carr = [], None
+        for k in range(50):
+            ch1 = d_h[k].copy()
+            if carr is not None:
+                ch1["carr_phase"] = carr
+            t1 = time.perf_counter()
+            _, carr = ctx.generate_block(ch1, nsamp, fs, ss, host_ptr=pinned.data_ptr())
+            lat.append(time.perf_counter() - t1)
+        lat = sorted(lat[10:])
+        ex[label] = {"what": "gpsiq_generate_block -> page-locked host memory, one 0.1 s block per call, carr_phase handed back in "
+                             "(the patched gps thread's call)", "median_us": round(lat[len(lat) // 2] * 1e6, 1),
+                     "max_us": round(lat[-1] * 1e6, 1), "x_realtime": round(0.1 / lat[len(lat) // 2], 1)}
+    # GPSIQ_NCO_REFERENCE over a batch: bound by the serial carrier walk on the host
+    ctx.set_nco_mode(NCO_REFERENCE)
+    nb_r = 1000
+    d_r = pat[np.arange(nb_r) % 64]
+    stride = (blk + 15) & ~15
+    ctx.generate_batch(d_r[:64], nsamp, fs, ss, device_ptr=ring.data_ptr())
+    t1 = time.perf_counter()
+    ctx.generate_batch(d_r, nsamp, fs, ss, device_ptr=ring.data_ptr())
+    dt = time.perf_counter() - t1
+    ex["reference_nco_batch"] = {"what": f"gpsiq_generate_batch, GPSIQ_NCO_REFERENCE, {nb_r} blocks -> device memory (host carrier walk + patches + kernel)",
+                                 "value": round(nb_r * nsamp / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / dt, 1),
+                                 "host_cpus": effective_cpus()}
+    ctx.set_nco_mode(NCO_FIXED)
+    # the batch call with a device destination from double-precision descriptors: host quantiser + upload + kernel
+    nb_d = min(ring_bytes // stride, 4130)
+    d_d = pat[np.arange(nb_d) % 64]
+    ctx.generate_batch(d_d, nsamp, fs, ss, device_ptr=ring.data_ptr())
+    dt = float("inf")
+    for _ in range(3):
+        t1 = time.perf_counter()
+        ctx.generate_batch(d_d, nsamp, fs, ss, device_ptr=ring.data_ptr())
+        dt = min(dt, time.perf_counter() - t1)
+    ex["device_dst_batch"] = {"what": f"gpsiq_generate_batch -> device memory, {nb_d} blocks from gpsiq_chan_t (quantise + carrier prefix + upload + kernel)",
+                              "value": round(nb_d * nsamp / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_d * 0.1 / dt, 1)}
+    return ex
+
+
+def sweep_legs(ctx, ring, stream, args, q, nblocks, nsamp, ss, stride):
+    import gpsiq
+    ctx.set_descriptors(q)
+    for name, v in gpsiq.variants().items():
+        if name == "auto":
+            continue
+        try:
+            ms = min(ctx.time_launches(0, nblocks, nsamp, ss, ring.data_ptr(), stride, 5, stream=stream, variant=v)
+                     for _ in range(3))
+            print(f"[sweep] variant {name}: {ms:.3f} ms/launch, {nblocks * nsamp / ms / 1e6:.1f} Gsamples/s",
+                  file=sys.stderr)
+        except gpsiq.GpsiqError as e:
+            print(f"[sweep] variant {name}: {e}", file=sys.stderr)
+    # the host refresh that feeds the kernel (gpsiq_refresh_batch, reference gps.c:2731-2765):
+    # blocks per second on this host, 1 thread and all threads
+    from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks
+    pos = llh_to_ecef(*TOKYO_LLH)
+    eph = synth_constellation(args.nchan, pos, SEC0, seed=3)
+    xyz = circle_track(pos, 200000)
+    for nt in (1, 0):
+        trk = synth_tracks(args.nchan, WEEK, SEC0)
+        gpsiq.track_init(eph, synth_iono(), WEEK, SEC0, xyz[0], trk)
+        t1 = time.perf_counter()
+        gpsiq.refresh_batch(eph, synth_iono(), WEEK, SEC0, xyz[1:], trk, nthreads=nt)
+        dt = time.perf_counter() - t1
+        print(f"[refresh] gpsiq_refresh_batch {args.nchan} ch, {len(xyz) - 1} blocks, threads={'all' if nt == 0 else nt}: "
+              f"{(len(xyz) - 1) / dt / 1e3:.1f} kblocks/s = {(len(xyz) - 1) * 0.1 / dt:.0f}x real time", file=sys.stderr)
 
 
 if __name__ == "__main__":

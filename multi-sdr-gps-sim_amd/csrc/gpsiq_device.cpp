@@ -380,8 +380,7 @@ const char *gpsiq_variant_name(int v)
 // 0 = one kernel, then one copy (the round-1 behaviour, kept for A/B measurements).
 static int d2h_chunk_blocks(size_t stride)
 {
-    static const int forced = [] { const char *e = std::getenv("GPSIQ_D2H_CHUNK_BLOCKS"); return e ? std::atoi(e) : -1; }();
-    if (forced >= 0) return forced;
+    if (const char *e = std::getenv("GPSIQ_D2H_CHUNK_BLOCKS")) return std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: A/B in one process
     const size_t target = (size_t) 32 << 20;                 // ~32 MiB per piece: >= 0.5 ms on the link, a few hundred workgroups
     const size_t n = (target + stride - 1) / stride;
     return (int) (n < 8 ? 8 : n);

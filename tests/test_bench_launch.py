@@ -1,0 +1,44 @@
+"""bench.py's launch logic on CPU (no GPU here): --gpus N starts N ranks by itself, refuses a
+WORLD_SIZE that disagrees, refuses to run with fewer GPUs than ranks -- it never prints "n_gpus": 1
+for a --gpus 8 request.  --dry-run exercises everything but the device: rendezvous (gloo), the
+host-side sharding (own-rows quantiser + carrier seed exchange, sharded refresh) and the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_2_starts_two_ranks_by_itself():
+    r = run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--blocks", "30", "--launches", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                              # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None and out["scaling"] == "weak"
+    assert out["config"]["blocks_per_gpu_per_step"] == 60
+    e = out["end_to_end"]
+    assert e["blocks_per_gpu"] == 30 and e["channels"] == 16 and e["host_refresh_ms"] > 0.0
+
+
+def test_world_size_must_agree_with_gpus():
+    r = run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+    r = run(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2
+
+
+def test_more_ranks_than_gpus_is_an_error():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = run(["--gpus", str(have + 7), "--steps", "1", "--no-cpu-baseline"])
+    assert r.returncode == 3 and "visible" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

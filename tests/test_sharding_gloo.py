@@ -30,10 +30,15 @@ def _worker(rank, world, port, out):
     import torch.distributed as dist
     import _oracle
     from gpsiq.abi import SC16
-    from gpsiq.shard import max_over_ranks, shard_descriptors, shard_range
+    import numpy as np
+    from gpsiq.shard import max_over_ranks, quantize_own_shard, shard_descriptors, shard_range, torch_all_gather_bytes
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     q, (b0, b1) = shard_descriptors(_timeline(), FS, NSAMP, rank, world)
     assert (b0, b1) == shard_range(NBLOCKS, rank, world) and len(q) == b1 - b0
+    # the host side sharded as well: this rank sees ONLY its own rows and gets its carrier seed from the
+    # 32 bytes per channel every rank publishes (one all-gather); same descriptors as the whole-timeline recipe
+    own = quantize_own_shard(_timeline()[b0:b1], FS, NSAMP, rank, world, torch_all_gather_bytes(dist))
+    assert np.array_equal(own, q)
     orc = _oracle.load_oracle()
     digests = [hashlib.sha256(orc.block_fixed(q[i], NSAMP, SC16, seq=True).tobytes()).hexdigest() for i in range(len(q))]
     dist.barrier()
