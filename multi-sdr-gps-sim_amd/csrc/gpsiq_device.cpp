@@ -411,7 +411,10 @@ static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nbloc
     if (dst_is_device || chunk <= 0 || nblocks <= chunk) {
         rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, c->d_out, stride, c->stream, kAuto);
         if (rc) return rc;
-        HIP_TRY(hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks, kind, c->stream));
+        if (stride == blk_bytes)
+            HIP_TRY(hipMemcpyAsync(dst, c->d_out, blk_bytes * (size_t) nblocks, kind, c->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks, kind, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return GPSIQ_OK;
     }
@@ -425,8 +428,11 @@ static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nbloc
         hipStream_t cs = c->copy_stream[k & 1];
         HIP_TRY(hipEventRecord(c->chunk_done[k & 1], c->stream));
         HIP_TRY(hipStreamWaitEvent(cs, c->chunk_done[k & 1], 0));
-        HIP_TRY(hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, piece, stride, blk_bytes,
-                                 (size_t) nb, kind, cs));
+        if (stride == blk_bytes)                                  // rows are contiguous: one linear DMA
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, piece, blk_bytes * (size_t) nb, kind, cs));
+        else
+            HIP_TRY(hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, piece, stride, blk_bytes,
+                                     (size_t) nb, kind, cs));
     }
     HIP_TRY(hipStreamSynchronize(c->copy_stream[0]));
     HIP_TRY(hipStreamSynchronize(c->copy_stream[1]));

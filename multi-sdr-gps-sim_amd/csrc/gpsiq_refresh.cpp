@@ -350,9 +350,11 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
     t[0] = GpsTime{week, sec};
 
     Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0};
-    parallel_for(nblocks, nthreads, 1024, work, &job);      // >= ~1000 blocks (a few ms) per thread
+    // pass 0 costs ~4 us per block (16 satellite positions with light-time iteration), waking the pool ~20 us:
+    // 64 blocks per thread keep a 300-block epoch of the run-ahead loop (gpsiq/pipeline.py) on several cores
+    parallel_for(nblocks, nthreads, 64, work, &job);
     job.pass = 1;
-    parallel_for(nblocks, nthreads, 1024, work, &job);
+    parallel_for(nblocks, nthreads, 256, work, &job);
 
     for (int c = 0; c < nchan; ++c) {                      // chan.rho0 = rho1 (gps.c:2063)
         if (trk[c].prn <= 0) continue;

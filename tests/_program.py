@@ -1,0 +1,60 @@
+"""Run the reference PROGRAM headless (oracle/_ref/gps-sim-ref: the reference's own sources; or
+oracle/_ref/gps-sim-gpsiq: the same with its sample loop replaced by gpsiq_generate_block, see
+oracle/Makefile) and collect the iqdata.bin it writes.  TEST INFRASTRUCTURE."""
+import os
+import signal
+import subprocess
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+RINEX = os.path.join(ROOT, "tests", "golden", "synth_static.21n")
+LLH = "35.681298,139.766247,10.0"          # BASELINE config 1: static position
+FS = 3000000                                # the reference's TX_SAMPLERATE as shipped (sdr.h:21)
+
+
+def program(name):
+    p = os.path.join(REFDIR, name)
+    return p if os.path.exists(p) else None
+
+
+def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout=300):
+    """-> bytes of iqdata.bin.  The program has no batch mode: it draws its ncurses screen (LINES/COLUMNS
+    given so that it does not ask about the window size), generates `seconds` of signal through the fifo
+    into iqdata.bin in the working directory and then idles in its key loop until it is told to stop."""
+    nblocks = seconds * 10 - 1                                   # the block loop starts at 1 (gps.c:2703)
+    expect = nblocks * (FS // 10) * 2 * (2 if iq16 else 1)
+    args = [binary, "-e", RINEX, "-l", LLH, "-r", "iqfile", "-d", str(seconds), "--disable-almanac"]
+    if iq16:
+        args.append("--iq16")
+    env = dict(os.environ, LINES="50", COLUMNS="160", TERM="xterm")
+    env.update(env_extra or {})
+    out = os.path.join(workdir, "iqdata.bin")
+    if os.path.exists(out):
+        os.remove(out)
+    p = subprocess.Popen(args, cwd=workdir, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL,
+                         stderr=subprocess.DEVNULL)
+    try:
+        t0, last, stable = time.time(), -1, 0
+        while time.time() - t0 < timeout:
+            time.sleep(0.25)
+            if p.poll() is not None:
+                raise RuntimeError(f"{binary} exited with {p.returncode} before the run was complete")
+            size = os.path.getsize(out) if os.path.exists(out) else 0
+            stable = stable + 1 if size == last else 0
+            last = size
+            if size > expect - (1 << 20) and stable >= 3:          # all written but the stdio tail
+                break
+        else:
+            raise RuntimeError(f"{binary}: {last} of {expect} bytes after {timeout} s")
+    finally:
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)                          # main loop: signal_handler -> cleanup_and_exit (gps-sim.c:216-247)
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    data = open(out, "rb").read()
+    assert len(data) == expect, (len(data), expect)
+    return data

@@ -236,8 +236,28 @@ def make_alloc_golden():
     print("alloc_horizon:", desc.shape, "nsat", list(nsat), "prn changes", int((desc["prn"][1:] != desc["prn"][:-1]).sum()))
 
 
+def make_program_golden():
+    """The reference PROGRAM as shipped (oracle/_ref/gps-sim-ref: its own gps.c, gps-sim.c, sdr.c, sdr_iqfile.c,
+    almanac.c, gui.c; 3.0 Msps, 12 channels), 30 s at the static BASELINE position on tests/golden/synth_static.21n,
+    int8 and --iq16: SHA-256 of every 0.1 s block of the iqdata.bin it writes."""
+    import tempfile
+    from _program import program, run_program, FS
+    ref = program("gps-sim-ref")
+    assert ref, "oracle/_ref/gps-sim-ref missing (make -C oracle progs)"
+    sha = {}
+    for iq16 in (False, True):
+        with tempfile.TemporaryDirectory() as td:
+            data = run_program(ref, td, 30, iq16)
+        blk = (FS // 10) * 2 * (2 if iq16 else 1)
+        sha["sha16" if iq16 else "sha8"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
+        print("program_static_30s", "iq16" if iq16 else "int8", len(data), "bytes", hashlib.sha256(data).hexdigest())
+    np.savez_compressed(os.path.join(HERE, "program_static_30s.npz"), fs=FS, seconds=30, **sha)
+
+
 if __name__ == "__main__":
-    if "--alloc-only" in sys.argv:
+    if "--program-only" in sys.argv:
+        make_program_golden()
+    elif "--alloc-only" in sys.argv:
         make_alloc_golden()
     elif "--epochs-only" in sys.argv:
         make_epochs_golden()
@@ -255,3 +275,4 @@ if __name__ == "__main__":
         make_rinex_golden()
         make_epochs_golden()
         make_alloc_golden()
+        make_program_golden()

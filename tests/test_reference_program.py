@@ -1,0 +1,65 @@
+"""The drop-in inside the reference's own thread.  oracle/_ref/gps-sim-gpsiq is the reference program
+(gps-sim.c, sdr.c, sdr_iqfile.c, almanac.c, gui.c and gps.c itself) with gps_thread_ep()'s sample loop
++ pack + fifo hand-off (gps.c:2767-2865) cut out and replaced by gpsiq_generate_block() and the chunker,
+exactly as INTEGRATION.md section 2 describes (oracle/patch_gps_thread.py applies it at build time);
+oracle/_ref/gps-sim-ref is the same program unpatched.  Both run headless on the same RINEX file and
+must write the same iqdata.bin, byte for byte."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from _program import FS, program, run_program
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "program_static_30s.npz")
+
+
+def block_digests(data, iq16):
+    blk = (FS // 10) * 2 * (2 if iq16 else 1)
+    return [hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)]
+
+
+@pytest.mark.parametrize("iq16", [False, True])
+def test_unpatched_program_reproduces_its_committed_capture(tmp_path, iq16):
+    """Pins the fixture (tests/golden/make_golden.py --program-only): the reference program as shipped,
+    30 s, static position, int8 and --iq16."""
+    ref = program("gps-sim-ref")
+    if ref is None:
+        pytest.skip("oracle/_ref/gps-sim-ref not built (no /root/reference here)")
+    z = np.load(GOLD)
+    data = run_program(ref, str(tmp_path), 30, iq16)
+    assert block_digests(data, iq16) == [str(s) for s in z["sha16" if iq16 else "sha8"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("iq16", [False, True])
+def test_patched_reference_thread_writes_the_same_file(tmp_path, iq16):
+    """gps_thread_ep() producing its bytes through gpsiq_generate_block (GPSIQ_NCO_REFERENCE) on the GPU ==
+    the committed capture of the unpatched program, all 299 blocks; and == the unpatched program run here."""
+    patched = program("gps-sim-gpsiq")
+    assert patched is not None, "oracle/_ref/gps-sim-gpsiq missing: run __graft_entry__.build() where /root/reference exists"
+    z = np.load(GOLD)
+    data = run_program(patched, str(tmp_path), 30, iq16)
+    got = block_digests(data, iq16)
+    want = [str(s) for s in z["sha16" if iq16 else "sha8"]]
+    assert len(got) == 299
+    bad = [b for b in range(299) if got[b] != want[b]]
+    assert not bad, f"blocks {bad[:10]} differ from the reference program's output"
+    ref = program("gps-sim-ref")
+    if ref is not None:
+        os.makedirs(tmp_path / "ref")
+        assert run_program(ref, str(tmp_path / "ref"), 30, iq16) == data
+
+
+@pytest.mark.gpu
+def test_patched_reference_thread_fixed_point_model(tmp_path):
+    """The same program in the library's default NCO model (GPSIQ_NCO=fixed): everything but a handful of
+    elements per 10^8 equals the reference program's file (tier T2)."""
+    patched = program("gps-sim-gpsiq")
+    assert patched is not None
+    z = np.load(GOLD)
+    data = run_program(patched, str(tmp_path), 30, False, {"GPSIQ_NCO": "fixed"})
+    got = block_digests(data, False)
+    want = [str(s) for s in z["sha8"]]
+    assert sum(g != w for g, w in zip(got, want)) <= 40           # blocks that hold a differing element
