@@ -213,13 +213,16 @@ def sat_visibility(eph, week, sec, xyz, elv_mask_deg=0.0):
     return bool(_check(_sat_visibility(_p(eph), int(week), float(sec), _p(xyz), float(elv_mask_deg), _p(azel)))), azel
 
 
-def refresh_batch(eph, iono, week, sec, xyz, trk, gain_x2=False, nthreads=0):
-    """The per-block host refresh (reference gps.c:2731-2765) for len(xyz) blocks -> gpsiq_chan_t[nblocks][nchan]."""
+def refresh_batch(eph, iono, week, sec, xyz, trk, gain_x2=False, nthreads=0, out=None):
+    """The per-block host refresh (reference gps.c:2731-2765) for len(xyz) blocks -> gpsiq_chan_t[nblocks][nchan].
+    out: optional preallocated C-contiguous [len(xyz)][len(trk)] array (every field is written)."""
     eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
     iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
     xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
     assert trk.dtype == TRACK_DTYPE and trk.flags.c_contiguous
-    out = np.zeros((len(xyz), len(trk)), dtype=CHAN_DTYPE)
+    if out is None:
+        out = np.zeros((len(xyz), len(trk)), dtype=CHAN_DTYPE)
+    assert out.dtype == CHAN_DTYPE and out.shape == (len(xyz), len(trk)) and out.flags.c_contiguous
     _check(_refresh_batch(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), len(trk), int(bool(gain_x2)),
                           _p(trk), _p(out), int(nthreads)))
     return out

@@ -93,17 +93,17 @@ class RunAhead:
         (carr_out) when continuing a run; None on the first call = the allocation's value.
         Only block 0's carr_phase is read by the library, which carries it exactly from there."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
-        out = []
+        desc = np.empty((len(xyz), len(self.svs)), dtype=CHAN_DTYPE)      # every epoch writes its own rows, once
         for b0, b1, roll in epoch_plan(gps_time_after(self.sec, self.blocks_done), len(xyz)):
             t = gps_time_after(self.sec, self.blocks_done)
-            d = refresh_batch(self.orbit, self.iono, self.week, t, xyz[b0:b1], self.trk, gain_x2=gain_x2, nthreads=nthreads)
-            out.append(d)
+            refresh_batch(self.orbit, self.iono, self.week, t, xyz[b0:b1], self.trk, gain_x2=gain_x2, nthreads=nthreads, out=desc[b0:b1])
             self.blocks_done += b1 - b0
             if roll:                                                          # gps.c:2878-2885
                 self._roll(gps_time_after(self.sec, self.blocks_done))
-        desc = np.concatenate(out) if out else np.zeros((0, len(self.svs)), dtype=CHAN_DTYPE)
-        # the loop's own state (gps.c:2821), not the host model's
-        desc["carr_phase"] = (self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64))[None, :]
+        # the loop's own state (gps.c:2821), not the host model's; only block 0's value is read by the library
+        # (it carries the phase itself from there), the reference keeps it in chan[i] between blocks
+        if len(desc):
+            desc["carr_phase"][0] = self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64)
         return desc
 
 
