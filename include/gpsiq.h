@@ -223,6 +223,18 @@ int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, 
                          int nsamp, double fs, int sample_size,
                          void *dst, int dst_is_device, double *carr_phase_out);
 
+/* The batch call over several devices from ONE process (SURVEY.md 8b "batch extension"; the reference is
+ * one process, gps-sim.c:314).  ctx[ndev]: one context per GPU (several contexts on one device work too).
+ * The timeline is quantised once with the exact carrier prefix (or walked once in GPSIQ_NCO_REFERENCE,
+ * taken from ctx[0]'s mode), cut into ndev contiguous block ranges (gpsiq_shard_range) and rendered by
+ * one host thread per context; nothing passes between the devices.  Results land in timeline order:
+ *   host_dst != NULL: one host buffer of nblocks*2*nsamp elements (page-locked: gpsiq_host_alloc);
+ *   else dev_dst[i]:  device buffer on ctx[i]'s device for range i (its blocks packed, no padding).
+ * Carrier continuation between calls follows gpsiq_generate_batch, with ctx[0] keeping the state. */
+int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_chan_t *ch, int nblocks, int nchan,
+                               int nsamp, double fs, int sample_size, void *host_dst, void *const *dev_dst,
+                               double *carr_phase_out);
+
 /* One shard of a time-sharded run: synthesise nblocks already-quantised blocks
  * (a contiguous slice of gpsiq_quantize_batch's output, which carries the exact carrier
  * phase of every block) into dst, host or device as above.  Synchronous.  Does not touch

@@ -544,4 +544,79 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     return GPSIQ_OK;
 }
 
+int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_chan_t *ch, int nblocks, int nchan,
+                               int nsamp, double fs, int sample_size, void *host_dst, void *const *dev_dst,
+                               double *carr_phase_out)
+{
+    if (!ctx || ndev < 1 || ndev > 64) return fail(GPSIQ_E_ARG, "bad device list");
+    for (int i = 0; i < ndev; ++i)
+        if (!ctx[i]) return fail(GPSIQ_E_ARG, "null context %d", i);
+    if (!host_dst && !dev_dst) return fail(GPSIQ_E_ARG, "no destination");
+    int rc = check_gen_args(ctx[0], ch, host_dst ? host_dst : (void *) dev_dst, nblocks, nchan, nsamp, fs, sample_size);
+    if (rc) return rc;
+    if (nblocks == 0) return GPSIQ_OK;
+    gpsiq_ctx *c0 = ctx[0];
+    // the host side once, for the whole timeline
+    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+    std::vector<gpsiq_patch_t> patches;
+    uint64_t carry[GPSIQ_MAX_CHAN] = {};
+    double carr_end[GPSIQ_MAX_CHAN] = {};
+    int prev_prn[GPSIQ_MAX_CHAN] = {};
+    const bool reference = c0->nco_mode == GPSIQ_NCO_REFERENCE;
+    if (reference) {
+        rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), &patches, carr_end, prev_prn);
+    } else {
+        bool cont0[GPSIQ_MAX_CHAN];
+        for (int i = 0; i < nchan; ++i)
+            cont0[i] = ch[i].prn > 0 && c0->carry_prn[i] == ch[i].prn && c0->handed[i] == ch[i].carr_phase;
+        rc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c0->carry, q.data(), carry, prev_prn);
+    }
+    if (rc) return rc;
+    // one host thread per context; each renders its own contiguous range
+    struct Part { gpsiq_ctx *c; const gpsiq_qchan_t *q; std::vector<gpsiq_patch_t> patches; int nb, nchan, nsamp, ss; void *dst; int dst_is_device;
+                  int rc; char err[256]; pthread_t th; bool started; };
+    std::vector<Part> parts((size_t) ndev);
+    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
+    for (int i = 0; i < ndev; ++i) {
+        int b0 = 0, b1 = 0;
+        (void) gpsiq_shard_range(nblocks, i, ndev, &b0, &b1);
+        Part &p = parts[(size_t) i];
+        p.c = ctx[i]; p.q = q.data() + (size_t) b0 * nchan; p.nb = b1 - b0; p.nchan = nchan; p.nsamp = nsamp; p.ss = sample_size;
+        p.dst = host_dst ? (void *) (static_cast<uint8_t *>(host_dst) + (size_t) b0 * blk_bytes) : dev_dst[i];
+        p.dst_is_device = host_dst ? 0 : 1;
+        p.rc = GPSIQ_OK; p.err[0] = 0; p.started = false;
+        for (const gpsiq_patch_t &pt : patches)
+            if ((int) pt.block >= b0 && (int) pt.block < b1) { gpsiq_patch_t r = pt; r.block -= (uint32_t) b0; p.patches.push_back(r); }
+        if (p.nb > 0 && !p.dst) return fail(GPSIQ_E_ARG, "null destination for range %d", i);
+    }
+    auto body = [](void *arg) -> void * {
+        Part &p = *static_cast<Part *>(arg);
+        if (p.nb > 0) {
+            p.rc = run_to_host_or_device(p.c, p.q, p.nb, p.nchan, p.nsamp, p.ss, p.dst, p.dst_is_device, &p.patches);
+            if (p.rc != GPSIQ_OK) std::snprintf(p.err, sizeof p.err, "%s", gpsiq_last_error());
+        }
+        return nullptr;
+    };
+    for (int i = 1; i < ndev; ++i)
+        parts[(size_t) i].started = pthread_create(&parts[(size_t) i].th, nullptr, body, &parts[(size_t) i]) == 0;
+    body(&parts[0]);
+    for (int i = 1; i < ndev; ++i) {
+        if (parts[(size_t) i].started) pthread_join(parts[(size_t) i].th, nullptr);
+        else body(&parts[(size_t) i]);                       // could not start a thread: do it here
+    }
+    for (int i = 0; i < ndev; ++i)
+        if (parts[(size_t) i].rc != GPSIQ_OK) return fail(parts[(size_t) i].rc, "device range %d: %s", i, parts[(size_t) i].err);
+    for (int i = 0; i < nchan; ++i) {
+        if (reference) {
+            if (carr_phase_out) carr_phase_out[i] = prev_prn[i] ? carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+        } else {
+            c0->carry_prn[i] = prev_prn[i];
+            c0->carry[i] = carry[i];
+            c0->handed[i] = prev_prn[i] ? carr_phase_to_double(carry[i]) : 0.0;
+            if (carr_phase_out) carr_phase_out[i] = c0->handed[i];
+        }
+    }
+    return GPSIQ_OK;
+}
+
 }  // extern "C"

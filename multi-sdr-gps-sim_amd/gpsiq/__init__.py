@@ -76,6 +76,7 @@ _quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp
 _reference_batch = _sig("gpsiq_reference_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _i, C.POINTER(C.c_int), _vp)
 _set_patches = _sig("gpsiq_set_patches", _i, _vp, _vp, _i)
 _set_nco_mode = _sig("gpsiq_set_nco_mode", _i, _vp, _i)
+_generate_batch_multi = _sig("gpsiq_generate_batch_multi", _i, _vp, _i, _vp, _i, _i, _i, _d, _i, _vp, _vp, _vp)
 _shard_carry = _sig("gpsiq_shard_carry", _i, _vp, _i, _i, _i, _vp)
 _shard_seed = _sig("gpsiq_shard_seed", _i, _vp, _i, _i, _i, _vp, _i)
 _shard_range = _sig("gpsiq_shard_range", _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -263,6 +264,25 @@ def rinex_read(path, version=2):
 def rinex_select(eph, nsets, week, sec):
     eph = np.ascontiguousarray(eph, dtype=RINEX_EPH_DTYPE)
     return int(_rinex_select(_p(eph), int(nsets), int(week), float(sec)))
+
+
+def generate_batch_multi(contexts, desc, nsamp, fs, sample_size, host_ptr=None, device_ptrs=None, carr_out=None):
+    """gpsiq_generate_batch_multi: one call, one contiguous block range per context.  host_ptr: one host buffer
+    for the whole timeline; device_ptrs: one device pointer per context (its own range); neither: a numpy array."""
+    desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+    nb, nc = desc.shape
+    handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    co = None if carr_out is None else _p(carr_out)
+    out = None
+    if device_ptrs is not None:
+        dp = (C.c_void_p * len(contexts))(*[int(p) for p in device_ptrs])
+        _check(_generate_batch_multi(handles, len(contexts), _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), None, dp, co))
+        return None
+    if host_ptr is None:
+        out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
+        host_ptr = out.ctypes.data
+    _check(_generate_batch_multi(handles, len(contexts), _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(host_ptr), None, co))
+    return out
 
 
 class Context:
