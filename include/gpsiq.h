@@ -383,7 +383,8 @@ typedef struct gpsiq_rinex_eph {  /* one ephem_t (gps.h:155-196), in the groupin
 
 /* version: 2 or 3.  eph is [GPSIQ_EPHEM_SETS][GPSIQ_MAX_SAT]; utc receives the header's
  * ionosphere/UTC parameters (vflg set when all four header records were present, gps.c:1257-1259).
- * Returns the number of ephemeris sets (>= 0), or the reference's error codes: -1 cannot open,
+ * Returns the number of ephemeris sets (0 .. GPSIQ_EPHEM_SETS; the reference reports 14 for a file with more
+ * than 13 hourly groups although it stores 13 -- the library does not), or the reference's error codes: -1 cannot open,
  * -2 wrong RINEX version for this reader, -3 not a GPS navigation file. */
 int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsiq_nav_utc_t *utc);
 /* The set gps_thread_ep() would use for a start time (gps.c:2588-2608): first set with a

@@ -204,7 +204,11 @@ int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsi
         e.orbit.omgkdot = e.nav.omgdot - kOmegaEarth;
     }
     gzclose(fp);
-    return g0.week >= 0 ? iset + 1 : iset;
+    // the reference returns ieph + 1 = 14 when it stops at a 14th hourly group (gps.c:1310-1311, 1500), one more than
+    // its array holds; callers index eph[nsets - 1] and eph[ieph + 1] with it.  Deliberate deviation: never report
+    // more sets than were stored.
+    const int nsets = g0.week >= 0 ? iset + 1 : iset;
+    return nsets > GPSIQ_EPHEM_SETS ? GPSIQ_EPHEM_SETS : nsets;
 }
 
 int gpsiq_rinex_select(const gpsiq_rinex_eph_t *eph, int nsets, int week, double sec)

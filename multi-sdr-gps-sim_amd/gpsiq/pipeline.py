@@ -145,7 +145,9 @@ class RunAheadAllocating:
                             self.trk[i]["prn"] = sv + 1
                             self.orbit[i] = e["orbit"]
                             self.sbf[i] = nav_subframes(e["nav"], self.utc, self.alm)               # gps.c:2190
-                            self.nav[i] = np.zeros((), dtype=NAV_STATE_DTYPE)
+                            ipage = self.nav[i]["ipage"]          # chan[i].ipage survives release and re-allocation:
+                            self.nav[i] = np.zeros((), dtype=NAV_STATE_DTYPE)      # only generateNavMsg ever touches it
+                            self.nav[i]["ipage"] = ipage                          # (gps.c:2137-2139)
                             nav_message(self.sbf[i], self.week, t, True, self.nav[i:i + 1])          # gps.c:2193
                             self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
                             self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
@@ -177,11 +179,15 @@ class RunAheadAllocating:
                             self.orbit[i] = e["orbit"]
                 break
 
-    def descriptors(self, xyz, gain_x2=False, nthreads=0):
+    def descriptors(self, xyz, carr_phase=None, gain_x2=False, nthreads=0):
         """As RunAhead.descriptors.  carr_phase of every block is the value allocateChannel() gave the
         channel's current satellite: the library re-seeds a slot from it whenever the slot's PRN changes
-        and carries the phase itself otherwise."""
+        and carries the phase itself otherwise.  carr_phase: when a scenario is rendered in several
+        descriptors() + generate_batch() calls, what the previous generate_batch handed out (carr_out); it
+        goes into block 0 for the slots that still hold the satellite they held in the previous call's last
+        block, so the run continues exactly (slots re-allocated in between start from their allocation)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        first_prn = self.trk["prn"].copy()
         out = []
         for b0, b1, roll in epoch_plan(gps_time_after(self.sec, self.blocks_done), len(xyz)):
             t = gps_time_after(self.sec, self.blocks_done)
@@ -201,4 +207,10 @@ class RunAheadAllocating:
                         self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
                 self.refresh_ephemeris(t_roll)                           # gps.c:2889-2906
                 self.nsat.append(self.allocate(t_roll))                  # gps.c:2909
-        return np.concatenate(out) if out else np.zeros((0, self.nchan), dtype=CHAN_DTYPE)
+        desc = np.concatenate(out) if out else np.zeros((0, self.nchan), dtype=CHAN_DTYPE)
+        if len(desc):
+            if carr_phase is not None and getattr(self, "_prn_at_end", None) is not None:
+                keep = (first_prn > 0) & (first_prn == self._prn_at_end)
+                desc["carr_phase"][0] = np.where(keep, np.asarray(carr_phase, dtype=np.float64), desc["carr_phase"][0])
+            self._prn_at_end = desc["prn"][-1].copy()
+        return desc

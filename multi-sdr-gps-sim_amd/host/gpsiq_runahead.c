@@ -66,7 +66,11 @@ static int allocate(struct host_state *h, double t)
             for (int i = 0; i < h->nchan; ++i) {
                 if (h->trk[i].prn != 0) continue;
                 memset(&h->trk[i], 0, sizeof h->trk[i]);
-                memset(&h->nav[i], 0, sizeof h->nav[i]);
+                {   /* chan[i].ipage survives release and re-allocation of a slot: only generateNavMsg touches it (gps.c:2137-2139) */
+                    const int32_t ipage = h->nav[i].ipage;
+                    memset(&h->nav[i], 0, sizeof h->nav[i]);
+                    h->nav[i].ipage = ipage;
+                }
                 h->trk[i].prn = sv + 1;
                 h->orbit[i] = e->orbit;
                 if (gpsiq_nav_subframes(&e->nav, &h->utc, NULL, h->sbf[i]) != GPSIQ_OK) return -1;          /* gps.c:2190 */

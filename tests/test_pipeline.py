@@ -284,3 +284,73 @@ def test_c_runahead_program_equals_the_python_pipeline(oracle, tmp_path):
     q = oracle.quantize_blocks(desc, fs, ns)
     for b in (0, 99, 100, 399, 400, 429):
         assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, SC08)), b
+
+
+def late_scenario(tmp_path, nblocks, sec=270000.0, seed=11):
+    """Nine satellites that stay up, one that sets between the refreshes at 450 s and 480 s and one that rises
+    between those at 510 s and 540 s: with ten channels the riser can only take the slot the setter gave up,
+    and it takes it when that slot's page counter stands at 17, i.e. at the iono/UTC page 18 of subframe 4."""
+    from gpsiq.scenario import _elevation_deg, synth_constellation
+    high = synth_constellation(9, TOKYO, sec, seed=seed, min_elev_deg=20.0)
+    cand = synth_constellation(1500, TOKYO, sec, seed=seed + 100, min_elev_deg=-4.0, max_elev_deg=4.0)
+    def up(e, t):                                                 # what allocateChannel() will see at the refresh at sec + t
+        return gpsiq.sat_visibility(e, WEEK, sec + t, TOKYO)[0]
+    near = [e for e in cand if abs(_elevation_deg(e, sec + 500.0, TOKYO)) < 1.0]
+    setter = [e for e in near if up(e, 0) and up(e, 450) and not up(e, 480) and not up(e, 600)]
+    riser = [e for e in near if not up(e, 0) and not up(e, 510) and up(e, 540) and up(e, 600)]
+    assert setter and riser
+    orbits = np.concatenate([high, np.array(setter[:1]), np.array(riser[:1])])
+    recs = synth_rinex_records(len(orbits), TOKYO, WEEK, sec, seed=seed, sets=2, eph=orbits)
+    path = write_rinex_nav(str(tmp_path / "late.21n"), recs, UTC, 2)
+    eph, utc, n = gpsiq.rinex_read(path, 2)
+    ieph = gpsiq.rinex_select(eph, n, WEEK, sec)
+    xyz = np.repeat(TOKYO[None, :], nblocks + 1, axis=0)
+    return path, eph[:n], ieph, utc, xyz, sec
+
+
+def test_subframe_page_counter_survives_reallocation(ref, tmp_path):
+    """chan[i].ipage is only ever advanced by generateNavMsg (gps.c:2137-2139): a slot that is released after
+    16 refreshes and re-allocated later continues with the subframe 4/5 page it had reached -- here the
+    iono/UTC page 18 -- it does not start over at page 1.  6 000 blocks = 20 refreshes, ten channels, all in use."""
+    from gpsiq.pipeline import RunAheadAllocating
+    nblocks, nchan = 6000, 10
+    _, eph, ieph, utc, xyz, sec = late_scenario(tmp_path, nblocks)
+    assert utc["vflg"] == 1
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
+    desc = ra.descriptors(xyz[1:])
+    want, nsat, _ = ref.run_host(eph, ieph, utc, WEEK, sec, xyz, nchan)
+    prn = desc["prn"]
+    reused = [(b, c) for b in range(1, nblocks) for c in range(nchan) if prn[b, c] > 0 and prn[b - 1, c] == 0]
+    released = [(b, c) for b in range(1, nblocks) for c in range(nchan) if prn[b, c] == 0 and prn[b - 1, c] > 0]
+    assert released == [(4800, reused[0][1])] and len(reused) == 1 and reused[0][0] > 4800, (released, reused)   # gone at the 16th refresh
+    assert list(nsat) == ra.nsat
+    for f in ("prn", "iword", "ibit", "icode", "f_carr", "f_code", "code_phase", "gain", "dwrd", "carr_phase"):
+        assert desc[f].tobytes() == want[f].tobytes(), f
+    # and the words really depend on where the counter stands: a fresh counter gives other words
+    b, c = reused[0]
+    fresh = RunAheadAllocating(eph, utc, nchan, WEEK, gps_time_after(sec, b), xyz[0], ieph=ieph)
+    slot = [i for i in range(nchan) if fresh.trk[i]["prn"] == prn[b, c]]
+    assert slot and fresh.trk[slot[0]]["dwrd"].tobytes() != desc["dwrd"][b, c].tobytes()
+
+
+def test_split_batches_continue_the_carrier(tmp_path):
+    """RunAheadAllocating.descriptors(carr_phase=...): a scenario rendered in several calls hands the phase
+    the previous generate_batch returned to the slots that kept their satellite, the allocation's phase to
+    the slots (re-)allocated at the refresh in between; everything else equals the single call."""
+    from gpsiq.pipeline import RunAheadAllocating
+    nblocks, nchan = 900, 16
+    _, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=6)
+    whole = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph).descriptors(xyz[1:])
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
+    cut = 300                                                   # right at a refresh: slots change hands here
+    assert (whole["prn"][cut] != whole["prn"][cut - 1]).any()
+    a = ra.descriptors(xyz[1:1 + cut])
+    handed = np.arange(nchan) * 0.01 + 0.005                    # stands for generate_batch's carr_out
+    b = ra.descriptors(xyz[1 + cut:], carr_phase=handed)
+    assert a.tobytes() == whole[:cut].tobytes()
+    kept = (whole["prn"][cut] == whole["prn"][cut - 1]) & (whole["prn"][cut] > 0)
+    assert kept.any() and not kept.all()
+    assert np.array_equal(b["carr_phase"][0][kept], handed[kept])
+    assert np.array_equal(b["carr_phase"][0][~kept], whole["carr_phase"][cut][~kept])
+    b["carr_phase"][0] = whole["carr_phase"][cut]
+    assert b.tobytes() == whole[cut:].tobytes()

