@@ -320,6 +320,16 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
                         const double *xyz, int nblocks, int nchan, int gain_x2,
                         gpsiq_track_t *trk, gpsiq_chan_t *out, int nthreads);
 
+/* The same over several navigation-message epochs in ONE threaded pass (a run-ahead host refreshes the word
+ * buffers every 30 s, gps.c:2878-2885, but the ranges -- the expensive part -- do not depend on them): epoch e
+ * covers blocks [first_block[e], first_block[e+1]) (first_block[0] = 0, the last epoch ends at nblocks) and takes
+ * dwrd / g0 from trk_epochs[e][c]; prn, rho0 and carr_phase come from trk_epochs[0], whose rho0 is updated to the
+ * state after the last block.  Every epoch must hold the same satellites (one allocation per call). */
+int gpsiq_refresh_epochs(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                         const double *xyz, int nblocks, int nchan, int gain_x2,
+                         gpsiq_track_t *trk_epochs /* [nepochs][nchan] */, const int *first_block /* [nepochs] */,
+                         int nepochs, gpsiq_chan_t *out, int nthreads);
+
 /* ---- navigation message words ------------------- */
 /* The 60-word rolling buffer dwrd[] the sample loop reads its data bits from
  * (gps.c:2811) is built by the reference from the broadcast ephemeris: eph2sbf()

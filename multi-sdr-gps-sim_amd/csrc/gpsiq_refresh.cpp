@@ -235,6 +235,9 @@ struct Job {
     Range *rng;            // [nblocks + 1][nchan], row 0 = the state before the batch
     gpsiq_chan_t *out;
     int pass;
+    // several navigation-message epochs in one batch: epoch e covers blocks [first[e], first[e+1]) and reads its
+    // word buffer and g0 from trk[e*nchan + c]; prn / rho0 / carr_phase always come from trk[0..nchan)
+    const int *first = nullptr; int nepochs = 1;
 };
 
 void work(void *p, int b0, int b1)
@@ -247,6 +250,9 @@ void work(void *p, int b0, int b1)
                 if (j.trk[c].prn > 0)
                     j.rng[(size_t) (b + 1) * j.nchan + c] = range_to(j.eph[c], *j.iono, j.t[b + 1].sec, j.xyz + 3 * (size_t) b, site);
         } else {                                             // code phase, Doppler, gain
+            int ep = 0;
+            if (j.nepochs > 1) { while (ep + 1 < j.nepochs && j.first[ep + 1] <= b) ++ep; }
+            const gpsiq_track_t *nav = j.trk + (size_t) ep * j.nchan;      // word buffer and g0 of this block's epoch
             for (int c = 0; c < j.nchan; ++c) {
                 gpsiq_chan_t &o = j.out[(size_t) b * j.nchan + c];
                 std::memset(&o, 0, sizeof o);
@@ -259,8 +265,8 @@ void work(void *p, int b0, int b1)
                 const double rhorate = (r1.prange - r0.prange) / 0.1;
                 o.f_carr = -rhorate / kLambdaL1;
                 o.f_code = kCodeFreq + o.f_carr * kCarrToCode;
-                double dtg = t0.sec - j.trk[c].g0_sec;
-                dtg += (double) (t0.week - j.trk[c].g0_week) * kSecWeek;
+                double dtg = t0.sec - nav[c].g0_sec;
+                dtg += (double) (t0.week - nav[c].g0_week) * kSecWeek;
                 const double ms = ((dtg + 6.0) - r0.prange / kC) * 1000.0;
                 int ims = (int) ms;
                 o.code_phase = (ms - (double) ims) * GPSIQ_CA_SEQ_LEN;
@@ -274,7 +280,7 @@ void work(void *p, int b0, int b1)
                 double g = path_loss * j.ant_pat[ibs < 0 ? 0 : ibs > 36 ? 36 : ibs];
                 if (j.gain_x2) g *= 2;
                 o.gain = g;
-                std::memcpy(o.dwrd, j.trk[c].dwrd, sizeof o.dwrd);
+                std::memcpy(o.dwrd, nav[c].dwrd, sizeof o.dwrd);
             }
         }
     }
@@ -326,9 +332,37 @@ int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const d
     return el * kR2D > elv_mask_deg ? 1 : 0;                                 // gps.c:2158-2161
 }
 
+static int refresh_impl(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                        const double *xyz, int nblocks, int nchan, int gain_x2,
+                        gpsiq_track_t *trk, const int *first, int nepochs, gpsiq_chan_t *out, int nthreads);
+
 int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
                         const double *xyz, int nblocks, int nchan, int gain_x2,
                         gpsiq_track_t *trk, gpsiq_chan_t *out, int nthreads)
+{
+    return refresh_impl(eph, iono, week, sec, xyz, nblocks, nchan, gain_x2, trk, nullptr, 1, out, nthreads);
+}
+
+int gpsiq_refresh_epochs(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                         const double *xyz, int nblocks, int nchan, int gain_x2,
+                         gpsiq_track_t *trk_epochs, const int *first_block, int nepochs,
+                         gpsiq_chan_t *out, int nthreads)
+{
+    if (!first_block || nepochs < 1) return fail(GPSIQ_E_ARG, "bad epoch list");
+    for (int e = 0; e < nepochs; ++e)
+        if (first_block[e] < 0 || first_block[e] > nblocks || (e == 0 ? first_block[0] != 0 : first_block[e] < first_block[e - 1]))
+            return fail(GPSIQ_E_ARG, "epoch %d starts at block %d: not an ascending cover of [0, %d)", e, first_block[e], nblocks);
+    if (trk_epochs)
+        for (int e = 1; e < nepochs; ++e)
+            for (int c = 0; c < nchan && c < GPSIQ_MAX_CHAN; ++c)
+                if (trk_epochs[(size_t) e * nchan + c].prn != trk_epochs[c].prn)
+                    return fail(GPSIQ_E_ARG, "epoch %d slot %d holds another satellite: one call covers one allocation", e, c);
+    return refresh_impl(eph, iono, week, sec, xyz, nblocks, nchan, gain_x2, trk_epochs, first_block, nepochs, out, nthreads);
+}
+
+static int refresh_impl(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                        const double *xyz, int nblocks, int nchan, int gain_x2,
+                        gpsiq_track_t *trk, const int *first, int nepochs, gpsiq_chan_t *out, int nthreads)
 {
     if (!eph || !iono || !xyz || !trk || !out) return fail(GPSIQ_E_ARG, "null argument");
     if (nchan < 1 || nchan > GPSIQ_MAX_CHAN || nblocks < 0) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
@@ -349,7 +383,7 @@ int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
     }
     t[0] = GpsTime{week, sec};
 
-    Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0};
+    Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0, first, nepochs};
     // pass 0 costs ~4 us per block (16 satellite positions with light-time iteration), waking the pool ~20 us:
     // 64 blocks per thread keep a 300-block epoch of the run-ahead loop (gpsiq/pipeline.py) on several cores
     parallel_for(nblocks, nthreads, 64, work, &job);

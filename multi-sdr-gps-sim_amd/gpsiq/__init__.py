@@ -89,6 +89,7 @@ _host_free = _sig("gpsiq_host_free", None, _vp)
 _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
 _sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
+_refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
 _nav_parity = _sig("gpsiq_nav_parity", C.c_uint32, C.c_uint32, _i)
 _nav_subframes = _sig("gpsiq_nav_subframes", _i, _vp, _vp, _vp, _vp)
 _nav_message = _sig("gpsiq_nav_message", _i, _vp, _i, _d, _i, _vp)
@@ -226,6 +227,24 @@ def refresh_batch(eph, iono, week, sec, xyz, trk, gain_x2=False, nthreads=0, out
     assert out.dtype == CHAN_DTYPE and out.shape == (len(xyz), len(trk)) and out.flags.c_contiguous
     _check(_refresh_batch(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), len(trk), int(bool(gain_x2)),
                           _p(trk), _p(out), int(nthreads)))
+    return out
+
+
+def refresh_epochs(eph, iono, week, sec, xyz, trk_epochs, first_block, gain_x2=False, nthreads=0, out=None):
+    """gpsiq_refresh_epochs: refresh_batch over several navigation-message epochs in one threaded pass.
+    trk_epochs [nepochs][nchan] (TRACK_DTYPE): epoch e's word buffer and g0; first_block [nepochs]."""
+    eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+    iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    assert trk_epochs.dtype == TRACK_DTYPE and trk_epochs.flags.c_contiguous and trk_epochs.ndim == 2
+    first = np.ascontiguousarray(first_block, dtype=np.int32)
+    ne, nc = trk_epochs.shape
+    assert len(first) == ne
+    if out is None:
+        out = np.empty((len(xyz), nc), dtype=CHAN_DTYPE)
+    assert out.dtype == CHAN_DTYPE and out.shape == (len(xyz), nc) and out.flags.c_contiguous
+    _check(_refresh_epochs(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), nc, int(bool(gain_x2)),
+                           _p(trk_epochs), _p(first), ne, _p(out), int(nthreads)))
     return out
 
 

@@ -14,7 +14,7 @@ Every call below is one C-ABI entry point; this module is only the loop around t
 import numpy as np
 
 from . import (CHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_subframes,
-               refresh_batch, sat_visibility, track_init)
+               refresh_batch, refresh_epochs, sat_visibility, track_init)
 
 
 def gps_time_after(sec, steps):
@@ -93,13 +93,25 @@ class RunAhead:
         (carr_out) when continuing a run; None on the first call = the allocation's value.
         Only block 0's carr_phase is read by the library, which carries it exactly from there."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
-        desc = np.empty((len(xyz), len(self.svs)), dtype=CHAN_DTYPE)      # every epoch writes its own rows, once
-        for b0, b1, roll in epoch_plan(gps_time_after(self.sec, self.blocks_done), len(xyz)):
-            t = gps_time_after(self.sec, self.blocks_done)
-            refresh_batch(self.orbit, self.iono, self.week, t, xyz[b0:b1], self.trk, gain_x2=gain_x2, nthreads=nthreads, out=desc[b0:b1])
-            self.blocks_done += b1 - b0
+        # The satellites are fixed, so the whole call is ONE threaded pass in C (gpsiq_refresh_epochs): the word
+        # buffers of the 30 s epochs it crosses are rolled first (cheap), the ranges -- the expensive part -- do
+        # not depend on them.
+        t_start = gps_time_after(self.sec, self.blocks_done)
+        plan = epoch_plan(t_start, len(xyz))
+        if not plan:
+            return np.zeros((0, len(self.svs)), dtype=CHAN_DTYPE)
+        trk_ep = np.empty((len(plan), len(self.svs)), dtype=TRACK_DTYPE)
+        done = self.blocks_done
+        for e, (b0, b1, roll) in enumerate(plan):
+            trk_ep[e] = self.trk
+            done += b1 - b0
             if roll:                                                          # gps.c:2878-2885
-                self._roll(gps_time_after(self.sec, self.blocks_done))
+                self._roll(gps_time_after(self.sec, done))
+        desc = refresh_epochs(self.orbit, self.iono, self.week, t_start, xyz, trk_ep, [p[0] for p in plan],
+                              gain_x2=gain_x2, nthreads=nthreads)
+        for f in ("rho0_week", "rho0_sec", "rho0_range"):                     # chan.rho0 = rho1 (gps.c:2063)
+            self.trk[f] = trk_ep[0][f]
+        self.blocks_done = done
         # the loop's own state (gps.c:2821), not the host model's; only block 0's value is read by the library
         # (it carries the phase itself from there), the reference keeps it in chan[i] between blocks
         if len(desc):

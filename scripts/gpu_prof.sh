@@ -4,7 +4,7 @@ REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline"   # the default command: --gpus 1 --steps 20 --warmup 3
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-extra"   # the default workload (--gpus 1 --steps 20 --warmup 3, 18 launches per step) without the extra legs
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
 tail -3 $OUT/kt.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
@@ -14,6 +14,6 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_L
 find $OUT -type f | head -50
 du -sh $OUT
 # summarise on the box too (the .db files can be large; only the text summaries are needed)
-( cd $REPO && python scripts/prof_summary.py gpurun_out/prof ${PROF_TAG:-r01_final} > $OUT/summary.log 2>&1; tail -3 $OUT/summary.log )
+( cd $REPO && python scripts/prof_summary.py gpurun_out/prof ${PROF_TAG:-r02} > $OUT/summary.log 2>&1; tail -3 $OUT/summary.log )
 find $OUT -name "*.db" -size +8M -delete
-mkdir -p $REPO/gpurun_out/profiles_out; cp $REPO/profiles/${PROF_TAG:-r01_final}_* $REPO/profiles/pmc_traffic.json $REPO/gpurun_out/profiles_out/
+mkdir -p $REPO/gpurun_out/profiles_out; cp $REPO/profiles/${PROF_TAG:-r02}_* $REPO/profiles/pmc_traffic.json $REPO/gpurun_out/profiles_out/

@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 os.makedirs("profiles", exist_ok=True)
 
 
@@ -24,9 +24,22 @@ for db in sorted(glob.glob(os.path.join(src, "kt*", "*.db"))):
     lines.append(f"{'kernel':<70} {'calls':>6} {'total_ns':>14} {'avg_ns':>14} {'pct':>7}")
     for name, calls, tot, avg, pct in q(db, "select name,total_calls,total_duration,average,percentage from top_kernels"):
         lines.append(f"{name[:70]:<70} {calls:>6} {tot:>14.0f} {avg:>14.1f} {pct:>7.2f}")
-    lines.append("per dispatch: kernel, grid, wg, vgpr, sgpr, lds, duration_ns")
-    for r in q(db, "select name,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,duration from kernels order by start"):
-        lines.append("  " + " ".join(str(x)[:60] for x in r))
+    lines.append("per dispatch: kernel, grid, wg, vgpr, sgpr, lds, duration_ns (the first 40 and the last 10 dispatches)")
+    rows = q(db, "select name,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,duration from kernels order by start")
+    for i, r in enumerate(rows):
+        if i < 40 or i >= len(rows) - 10:
+            lines.append("  " + " ".join(str(x)[:60] for x in r))
+        elif i == 40:
+            lines.append(f"  ... {len(rows) - 50} more dispatches ...")
+    # the steady state of the dominant kernel: all dispatches of its most frequent grid shape after the first 20
+    main = [r for r in rows if "synth_tile" in r[0]]
+    if main:
+        from collections import Counter
+        shape = Counter((r[0], r[1]) for r in main).most_common(1)[0][0]
+        d = [r[6] for r in main if (r[0], r[1]) == shape]
+        steady = d[20:] if len(d) > 40 else d
+        lines.append(f"dominant kernel {shape[0][:60]} grid {shape[1]}: {len(d)} dispatches, mean {sum(d) / len(d):.0f} ns; "
+                     f"after the first 20: mean {sum(steady) / len(steady):.0f} ns, min {min(steady)} ns, max {max(steady)} ns")
 open(f"profiles/{tag}_kernel_trace_stats.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 

@@ -59,6 +59,27 @@ __global__ __launch_bounds__(256) void ub(uint32_t *out, int iters, uint64_t s0,
             : [ph] "v"((uint32_t) (Pn >> 32)), [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [mask] "s"(mask), [sp] "s"(s0), [sq] "s"(s1));
 #define PA2(Pa, Qa, Pb, Qb) PA(Pa, Qa, "%[a]") PA(Pb, Qb, "%[k]") asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(k));
             PA2(P0, Q0, P1, Q1) PA2(P2, Q2, P3, Q3) PA2(P0, Q0, P1, Q1) PA2(P2, Q2, P3, Q3)
+        } else if (MODE == 5) {    // lane = channel (north_star's "wavefront-level sum over visible channels"): a wave holds
+            // 4 samples x 16 channels; the same plain-add core per lane, but the NCO steps and the LUT base are per-lane
+            // VGPRs, and the channel sum is a 16-lane DPP reduction (row_shr 8,4,2,1) per 4 samples.  One trip below =
+            // 8 wave-steps = 8 x 64 channel-samples, the same count the lane = sample modes process per trip.
+            uint64_t v0 = s0 + threadIdx.x, v1 = s1 + threadIdx.x;
+            uint32_t base = (threadIdx.x & 15u) * 2048u;
+#define LC(Pn, Qn) asm volatile( \
+            "v_lshrrev_b32_sdwa %[a], %[qh], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n" \
+            "v_lshl_add_u32 %[a], %[a], 26, %[ph]\n" \
+            "v_and_b32_sdwa %[a], %[a], %[mask] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n" \
+            "v_add_u32 %[a], %[a], %[base]\n" \
+            "v_lshl_add_u64 %[p], %[p], 0, %[sp]\n" \
+            "v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" \
+            "v_add_u32_dpp %[k], %[a], %[a] row_shr:8 row_mask:0xf bank_mask:0xf\n" \
+            "v_add_u32_dpp %[k], %[k], %[k] row_shr:4 row_mask:0xf bank_mask:0xf\n" \
+            "v_add_u32_dpp %[k], %[k], %[k] row_shr:2 row_mask:0xf bank_mask:0xf\n" \
+            "v_add_u32_dpp %[k], %[k], %[k] row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+            "v_add_u32 %[acc], %[acc], %[k]\n" \
+            : [p] "+v"(Pn), [q] "+v"(Qn), [a] "+v"(a), [k] "+v"(k), [acc] "+v"(acc) \
+            : [ph] "v"((uint32_t) (Pn >> 32)), [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [mask] "s"(mask), [sp] "v"(v0), [sq] "v"(v1), [base] "v"(base));
+            LC(P0, Q0) LC(P1, Q1) LC(P2, Q2) LC(P3, Q3) LC(P0, Q0) LC(P1, Q1) LC(P2, Q2) LC(P3, Q3)
         } else if (MODE == 3) {    // NCO adds with VGPR steps instead of SGPR pairs
             uint64_t v0 = s0 + threadIdx.x, v1 = s1 + threadIdx.x;
 #define TWOV(Pn, Qn) asm volatile("v_lshl_add_u64 %[p], %[p], 0, %[sp]\n v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" : [p] "+v"(Pn), [q] "+v"(Qn) : [sp] "v"(v0), [sq] "v"(v1));
@@ -101,6 +122,7 @@ int main()
         run<3>("2x v_lshl_add_u64 (VGPR-pair step)", w, 2);
         run<2>("sdwa,lshr,bfe,or,pk_mad", w, 5);
         run<4>("plain-add core: sdwa lshr,lshl_add,sdwa and,1/2 add3,2x lshl_add_u64", w, 5);
+        run<5>("lane = channel: the same core + LUT base + 4 DPP row adds per 4 samples", w, 11);
     }
     return 0;
 }
