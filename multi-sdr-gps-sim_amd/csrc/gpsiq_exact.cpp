@@ -13,7 +13,8 @@
 //     binade's ulp u and the addition adds the constant S = rnd(c/u)*u (ties to even: constant from the
 //     second addition inside the binade on, when the parity has settled).  Nco::advance() does the
 //     reference's own operation (a real double addition, then the wrap rule) at binade crossings and
-//     wraps and jumps over the steady run in between with one integer division: about a dozen pieces
+//     wraps and jumps over the steady run in between with one integer division (S straight from the addend's
+//     mantissa; the rare exact-tie binades are probed with two real additions): about a dozen pieces
 //     per carrier cycle or code period.
 //   * Only samples whose fixed-point phase lies within the drift bound of a boundary can differ:
 //     |double path - real arithmetic| <= n * 2^-54 cycle (carrier, values < 1) or n * 2^-44 chip (code,
@@ -62,38 +63,79 @@ struct Nco {
         return y;
     }
 
+    // Largest j such that x, x + S, ..., x + j*S (S = dm ulps of x's binade) all stay inside x's binade and short of
+    // the wrap, capped at `cap`.  mx = x's 53-bit mantissa.
+    inline long run_length(int64_t mx, int64_t dm, uint64_t expo, long cap) const
+    {
+        if (dm > 0) {
+            int64_t lim = (int64_t) 1 << 53;            // first mantissa of the next binade
+            // the wrap comes before the binade ends only in the code phase's top binade [512, 1024):
+            // 1023 = 1023 * 2^43 ulps there (the carrier's top binade [0.5, 1) ends exactly at its wrap)
+            if (kind == 0 && expo == 1023 + 9) lim = (int64_t) GPSIQ_CA_SEQ_LEN << 43;
+            const int64_t j = (lim - 1 - mx) / dm;
+            return j < cap ? (long) j : cap;
+        }
+        if (dm < 0) {
+            const int64_t j = (mx - ((int64_t) 1 << 52)) / -dm;
+            return j < cap ? (long) j : cap;
+        }
+        return cap;                                      // the addend is below half an ulp: the phase stands still
+    }
+
     // Move to sample `target` (>= n).
     void advance(long target)
     {
+        const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
+        const int64_t ec = (int64_t) (bc >> 52), mc = (int64_t) ((bc & kMant) | (kMant + 1));
+        const bool neg = c < 0.0;
         while (n < target) {
+            const uint64_t bx = bits_of(x);
+            const int64_t ex = (int64_t) (bx >> 52);
+            if (ex != 0 && ec != 0 && ex >= ec) {
+                // x + c inside x's binade is x + S with S = rnd(c/u) ulps, whatever x is -- unless c/u ends in exactly
+                // one half, where the rounding goes to even and depends on x's parity (handled by probing below)
+                const int64_t shift = ex - ec;
+                int64_t dm = 0;
+                bool tie = false;
+                if (shift == 0) dm = mc;
+                else if (shift <= 53) {
+                    dm = shift == 53 ? 0 : mc >> shift;
+                    const int64_t rem = mc & (((int64_t) 1 << shift) - 1), half = (int64_t) 1 << (shift - 1);
+                    if (rem > half) ++dm;
+                    else if (rem == half) tie = true;
+                }
+                if (!tie) {
+                    const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1));
+                    const long cap = target - n;
+                    const long run = run_length(mx, neg ? -dm : dm, (uint64_t) ex, cap);
+                    if (run > 0) {
+                        x = from_bits((bx & ~kMant) | ((uint64_t) (mx + (int64_t) run * (neg ? -dm : dm)) & kMant));
+                        n += run;
+                        if (run == cap) return;
+                    }
+                    // the next addition leaves the binade or wraps: the reference's own operation
+                    int w;
+                    x = step(x, &w); ++n; wraps += w;
+                    continue;
+                }
+            }
+            // zero / subnormal, a binade below the addend's, or the tie case: real additions, and a jump once two
+            // consecutive additions inside one binade have shown the settled step
             int wy;
             const double y = step(x, &wy);
-            const uint64_t bx = bits_of(x), by = bits_of(y);
-            if (wy || (bx >> 52) != (by >> 52) || (bx >> 52) == 0) {     // a wrap, a binade crossing, zero/subnormal: one step
+            const uint64_t by = bits_of(y);
+            if (wy || (bx >> 52) != (by >> 52) || (bx >> 52) == 0) {
                 x = y; ++n; wraps += wy;
                 continue;
             }
-            // y came out of an addition inside the binade: the step is steady from y on
             if (n + 1 == target) { x = y; ++n; return; }
             int wz;
             const double z = step(y, &wz);
             const uint64_t bz = bits_of(z);
             if (wz || (bz >> 52) != (by >> 52)) { x = z; n += 2; wraps += wz; continue; }
             const int64_t my = (int64_t) ((by & kMant) | (kMant + 1)), mz = (int64_t) ((bz & kMant) | (kMant + 1));
-            const int64_t dm = mz - my;
-            long run = target - (n + 1);                    // samples n+1 .. n+1+run all of the form y + j*S
-            if (dm > 0) {
-                int64_t lim = (int64_t) 1 << 53;            // first mantissa of the next binade
-                // the wrap comes before the binade ends only in the code phase's top binade [512, 1024):
-                // 1023 = 1023 * 2^43 ulps there (the carrier's top binade [0.5, 1) ends exactly at its wrap)
-                if (kind == 0 && (by >> 52) == 1023 + 9) lim = (int64_t) GPSIQ_CA_SEQ_LEN << 43;
-                const int64_t j = (lim - 1 - my) / dm;
-                if (j < run) run = (long) j;
-            } else if (dm < 0) {
-                const int64_t j = (my - ((int64_t) 1 << 52)) / -dm;
-                if (j < run) run = (long) j;
-            }
-            x = from_bits((by & ~kMant) | ((uint64_t) (my + (int64_t) run * dm) & kMant));
+            const long run = run_length(my, mz - my, by >> 52, target - (n + 1));    // samples n+1 .. n+1+run are y + j*S
+            x = from_bits((by & ~kMant) | ((uint64_t) (my + (int64_t) run * (mz - my)) & kMant));
             n += 1 + run;
         }
     }

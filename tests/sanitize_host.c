@@ -45,6 +45,43 @@ int main(int argc, char **argv)
     CHECK(gpsiq_quantize_batch(ch, 0, nc, 2.6e6, 260000, q, NULL, carry) == GPSIQ_OK);
     int b0, b1;
     CHECK(gpsiq_shard_range(35999, 7, 8, &b0, &b1) == GPSIQ_OK && b1 == 35999);
+    ch[1234 * nc + 5].icode = 3;
+
+    /* ---- GPSIQ_NCO_REFERENCE host half: carrier walk on the channel threads, candidate search, patches;
+     *      slots that change satellite, unused slots, a phase on a LUT boundary with a tiny step (every sample
+     *      is then a candidate), too small a patch buffer ---- */
+    {
+        const int nbr = 40;
+        gpsiq_chan_t *cr = calloc((size_t) nbr * nc, sizeof *cr);
+        memcpy(cr, ch, sizeof *cr * (size_t) nbr * nc);
+        for (int b = 0; b < nbr; ++b)
+            for (int c = 0; c < nc; ++c) {
+                gpsiq_chan_t *e = &cr[b * nc + c];
+                e->prn = c == 3 ? 0 : (c == 5 && b >= 17 ? 29 : c + 1);
+                e->f_carr = cr[c].f_carr + 0.4 * b; e->f_code = 1.023e6 + e->f_carr / 1540.0;
+                if (c == 7) { e->f_carr = -1e-9; e->f_code = 1.023e6; e->carr_phase = 0.5; }
+                if (c == 8) { e->f_carr = 0.0; e->f_code = 1.023e6; e->carr_phase = 0.0; }
+            }
+        static gpsiq_patch_t patches[1 << 16];
+        int np = -1; double carr_end[GPSIQ_MAX_CHAN];
+        for (int fsk = 0; fsk < 2; ++fsk) {
+            const double fs = fsk ? 25e6 : 2.6e6; const int ns = fsk ? 250000 : 26000;     /* short blocks: the walk does not care */
+            CHECK(gpsiq_reference_batch(cr, nbr, nc, fs, ns, q, patches, 1 << 16, &np, carr_end) == GPSIQ_OK && np >= 0);
+            for (int i = 1; i < np; ++i)
+                CHECK(patches[i - 1].block < patches[i].block || (patches[i - 1].block == patches[i].block && patches[i - 1].sample <= patches[i].sample));
+            for (int i = 0; i < np; ++i) CHECK(patches[i].block < (uint32_t) nbr && patches[i].sample < (uint32_t) ns && patches[i].lut < 512 && patches[i].slot < nc);
+            if (np > 1) { int np2 = 0; CHECK(gpsiq_reference_batch(cr, nbr, nc, fs, ns, q, patches, 1, &np2, carr_end) == GPSIQ_E_RANGE && np2 == np); }
+        }
+        gpsiq_shard_carry_t sc[2][GPSIQ_MAX_CHAN];
+        CHECK(gpsiq_quantize_batch(cr, 20, nc, 2.6e6, 26000, q, NULL, NULL) == GPSIQ_OK);
+        CHECK(gpsiq_quantize_batch(cr + 20 * nc, 20, nc, 2.6e6, 26000, q + 20 * nc, NULL, NULL) == GPSIQ_OK);
+        CHECK(gpsiq_shard_carry(q, 20, nc, 26000, sc[0]) == GPSIQ_OK && gpsiq_shard_carry(q + 20 * nc, 20, nc, 26000, sc[1]) == GPSIQ_OK);
+        CHECK(gpsiq_shard_seed(q + 20 * nc, 20, nc, 26000, &sc[0][0], 1) == GPSIQ_OK);
+        gpsiq_qchan_t *whole = calloc((size_t) nbr * nc, sizeof *whole);
+        CHECK(gpsiq_quantize_batch(cr, nbr, nc, 2.6e6, 26000, whole, NULL, NULL) == GPSIQ_OK);
+        CHECK(memcmp(whole + 20 * nc, q + 20 * nc, sizeof *whole * 20 * nc) == 0);
+        free(whole); free(cr);
+    }
 
     /* ---- fifo hand-off rules ---- */
     static int16_t store[4][520000];

@@ -53,7 +53,7 @@ def test_host_half_under_sanitizers(tmp_path, san):
     if "undefined" in san:
         flags.append("-fno-sanitize-recover=undefined")
     objs = []
-    for src in ("gpsiq_host.cpp", "gpsiq_refresh.cpp", "gpsiq_nav.cpp", "gpsiq_rinex.cpp"):
+    for src in ("gpsiq_host.cpp", "gpsiq_exact.cpp", "gpsiq_refresh.cpp", "gpsiq_nav.cpp", "gpsiq_rinex.cpp"):
         o = str(tmp_path / (src + ".o"))
         b = subprocess.run(["g++", "-std=c++17", *flags, "-c", os.path.join(csrc, src), "-o", o], capture_output=True, text=True)
         if b.returncode != 0:
