@@ -75,8 +75,11 @@ struct Nco {
             const int64_t j = (lim - 1 - mx) / dm;
             return j < cap ? (long) j : cap;
         }
+        // downwards the run must stay strictly above the binade's first value 2^52 ulps: a sum that falls below it
+        // is rounded on the finer grid of the binade underneath, so the last step onto (or from) 2^52 is a real addition
+        if (mx <= ((int64_t) 1 << 52) && c < 0.0) return 0;
         if (dm < 0) {
-            const int64_t j = (mx - ((int64_t) 1 << 52)) / -dm;
+            const int64_t j = (mx - ((int64_t) 1 << 52) - 1) / -dm;
             return j < cap ? (long) j : cap;
         }
         return cap;                                      // the addend is below half an ulp: the phase stands still
@@ -115,7 +118,9 @@ struct Nco {
                     }
                     // the next addition leaves the binade or wraps: the reference's own operation
                     int w;
-                    x = step(x, &w); ++n; wraps += w;
+                    const double y = step(x, &w);
+                    if (y == x && !w) { n = target; return; }    // e.g. exactly 2^k with a negative addend below a quarter ulp: stuck for good
+                    x = y; ++n; wraps += w;
                     continue;
                 }
             }

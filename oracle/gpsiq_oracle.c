@@ -438,7 +438,11 @@ static int walk(double x, double c, int kind, long nsamp, fsegs_t *v, double *x_
                 int64_t lim = (int64_t) 1 << 53;    /* next binade */
                 if (ldexp((double) lim, qz) > top) lim = (int64_t) ldexp(top, -qz);   /* the wrap comes first */
                 J = (long) ((lim - 1 - mz) / dm);
-            } else J = (long) ((mz - ((int64_t) 1 << 52)) / -dm);
+            } else {
+                /* downwards the run stays strictly above the binade's first value: a sum that falls below 2^52 ulps is
+                 * rounded on the finer grid of the binade underneath, so that step is left to a real addition */
+                J = mz > ((int64_t) 1 << 52) ? (long) ((mz - ((int64_t) 1 << 52) - 1) / -dm) : 0;
+            }
             if (n + 2 + J > nsamp) J = nsamp - (n + 2);
             int64_t mx, my; int qx, qy;
             split(x, &mx, &qx); split(y, &my, &qy);

@@ -290,21 +290,25 @@ def apply_patches(orc, q, out, patches, sample_size):
     closed form of include/gpsiq.h with the patched channels' (lut, neg) substituted."""
     sin512, cos512 = orc.tables()
     active = [c for c in range(len(q)) if q[c]["prn"] > 0]           # device order: active channels first
+    codes = {c: orc.codegen(int(q[c]["prn"])) for c in active}
+    by_sample = {}
+    for p in patches:
+        by_sample.setdefault(int(p["sample"]), {})[int(p["slot"])] = (int(p["lut"]), int(p["neg"]))
 
     def s16(v):
         v &= 0xFFFF
         return v - 65536 if v >= 32768 else v
 
-    for n in sorted(set(int(p["sample"]) for p in patches)):
+    for n, over in by_sample.items():
         acc_i = acc_q = 0
         for slot, c in enumerate(active):
             d = q[c]
-            idx = ((int(d["carr_phase"]) + int(d["carr_step"]) * n) % (1 << 59)) >> 50
-            a = int(d["chip0"]) + ((int(d["code_frac"]) + int(d["code_step"]) * n) >> 56)
-            neg = int(orc.codegen(int(d["prn"]))[a % 1023]) ^ ((int(d["nav_bits"]) >> ((int(d["icode"]) + a // 1023) // 20)) & 1)
-            for p in patches:
-                if int(p["sample"]) == n and int(p["slot"]) == slot:
-                    idx, neg = int(p["lut"]), int(p["neg"])
+            if slot in over:
+                idx, neg = over[slot]
+            else:
+                idx = ((int(d["carr_phase"]) + int(d["carr_step"]) * n) % (1 << 59)) >> 50
+                a = int(d["chip0"]) + ((int(d["code_frac"]) + int(d["code_step"]) * n) >> 56)
+                neg = int(codes[c][a % 1023]) ^ ((int(d["nav_bits"]) >> ((int(d["icode"]) + a // 1023) // 20)) & 1)
             tc, ts = int(int(cos512[idx]) * float(d["gain"])), int(int(sin512[idx]) * float(d["gain"]))
             acc_i += -tc if neg else tc
             acc_q += -ts if neg else ts

@@ -1,0 +1,68 @@
+"""GPSIQ_NCO_REFERENCE, host half, on the CPU: gpsiq_reference_batch (carrier walk, candidate search, patches)
++ the fixed-point oracle + the patches applied == the float loop (oracle_block_float, pinned to the reference in
+test_oracle_vs_ref.py), on random scenarios and on the corners of the double arithmetic."""
+import numpy as np
+import pytest
+
+import gpsiq
+from _oracle import apply_patches
+from gpsiq.abi import SC08, SC16
+from gpsiq.scenario import synth_blocks
+
+
+def float_chain(oracle, d, fs, ns, ss):
+    out, carr, prev = [], None, None
+    for b in range(len(d)):
+        db = d[b].copy()
+        if b:
+            db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+        o, carr = oracle.block_float(db, ns, fs, ss)
+        out.append(o)
+        prev = db["prn"].copy()
+    return np.stack(out), carr
+
+
+def product_chain(oracle, d, fs, ns, ss):
+    q, patches, carr = gpsiq.reference_blocks(d, fs, ns)
+    out = []
+    for b in range(len(d)):
+        o = oracle.block_fixed(q[b], ns, ss, seq=True)
+        apply_patches(oracle, q[b], o, patches[patches["block"] == b], ss)
+        out.append(o)
+    return np.stack(out), carr, patches
+
+
+@pytest.mark.parametrize("fs,ns,nchan,nb,ss,seed", [(2.6e6, 260000, 16, 6, SC16, 1), (25e6, 2500000, 16, 2, SC08, 3032),
+                                                    (10e6, 300000, 9, 5, SC16, 3), (1.2e6, 120000, 5, 4, SC08, 4)])
+def test_random_scenarios(oracle, fs, ns, nchan, nb, ss, seed):
+    d = synth_blocks(nb, nchan, seed=seed)
+    d["prn"][nb // 2:, 1] = 0
+    want, carr_want = float_chain(oracle, d, fs, ns, ss)
+    got, carr, _ = product_chain(oracle, d, fs, ns, ss)
+    assert np.array_equal(got, want)
+    act = d[-1]["prn"] > 0
+    assert np.array_equal(carr[act], carr_want[act])
+
+
+def test_corners_of_the_double_arithmetic(oracle):
+    """Phases exactly on a power of two with a negative step (the sum falls into the finer binade underneath), steps
+    below half / a quarter of an ulp (the phase moves only from a binade edge, or not at all), zero Doppler, phases on
+    LUT boundaries where every sample is a candidate, a step that is an exact tie, one chip per sample."""
+    d = synth_blocks(3, 12, seed=5)
+    d["f_carr"][:] = [0.0, -4999.7, 4999.7, 1e-9, -1e-9, 0.25, -1234.5, 3e-14, -3e-10, -1.2e-9, 2.6e6 / 2 ** 20, -2.6e6 / 2 ** 21]
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    d["carr_phase"][:] = [0.0, 0.0, 0.999999999999, 0.5, 0.5, 0.0, 1e-300, 0.75, 0.25, 0.125, 0.5 + 2.0 ** -53, 0.25]
+    d["code_phase"][0, :4] = [0.0, 1022.9999999999, 511.99999999999994, 512.0]
+    for fs, ns in ((2.6e6, 70001), (25e6, 20000), (2.6e6, 1), (2.6e6, 65), (1.023e6, 30000)):
+        want, carr_want = float_chain(oracle, d, fs, ns, SC16)
+        got, carr, patches = product_chain(oracle, d, fs, ns, SC16)
+        assert np.array_equal(got, want), (fs, ns)
+        assert np.array_equal(carr, carr_want), (fs, ns)
+        # and the oracle's own closed form of the double path agrees as well
+        cin = d[0]["carr_phase"].copy()
+        for b in range(3):
+            db = d[b].copy()
+            db["carr_phase"] = cin
+            o, cin = oracle.block_float_closed(db, ns, fs, SC16)
+            assert np.array_equal(o, want[b]), (fs, ns, b)
+        assert np.array_equal(cin, carr_want)
