@@ -221,6 +221,9 @@ def main():
         sys.exit(2)
     ensure_built()
     dry = args.dry_run
+    # the ranks of one node share its host cores: each one's library thread pool gets its share
+    if world > 1 and "GPSIQ_THREADS" not in os.environ:
+        os.environ["GPSIQ_THREADS"] = str(max(1, effective_cpus() // int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     fs, nchan, ss = args.fs, args.nchan, args.sample_size
     nsamp = int(round(fs / 10))                      # NUM_IQ_SAMPLES, reference sdr.h:26

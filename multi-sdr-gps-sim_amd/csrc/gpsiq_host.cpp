@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <pthread.h>
 #include <unistd.h>
@@ -96,8 +97,11 @@ void parallel_for(int n, int nthreads, int grain, void (*fn)(void *, int, int), 
     if (n <= 0) return;
     if (grain < 1) grain = 1;
     if (nthreads <= 0) {
+        // default: one per online CPU; GPSIQ_THREADS caps it (several ranks of a time-sharded run share one host)
+        static const int cap = [] { const char *e = std::getenv("GPSIQ_THREADS"); return e ? std::atoi(e) : 0; }();
         long c = sysconf(_SC_NPROCESSORS_ONLN);
         nthreads = c > 0 ? (int) c : 1;
+        if (cap > 0 && nthreads > cap) nthreads = cap;
         const int useful = n / grain + 1;
         if (nthreads > useful) nthreads = useful;
     }
