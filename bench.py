@@ -454,6 +454,7 @@ def extra_legs(ctx, ring, stream, args, first):
                 "value": round(nb * nsamp / ms / 1e3, 1), "unit": "Msamples/s", "x_realtime": round(nb * 0.1 / (ms * 1e-3), 1),
                 "roofline": roofline_obj(nb * blk, ms)}
 
+    ex["reference_build_3M_int8_12ch"] = kernel_leg(3.0e6, 12, 1, "the reference as shipped: TX_SAMPLERATE 3 Msps, MAX_CHAN 12 (sdr.h:21, gps.h:36)")
     ex["cfg2_2M6_int8_12ch"] = kernel_leg(2.6e6, 12, 1, "BASELINE config 2")
     ex["cfg4_2M6_int16_16ch"] = kernel_leg(2.6e6, 16, 2, "BASELINE config 4 format")
     ex["cfg3_10M_int16_16ch"] = kernel_leg(10e6, 16, 2, "BASELINE config 3")

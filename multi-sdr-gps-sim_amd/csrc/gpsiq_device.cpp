@@ -549,8 +549,11 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
                                double *carr_phase_out)
 {
     if (!ctx || ndev < 1 || ndev > 64) return fail(GPSIQ_E_ARG, "bad device list");
-    for (int i = 0; i < ndev; ++i)
+    for (int i = 0; i < ndev; ++i) {
         if (!ctx[i]) return fail(GPSIQ_E_ARG, "null context %d", i);
+        for (int j = 0; j < i; ++j)
+            if (ctx[j] == ctx[i]) return fail(GPSIQ_E_ARG, "context %d listed twice: the ranges are rendered concurrently, one context each", i);
+    }
     if (!host_dst && !dev_dst) return fail(GPSIQ_E_ARG, "no destination");
     int rc = check_gen_args(ctx[0], ch, host_dst ? host_dst : (void *) dev_dst, nblocks, nchan, nsamp, fs, sample_size);
     if (rc) return rc;

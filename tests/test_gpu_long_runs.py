@@ -113,6 +113,9 @@ def test_multi_device_entry_point_on_one_gpu(ctx, oracle, ndev):
                 if b1 > b0:
                     part = buf[: (b1 - b0) * 2 * ns * ss].cpu().numpy().view(np.int8 if ss == SC08 else np.int16).reshape(b1 - b0, 2 * ns)
                     assert np.array_equal(part, want[b0:b1])
+        if ndev > 1:                                                  # one context per range, no sharing
+            with pytest.raises(gpsiq.GpsiqError):
+                gpsiq.generate_batch_multi([ctxs[0], ctxs[0]], d, ns, fs, SC08)
         # GPSIQ_NCO_REFERENCE through the same entry point (the mode is taken from the first context)
         one = gpsiq.Context(0)
         one.set_nco_mode(NCO_REFERENCE)
