@@ -200,10 +200,13 @@ class Scenario:
     def descriptors(self, b0, b1, nthreads=0):
         """gpsiq_chan_t rows [b0, b1) of the run, computing only those (RunAhead.seek)."""
         from gpsiq.pipeline import RunAhead
+        from gpsiq.abi import CHAN_DTYPE
         ra = RunAhead(self.eph[self.ieph], self.utc, self.svs, WEEK, SEC0, self.pos)
         ra.seek(b0, self.pos)
         xyz = np.repeat(self.pos[None, :], b1 - b0, axis=0)
-        return ra.descriptors(xyz, nthreads=nthreads)
+        if getattr(self, "_buf", None) is None or self._buf.shape != (b1 - b0, len(self.svs)):
+            self._buf = np.empty((b1 - b0, len(self.svs)), dtype=CHAN_DTYPE)      # reused by later calls
+        return ra.descriptors(xyz, nthreads=nthreads, out=self._buf)
 
 
 def main():

@@ -87,7 +87,7 @@ class RunAhead:
         self.trk["carr_phase"] = carr                    # the loop's state, not the host model's (gps.c:2821)
         self.blocks_done = block
 
-    def descriptors(self, xyz, carr_phase=None, gain_x2=False, nthreads=0):
+    def descriptors(self, xyz, carr_phase=None, gain_x2=False, nthreads=0, out=None):
         """Channel state at gps.c:2766 for the next len(xyz) blocks (xyz[k] = ECEF position of
         block k).  carr_phase: what the previous Context.generate_batch call handed out
         (carr_out) when continuing a run; None on the first call = the allocation's value.
@@ -107,8 +107,10 @@ class RunAhead:
             done += b1 - b0
             if roll:                                                          # gps.c:2878-2885
                 self._roll(gps_time_after(self.sec, done))
+        # out: a caller-owned [len(xyz)][nchan] array to fill (a fresh 20 MB array per call costs as much in page
+        # faults as the refresh itself)
         desc = refresh_epochs(self.orbit, self.iono, self.week, t_start, xyz, trk_ep, [p[0] for p in plan],
-                              gain_x2=gain_x2, nthreads=nthreads)
+                              gain_x2=gain_x2, nthreads=nthreads, out=out)
         for f in ("rho0_week", "rho0_sec", "rho0_range"):                     # chan.rho0 = rho1 (gps.c:2063)
             self.trk[f] = trk_ep[0][f]
         self.blocks_done = done
