@@ -30,7 +30,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 namespace gpsiq {
@@ -292,6 +294,9 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
             j.end[i] = carr; j.last[i] = prev;
         }
     }, &cj);
+    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    timespec ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
     // pass 2: quantise every block from its own start phase and look for the samples that differ
     struct PJob { const gpsiq_chan_t *ch; gpsiq_qchan_t *q; const double *start; int nchan, nsamp; double delt;
                   std::vector<gpsiq_patch_t> *out; pthread_mutex_t mu; int rc; char err[320]; };
@@ -326,6 +331,12 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
         }
     }, &pj);
     if (pj.rc != GPSIQ_OK) return fail(pj.rc, "%s", pj.err);
+    if (trace) {
+        timespec ts2;
+        clock_gettime(CLOCK_MONOTONIC, &ts2);
+        std::fprintf(stderr, "[gpsiq trace] reference NCO %d blocks x %d ch: candidates + code walks + patches %.2f ms (after the carrier chain)\n",
+                     nblocks, nchan, (double) (ts2.tv_sec - ts1.tv_sec) * 1e3 + (double) (ts2.tv_nsec - ts1.tv_nsec) * 1e-6);
+    }
     std::sort(patches->begin(), patches->end(), [](const gpsiq_patch_t &a, const gpsiq_patch_t &b) {
         if (a.block != b.block) return a.block < b.block;
         if (a.sample != b.sample) return a.sample < b.sample;
