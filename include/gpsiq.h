@@ -375,6 +375,10 @@ int gpsiq_nav_subframes(const gpsiq_nav_eph_t *eph, const gpsiq_nav_utc_t *utc,
 int gpsiq_nav_message(const uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], int week, double sec,
                       int init, gpsiq_nav_state_t *st);
 
+/* The 30 s refresh of every channel in one call (gps.c:2880-2885: generateNavMsg(grx, &chan[i], 0) for all allocated
+ * channels): sbf is [nchan][GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], st[nchan]. */
+int gpsiq_nav_roll(const uint32_t *sbf, int nchan, int week, double sec, gpsiq_nav_state_t *st);
+
 /* ---- RINEX navigation files ---------------------- */
 /* readRinex2() (gps.c:1131-1505) / readRinex3() (gps.c:1512-1891): fixed-column parse of a
  * GPS broadcast-ephemeris file (plain or gzip), records grouped into sets whenever the time

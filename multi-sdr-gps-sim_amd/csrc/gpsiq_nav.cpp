@@ -238,4 +238,15 @@ int gpsiq_nav_message(const uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], in
     return GPSIQ_OK;
 }
 
+int gpsiq_nav_roll(const uint32_t *sbf, int nchan, int week, double sec, gpsiq_nav_state_t *st)
+{
+    if (!sbf || !st || nchan < 0) return fail(GPSIQ_E_ARG, "null argument");
+    typedef const uint32_t (*pages_t)[GPSIQ_N_DWRD_SBF];
+    for (int i = 0; i < nchan; ++i) {
+        const int rc = gpsiq_nav_message(reinterpret_cast<pages_t>(sbf + (size_t) i * GPSIQ_N_SBF_PAGE * GPSIQ_N_DWRD_SBF), week, sec, 0, &st[i]);
+        if (rc != GPSIQ_OK) return rc;
+    }
+    return GPSIQ_OK;
+}
+
 }  // extern "C"

@@ -93,6 +93,7 @@ _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i
 _nav_parity = _sig("gpsiq_nav_parity", C.c_uint32, C.c_uint32, _i)
 _nav_subframes = _sig("gpsiq_nav_subframes", _i, _vp, _vp, _vp, _vp)
 _nav_message = _sig("gpsiq_nav_message", _i, _vp, _i, _d, _i, _vp)
+_nav_roll = _sig("gpsiq_nav_roll", _i, _vp, _i, _i, _d, _vp)
 _rinex_read = _sig("gpsiq_rinex_read", _i, C.c_char_p, _i, _vp, _vp)
 _rinex_select = _sig("gpsiq_rinex_select", _i, _vp, _i, _i, _d)
 _num_variants = _sig("gpsiq_num_variants", _i)
@@ -269,6 +270,14 @@ def nav_message(sbf, week, sec, init, state):
     assert sbf.shape == (53, 10) and state.dtype == NAV_STATE_DTYPE and state.size == 1
     _check(_nav_message(_p(sbf), int(week), float(sec), int(bool(init)), _p(state)))
     return state
+
+
+def nav_roll(sbf, week, sec, states):
+    """generateNavMsg(.., 0) for every channel in one call: sbf [nchan][53][10], states NAV_STATE_DTYPE[nchan] (in place)."""
+    sbf = np.ascontiguousarray(sbf, dtype=np.uint32)
+    assert sbf.ndim == 3 and sbf.shape[1:] == (53, 10) and states.dtype == NAV_STATE_DTYPE and len(states) == len(sbf) and states.flags.c_contiguous
+    _check(_nav_roll(_p(sbf), len(sbf), int(week), float(sec), _p(states)))
+    return states
 
 
 def rinex_read(path, version=2):

@@ -13,7 +13,7 @@ Every call below is one C-ABI entry point; this module is only the loop around t
 """
 import numpy as np
 
-from . import (CHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_subframes,
+from . import (CHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_roll, nav_subframes,
                refresh_batch, refresh_epochs, sat_visibility, track_init)
 
 
@@ -65,10 +65,9 @@ class RunAhead:
         self.blocks_done = 0
 
     def _roll(self, t_roll):
-        for i in range(len(self.svs)):                                        # gps.c:2878-2885
-            nav_message(self.sbf[i], self.week, t_roll, False, self.nav[i:i + 1])
-            self.trk[i]["dwrd"] = self.nav[i]["dwrd"]
-            self.trk[i]["g0_week"], self.trk[i]["g0_sec"] = self.nav[i]["g0_week"], self.nav[i]["g0_sec"]
+        nav_roll(self.sbf, self.week, t_roll, self.nav)                       # gps.c:2878-2885, all channels in one call
+        self.trk["dwrd"] = self.nav["dwrd"]
+        self.trk["g0_week"], self.trk["g0_sec"] = self.nav["g0_week"], self.nav["g0_sec"]
 
     def seek(self, block, xyz_prev):
         """Put the host state where the loop has it just before block `block`, without refreshing the
