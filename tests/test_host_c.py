@@ -155,6 +155,37 @@ def test_gpsiq_shard_parts_concatenate_to_the_single_run(host_built, oracle, tmp
     assert np.array_equal(np.fromfile(single, dtype=np.int16), got)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("contexts,mode", [(0, "fixed"), (3, "fixed"), (2, "reference")])
+def test_gpsiq_render_one_process_all_devices(host_built, oracle, tmp_path, contexts, mode):
+    """C host, one process: gpsiq_generate_batch_multi over `contexts` contexts (0 = one per visible GPU), the
+    timeline in slices of 256 blocks chained through carr_phase == the one-block-at-a-time program's stream; in
+    GPSIQ_NCO_REFERENCE == the float loop."""
+    fs, ns, nb, nc, ss = 2.6e6, 26000, 600, 7, SC08
+    d = synth_blocks(nb, nc, seed=23)
+    d["prn"][300:, 2] = 0
+    d["prn"][450:, 2] = 31
+    dpath, out = str(tmp_path / "desc.bin"), str(tmp_path / "render.bin")
+    write_descriptors(dpath, d, fs, ns, ss)
+    args = [os.path.join(host_built, "gpsiq_render"), dpath, out, str(contexts)] + (["reference"] if mode == "reference" else [])
+    p = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = np.fromfile(out, dtype=np.int8).reshape(nb, 2 * ns)
+    if mode == "fixed":
+        q = oracle.quantize_blocks(d, fs, ns)
+        for b in (0, 1, 255, 256, 257, 299, 300, 449, 450, 511, 512, 599):
+            assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, ss, seq=True)), b
+    else:
+        carr, prev = None, None
+        for b in range(nb):
+            db = d[b].copy()
+            if b:
+                db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+            want, carr = oracle.block_float(db, ns, fs, ss)
+            prev = db["prn"].copy()
+            assert np.array_equal(got[b], want), b
+
+
 def test_c_hosts_fail_loudly_without_a_gpu(host_built, tmp_path):
     """No CPU fallback anywhere: on a box without a GPU both C programs stop at gpsiq_create."""
     import torch
@@ -169,6 +200,7 @@ def test_c_hosts_fail_loudly_without_a_gpu(host_built, tmp_path):
     rinex = write_rinex_nav(str(tmp_path / "r.21n"), synth_rinex_records(6, pos, 2190, 270000.0, seed=3, sets=2), utc, 2)
     np.repeat(pos[None, :], 3, axis=0).tofile(str(tmp_path / "xyz.bin"))
     for argv in (["gpsiq_play", dpath, str(tmp_path / "o.bin")], ["gpsiq_shard", dpath, str(tmp_path / "p.bin"), "0", "1"],
+                 ["gpsiq_render", dpath, str(tmp_path / "r.bin")],
                  ["gpsiq_runahead", rinex, "2", "2190", "270000", str(tmp_path / "xyz.bin"), "2", "8", "2600000", "1", str(tmp_path / "q.bin")]):
         p = subprocess.run([os.path.join(host_built, argv[0])] + argv[1:], capture_output=True, text=True, timeout=120)
         assert p.returncode != 0
