@@ -24,7 +24,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   cpu_baseline — the reference's own loop (oracle/_ref, kind "reference") or our port of it
                  (oracle/, kind "port") timed on this host, 1 core, bounded sample (N = 1 only),
   end_to_end   — the same per-GPU block count from scratch on every rank: host refresh of its own
-                 blocks (gpsiq_refresh_batch) -> quantise -> carrier seed exchange -> upload -> kernel,
+                 blocks (gpsiq_refresh_epochs) -> quantise -> carrier seed exchange -> upload -> kernel,
   extra        — short legs for the other BASELINE configs (each with its own roofline), the
                  host-destination and single-block drop-in calls, GPSIQ_NCO_REFERENCE, first-launch times.
 """
@@ -366,8 +366,8 @@ def main():
                "validate_upload_ms": round(parts[2] * 1e3, 2), "kernel_ms": round(parts[3] * 1e3, 2),
                "host_cpus": effective_cpus(),
                "what": "static receiver (BASELINE config 1/2 geometry), RINEX-derived ephemeris; per rank: RunAhead.seek to its first block, "
-                       "gpsiq_refresh_batch of its own blocks only, gpsiq_quantize_batch, 32 B/channel carrier-seed all-gather, "
-                       "gpsiq_set_descriptors, one gpsiq_launch; slowest rank, best of 2 passes"}
+                       "nav words rolled over its 30 s epochs (gpsiq_nav_roll), gpsiq_refresh_epochs of its own blocks only, gpsiq_quantize_batch, "
+                       "32 B/channel carrier-seed all-gather, gpsiq_set_descriptors, one gpsiq_launch; slowest rank, best of 2 passes"}
         if not dry:
             ctx.set_descriptors(q)
 
