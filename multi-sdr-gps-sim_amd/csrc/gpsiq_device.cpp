@@ -16,7 +16,8 @@
 namespace gpsiq {
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude);
+                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude, void *scratch);
+size_t variant_scratch_bytes(int variant, int nsamp, int nblocks);
 hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size, void *dst, size_t block_stride,
                           int block0, int nblocks, const DeviceTables *tab, const gpsiq_patch_t *patches, int npatch,
                           hipStream_t stream);
@@ -49,6 +50,9 @@ struct gpsiq_ctx {
     size_t         patch_cap = 0;
     int            npatch = 0;
     int            nco_mode = GPSIQ_NCO_FIXED;
+    // scratch of the kernel variants that need some (segm: the sign masks of one launch)
+    void          *d_scratch = nullptr;
+    size_t         scratch_cap = 0;
     // staging for the synchronous entry points
     void          *d_out = nullptr;
     size_t         out_cap = 0;
@@ -155,6 +159,7 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->d_tab) (void) hipFree(c->d_tab);
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_patch) (void) hipFree(c->d_patch);
+    if (c->d_scratch) (void) hipFree(c->d_scratch);
     for (int i = 0; i < 2; ++i) {
         if (c->buf[i].d) (void) hipFree(c->buf[i].d);
         if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
@@ -300,8 +305,16 @@ int gpsiq_set_nco_mode(gpsiq_ctx_t *c, int mode)
 // kernel + patches of blocks [block0, block0+nblocks) on stream s; marks the descriptor buffer as in use
 static int launch_on(gpsiq_ctx *c, int v, int block0, int nblocks, int nsamp, int sample_size, void *dst, size_t stride, hipStream_t s)
 {
+    const size_t need = variant_scratch_bytes(v, nsamp, nblocks);
+    if (need > c->scratch_cap) {
+        // growing is rare (the first launch of a shape); hipFree waits for whatever still uses the old buffer
+        if (c->d_scratch) HIP_TRY(hipFree(c->d_scratch));
+        c->d_scratch = nullptr; c->scratch_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_scratch, need));
+        c->scratch_cap = need;
+    }
     hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, s,
-                                  c->max_active, c->max_amplitude);
+                                  c->max_active, c->max_amplitude, need ? c->d_scratch : nullptr);
     if (e == hipSuccess && c->npatch)
         e = launch_patches(c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, c->d_patch, c->npatch, s);
     if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
@@ -369,6 +382,7 @@ const char *gpsiq_variant_name(int v)
     case kTile: return "tile";
     case kSeg: return "seg";
     case kSegHalf: return "segh";
+    case kSegMask: return "segm";
     default: return "?";
     }
 }

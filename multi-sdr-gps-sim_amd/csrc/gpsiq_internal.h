@@ -46,6 +46,7 @@ enum Variant {
     kTile = 4,      // rowsx with trimmed per-tile overhead, 64 rows per wave (32768-sample tiles)
     kSeg = 5,       // tile kernel, each wave running several consecutive 64-row chunks
     kSegHalf = 6,   // seg with one window per 32 samples: for sample rates down to 1.023 Msps
+    kSegMask = 7,   // high sample rates: per-(channel,row) 64-bit sign masks from a pre-pass, applied as EXEC masks
     kNumVariants
 };
 

@@ -640,6 +640,153 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
 }
 
 // ---------------------------------------------------------------------------
+// Mask kernels ("segm"): an experiment for high sample rates, kept as a selectable, parity-tested variant; NOT the
+// default, because it measured slower than seg (the row loop itself reaches its instruction
+// count -- 0.78 ms against seg's 1.43 ms per 2 GiB at 25 Msps -- but delivering one 64-bit mask per (channel, row)
+// costs more than it saves: +0.74 ms for streaming them through the scalar cache, +0.44 ms for the pre-pass).
+// The idea: at >= 8 Msps a row of 64 samples holds only a few chip edges,
+// so the chip-sign of a (channel, row) is a 64-bit lane mask that ONE thread can build bit-parallel by walking
+// the edges with an exact DDA (sign_masks, a pre-pass: about ten instructions per edge, 64 (channel, row)s per
+// wave instruction).  The row loop then needs no code NCO and no window per lane: the mask arrives through a
+// scalar load as an EXEC mask, and the sign is applied as half a carrier cycle by one exec-masked
+// v_xor_b32 a, 0x400, a on the LDS address (a plain two-operand VALU form).  Per (channel, row): carrier NCO add,
+// SDWA and (address), masked xor, 1/2 add3 = 3.5 VALU instructions instead of 5.5, and nothing but the carrier
+// LUT in LDS.  The arithmetic is the closed form of include/gpsiq.h, evaluated exactly:
+//   sample pos of the chip edge e of a row: smallest pos with  f0 + pos*cs >= e*2^56  (f0: code fraction at the
+//   row start), walked with  2^56 = q*cs + r:  the next edge is q or q+1 samples on, by the remainder.
+constexpr int kMaskRowsPerThread = 16;      // consecutive rows one pre-pass thread walks (one division per 1024 samples)
+
+__global__ __launch_bounds__(256) void sign_masks(
+    const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, int block0, int nblocks,
+    const DeviceTables *__restrict__ tab, uint64_t *__restrict__ masks, int rows_total, int rowgroups)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int) (t & 15u);
+    const unsigned g = t >> 4;
+    const int rg = (int) (g % (unsigned) rowgroups), blk = (int) (g / (unsigned) rowgroups);
+    if (blk >= nblocks) return;
+    const int row0 = rg * kMaskRowsPerThread;
+    uint64_t *out = masks + ((size_t) blk * rows_total + row0) * 16 + c;
+    int nrows = rows_total - row0;
+    if (nrows > kMaskRowsPerThread) nrows = kMaskRowsPerThread;
+    if (c >= nchan || desc[(size_t) (block0 + blk) * nchan + c].prn == 0) {     // unused slot: its LUT is all zero
+        for (int r = 0; r < nrows; ++r) out[(size_t) r * 16] = 0u;
+        return;
+    }
+    const gpsiq_qchan_t q = desc[(size_t) (block0 + blk) * nchan + c];
+    const uint32_t *prn = tab->prn_ext[q.prn - 1];
+    const uint64_t cs = q.code_step;
+    const unsigned __int128 T = (unsigned __int128) q.code_frac + (unsigned __int128) cs * (unsigned) (row0 * 64);
+    const uint32_t A0 = (uint32_t) q.chip0 + (uint32_t) (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+    const uint64_t f0 = (uint64_t) T & kCodeFracMask;
+    uint32_t k = A0 % GPSIQ_CA_SEQ_LEN;
+    const uint32_t ic = q.icode + A0 / GPSIQ_CA_SEQ_LEN;
+    uint32_t bit = ic / 20u, icur = ic % 20u;
+    const uint64_t one = UINT64_C(1) << GPSIQ_CODE_FRAC_BITS;
+    const uint64_t q56 = one / cs, r56 = one % cs;
+    // first edge after the group's first sample: smallest pos with f0 + pos*cs >= 2^56
+    const uint64_t d = one - f0;
+    uint64_t pos = (d + cs - 1) / cs;
+    uint64_t over = pos * cs - d;                         // how far past the edge that sample is, < cs
+    uint32_t sgn = ((prn[k >> 5] >> (k & 31u)) ^ (q.nav_bits >> (bit & 31u))) & 1u;
+    for (int r = 0; r < nrows; ++r) {
+        uint64_t m = sgn ? ~UINT64_C(0) : UINT64_C(0);
+        while (pos < 64u) {
+            if (++k == GPSIQ_CA_SEQ_LEN) {                 // gps.c:2791-2811: next code period, maybe next data bit
+                k = 0;
+                if (++icur == 20u) { icur = 0; ++bit; }
+            }
+            const uint32_t ns = ((prn[k >> 5] >> (k & 31u)) ^ (q.nav_bits >> (bit & 31u))) & 1u;
+            if (ns != sgn) { m ^= ~UINT64_C(0) << pos; sgn = ns; }
+            if (r56 > over) { pos += q56 + 1; over += cs - r56; }
+            else            { pos += q56;     over -= r56; }
+        }
+        out[(size_t) r * 16] = m;
+        pos -= 64u;
+    }
+}
+
+template <int FMT, int NCH>
+__global__ __launch_bounds__(kRowsThreads) void synth_mask(
+    const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
+    size_t block_stride, int block0, const DeviceTables *__restrict__ tab, const uint64_t *__restrict__ masks,
+    int rows_total, int tiles_per_block, int wave_rows)
+{
+    __shared__ uint32_t lut[NCH][512];
+    __shared__ gpsiq_qchan_t qs[NCH];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    const gpsiq_qchan_t *q_blk = desc + (size_t) (block0 + blk) * nchan;
+    const int nq = nchan < NCH ? nchan : NCH;
+    for (int i = tid; i < NCH * 12; i += kRowsThreads)
+        reinterpret_cast<uint32_t *>(qs)[i] = i < nq * 12 ? reinterpret_cast<const uint32_t *>(q_blk)[i] : 0u;
+    __syncthreads();
+    {
+        const double sk = (double) dev_sin512(tab->quarter_wave, tid);
+        const double ck = (double) dev_sin512(tab->quarter_wave, tid + 128);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const double g = qs[c].gain;
+            const int ts = (int) (sk * g), tc = (int) (ck * g);   // gps.c:2781-2782
+            // the plain-add formats of synth_tile<FAST>: int8 two 12-bit fields, int16 one integer with slot 0's bias
+            if (FMT == GPSIQ_SC08) lut[c][tid] = (((uint32_t) tc & 0xfffu) << 4) | ((uint32_t) ts << 20);
+            else                   lut[c][tid] = (uint32_t) (tc + ts * 65536) + (c == 0 ? 0x8000u : 0u);
+        }
+    }
+    __syncthreads();
+    uint8_t *blk_dst = dst + (size_t) blk * block_stride;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int row_first = (tile * kWaves + wave) * wave_rows;
+    if (row_first >= rows_total) return;
+    int rows = rows_total - row_first;
+    rows = rows < wave_rows ? rows : wave_rows;
+    const uint32_t n0 = (uint32_t) row_first * 64u + (uint32_t) lane;
+    uint64_t P[NCH], dP[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool have = c < nchan;
+        const uint64_t p0 = have ? q_blk[c].carr_phase : 0u, ps = have ? (uint64_t) q_blk[c].carr_step : 0u;
+        P[c] = p0 + ps * (uint64_t) n0;
+        dP[c] = ps * 64u;
+    }
+    const unsigned char *lut_b = reinterpret_cast<const unsigned char *>(&lut[0][0]);
+    // the 16 masks of a row are one 128-byte line at a wave-uniform address: two s_load_dwordx16 per row
+    typedef uint64_t u64x8 __attribute__((ext_vector_type(8)));
+    const u64x8 *m_row = reinterpret_cast<const u64x8 *>(masks + ((size_t) blk * rows_total + row_first) * 16);
+    const int rows_s = __builtin_amdgcn_readfirstlane(rows);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int r = 0; r < rows_s; ++r) {
+        const u64x8 m_lo = m_row[2 * r];
+        u64x8 m_hi = m_lo;
+        if (NCH > 8) m_hi = m_row[2 * r + 1];
+        uint32_t sum = 0u;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint64_t m = c < 8 ? m_lo[c] : m_hi[c - 8];
+            uint32_t a = (uint32_t) (P[c] >> 48) & 0x7fcu;                      // 4 * LUT index
+            uint64_t saved;
+            // lanes whose chip sign is -1 read the entry half a cycle on: the table is antisymmetric
+            asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_xor_b32 %[a], 0x400, %[a]\n\ts_mov_b64 exec, %[sv]"
+                         : [a] "+v"(a), [sv] "=&s"(saved) : [m] "s"(m));
+            sum += *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+            P[c] += dP[c];
+        }
+        const uint32_t iq = FMT == GPSIQ_SC16 ? sum ^ 0x8000u : sum;
+        const uint32_t n = n0 + (uint32_t) r * 64u;
+        if (n < (uint32_t) nsamp) {
+            if (FMT == GPSIQ_SC16) *reinterpret_cast<uint32_t *>(blk_dst + n * 4u) = iq;
+            else *reinterpret_cast<uint16_t *>(blk_dst + n * 2u) = (uint16_t) __builtin_amdgcn_perm(iq, iq, 0x0c0c0301u);
+        }
+    }
+}
+
+size_t variant_scratch_bytes(int variant, int nsamp, int nblocks)
+{
+    if (variant != kSegMask || nsamp <= 0 || nblocks <= 0) return 0;
+    return (size_t) nblocks * (size_t) ((nsamp + 63) / 64) * 16u * sizeof(uint64_t);
+}
+
+// ---------------------------------------------------------------------------
 // GPSIQ_NCO_REFERENCE fix-up (csrc/gpsiq_exact.cpp): the few samples per 10^7 where the reference's
 // double accumulators pick another LUT entry or sign than the closed form are recomputed whole --
 // every channel from the closed form, the patched channels from the patch -- and stored over what
@@ -719,10 +866,35 @@ static const SegPolicy &seg_policy()
 
 hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
                           void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude)
+                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude, void *scratch)
 {
     if (nblocks <= 0 || nsamp <= 0) return hipSuccess;
     uint8_t *d = static_cast<uint8_t *>(dst);
+    // the mask kernel only has the plain-add LUT formats: int16 sums that may leave the int16 range go to seg's packed core
+    if (variant == kSegMask && ((sample_size == GPSIQ_SC16 && max_amplitude > 32767) || !scratch)) variant = kSeg;
+    if (variant == kSegMask) {
+        const int rows_total = (nsamp + 63) / 64;
+        const int rowgroups = (rows_total + kMaskRowsPerThread - 1) / kMaskRowsPerThread;
+        uint64_t *masks = static_cast<uint64_t *>(scratch);
+        const size_t threads = (size_t) nblocks * rowgroups * 16;
+        hipLaunchKernelGGL(sign_masks, dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, stream, desc, nchan, nsamp, block0, nblocks,
+                           tab, masks, rows_total, rowgroups);
+        // every wave the same number of rows; workgroups of ~256 rows per wave amortise the LUT build
+        int wave_rows = 256, tiles = (rows_total + kWaves * wave_rows - 1) / (kWaves * wave_rows);
+        wave_rows = (rows_total + kWaves * tiles - 1) / (kWaves * tiles);
+        dim3 grid((unsigned) (tiles * nblocks)), block(kRowsThreads);
+        const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
+#define GPSIQ_LAUNCH_M(F, N) hipLaunchKernelGGL((synth_mask<F, N>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, masks, rows_total, tiles, wave_rows)
+        if (sample_size == GPSIQ_SC16) {
+            if (slots == 4) GPSIQ_LAUNCH_M(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_M(GPSIQ_SC16, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_M(GPSIQ_SC16, 12); else GPSIQ_LAUNCH_M(GPSIQ_SC16, 16);
+        } else {
+            if (slots == 4) GPSIQ_LAUNCH_M(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_M(GPSIQ_SC08, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_M(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_M(GPSIQ_SC08, 16);
+        }
+#undef GPSIQ_LAUNCH_M
+        return hipGetLastError();
+    }
     if (variant == kTile || variant == kSeg || variant == kSegHalf) {
         const bool half = variant == kSegHalf;
         const int rows = half ? 32 : 64;                  // rows per chunk (the window array holds 64 windows per wave)
