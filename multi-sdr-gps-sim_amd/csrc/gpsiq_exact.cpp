@@ -205,8 +205,15 @@ inline unsigned nav_bit(const gpsiq_chan_t &ch, long bit)     // the data bit `b
 
 // Patches of one channel of one block.  ch.carr_phase is the double the block starts from; q is its
 // quantised form (quantize_one without carry_in, i.e. seeded from that double).
+// One C/A code, generated when a block first has a candidate to look at (most have none).
+struct CodeCache {
+    int     prn = 0;
+    uint8_t ca[GPSIQ_CA_SEQ_LEN];
+    const uint8_t *get(int p) { if (p != prn) { ca_code(p, ca); prn = p; } return ca; }
+};
+
 static void block_patches(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double delt, int nsamp, int block, int slot,
-                          const uint8_t *ca, std::vector<gpsiq_patch_t> *out)
+                          CodeCache *codes, std::vector<gpsiq_patch_t> *out)
 {
     const long ns = nsamp;
     if (ns <= 0) return;
@@ -229,6 +236,7 @@ static void block_patches(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double
         targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
     }
     if (targets.empty()) return;
+    const uint8_t *ca = codes->get(ch.prn);
     Nco carr = {ch.carr_phase, carr_inc, 0, 0, 1}, code = {ch.code_phase, code_inc, 0, 0, 0};
     const bool walk_code = every || !t_code.empty();
     for (long n : targets) {
@@ -304,7 +312,7 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
     parallel_for(nblocks, 0, 4, [](void *p, int b0, int b1) {
         PJob &j = *static_cast<PJob *>(p);
         std::vector<gpsiq_patch_t> mine;
-        uint8_t ca[GPSIQ_CA_SEQ_LEN];
+        CodeCache codes;
         for (int b = b0; b < b1; ++b) {
             int slot = 0;                                   // device order: active channels first (gpsiq_set_descriptors)
             for (int i = 0; i < j.nchan; ++i) {
@@ -319,8 +327,7 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
                     continue;
                 }
                 if (d.prn <= 0) continue;
-                ca_code(d.prn, ca);
-                block_patches(d, qq, j.delt, j.nsamp, b, slot, ca, &mine);
+                block_patches(d, qq, j.delt, j.nsamp, b, slot, &codes, &mine);
                 ++slot;
             }
         }
