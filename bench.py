@@ -451,8 +451,8 @@ def extra_legs(ctx, ring, stream, args, first):
         d = pat[np.arange(nb) % len(pat)]
         qq, _ = gpsiq.quantize_blocks(d, fs, nsamp)
         ctx.set_descriptors(qq)
-        ctx.time_launches(0, nb, nsamp, ss, ring.data_ptr(), stride, 2, stream=stream)
-        ms = min(ctx.time_launches(0, nb, nsamp, ss, ring.data_ptr(), stride, 5, stream=stream) for _ in range(2))
+        ctx.time_launches(0, nb, nsamp, ss, ring.data_ptr(), stride, 8, stream=stream)       # warm: the headline is pre-heated too
+        ms = min(ctx.time_launches(0, nb, nsamp, ss, ring.data_ptr(), stride, 8, stream=stream) for _ in range(3))
         return {"workload": f"{fs / 1e6:g} Msps int{8 * ss}, {nchan} ch, {nb} blocks per launch ({note})",
                 "value": round(nb * nsamp / ms / 1e3, 1), "unit": "Msamples/s", "x_realtime": round(nb * 0.1 / (ms * 1e-3), 1),
                 "roofline": roofline_obj(nb * blk, ms)}
