@@ -18,13 +18,29 @@ def program(name):
     return p if os.path.exists(p) else None
 
 
-def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout=300):
+def write_circle_motion(path, seconds=30):
+    """A user-motion file in the reference's format (readUserMotion, gps.c:2253-2280: one line 't,x,y,z' per 0.1 s,
+    ECEF metres): a 150 m circle around the static BASELINE position, 50 s per lap -- BASELINE config 4's kind of
+    scenario (per-block range/Doppler refresh on the host), written by this repository's own track generator."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+    from gpsiq.scenario import circle_track, llh_to_ecef
+    lat, lon, h = (float(v) for v in LLH.split(","))
+    xyz = circle_track(llh_to_ecef(lat, lon, h), seconds * 10, radius_m=150.0, period_s=50.0)
+    with open(path, "w") as f:
+        for k, (x, y, z) in enumerate(xyz):
+            f.write("%5.1f,%.3f,%.3f,%.3f\n" % (0.1 * k, x, y, z))
+    return path
+
+
+def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout=300, motion=None):
     """-> bytes of iqdata.bin.  The program has no batch mode: it draws its ncurses screen (LINES/COLUMNS
     given so that it does not ask about the window size), generates `seconds` of signal through the fifo
     into iqdata.bin in the working directory and then idles in its key loop until it is told to stop."""
     nblocks = seconds * 10 - 1                                   # the block loop starts at 1 (gps.c:2703)
     expect = nblocks * (FS // 10) * 2 * (2 if iq16 else 1)
-    args = [binary, "-e", RINEX, "-l", LLH, "-r", "iqfile", "-d", str(seconds), "--disable-almanac"]
+    where = ["-m", motion] if motion else ["-l", LLH]
+    args = [binary, "-e", RINEX] + where + ["-r", "iqfile", "-d", str(seconds), "--disable-almanac"]
     if iq16:
         args.append("--iq16")
     env = dict(os.environ, LINES="50", COLUMNS="160", TERM="xterm")

@@ -251,6 +251,13 @@ def make_program_golden():
         blk = (FS // 10) * 2 * (2 if iq16 else 1)
         sha["sha16" if iq16 else "sha8"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
         print("program_static_30s", "iq16" if iq16 else "int8", len(data), "bytes", hashlib.sha256(data).hexdigest())
+    # the moving receiver (BASELINE config 4's kind of scenario): a user-motion file, --iq16
+    from _program import write_circle_motion
+    with tempfile.TemporaryDirectory() as td:
+        data = run_program(ref, td, 30, True, motion=write_circle_motion(os.path.join(td, "circle.csv"), 30))
+    blk = (FS // 10) * 4
+    sha["sha16_circle"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
+    print("program circle iq16", len(data), "bytes", hashlib.sha256(data).hexdigest())
     np.savez_compressed(os.path.join(HERE, "program_static_30s.npz"), fs=FS, seconds=30, **sha)
 
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from _program import FS, program, run_program
+from _program import FS, program, run_program, write_circle_motion
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "program_static_30s.npz")
 
@@ -63,3 +63,28 @@ def test_patched_reference_thread_fixed_point_model(tmp_path):
     got = block_digests(data, False)
     want = [str(s) for s in z["sha8"]]
     assert sum(g != w for g, w in zip(got, want)) <= 40           # blocks that hold a differing element
+
+
+def test_unpatched_program_moving_receiver_capture(tmp_path):
+    """The fixture's third capture: the reference program on a user-motion file (a circle, this repository's own
+    track in the reference's CSV format), --iq16."""
+    ref = program("gps-sim-ref")
+    if ref is None:
+        pytest.skip("oracle/_ref/gps-sim-ref not built (no /root/reference here)")
+    z = np.load(GOLD)
+    data = run_program(ref, str(tmp_path), 30, True, motion=write_circle_motion(str(tmp_path / "circle.csv"), 30))
+    assert block_digests(data, True) == [str(s) for s in z["sha16_circle"]]
+
+
+@pytest.mark.gpu
+def test_patched_reference_thread_moving_receiver(tmp_path):
+    """BASELINE config 4's kind of scenario inside the reference's own thread: a moving receiver (user-motion file), the
+    reference's host model refreshing range and Doppler for every 0.1 s block, every block synthesised by
+    gpsiq_generate_block on the GPU: the same iqdata.bin as the unpatched program, all 299 blocks, int16."""
+    patched = program("gps-sim-gpsiq")
+    assert patched is not None
+    z = np.load(GOLD)
+    data = run_program(patched, str(tmp_path), 30, True, motion=write_circle_motion(str(tmp_path / "circle.csv"), 30))
+    got, want = block_digests(data, True), [str(s) for s in z["sha16_circle"]]
+    bad = [b for b in range(299) if got[b] != want[b]]
+    assert len(got) == 299 and not bad, f"blocks {bad[:10]} differ from the reference program's output"
