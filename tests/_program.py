@@ -9,6 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 RINEX = os.path.join(ROOT, "tests", "golden", "synth_static.21n")
+RINEX16 = os.path.join(ROOT, "tests", "golden", "synth_static16.21n")      # 16 satellites in view: for the MAX_CHAN 16 builds
 LLH = "35.681298,139.766247,10.0"          # BASELINE config 1: static position
 FS = 3000000                                # the reference's TX_SAMPLERATE as shipped (sdr.h:21)
 
@@ -33,14 +34,14 @@ def write_circle_motion(path, seconds=30):
     return path
 
 
-def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout=300, motion=None):
+def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout=300, motion=None, fs=FS, rinex=RINEX):
     """-> bytes of iqdata.bin.  The program has no batch mode: it draws its ncurses screen (LINES/COLUMNS
     given so that it does not ask about the window size), generates `seconds` of signal through the fifo
     into iqdata.bin in the working directory and then idles in its key loop until it is told to stop."""
     nblocks = seconds * 10 - 1                                   # the block loop starts at 1 (gps.c:2703)
-    expect = nblocks * (FS // 10) * 2 * (2 if iq16 else 1)
+    expect = nblocks * (fs // 10) * 2 * (2 if iq16 else 1)
     where = ["-m", motion] if motion else ["-l", LLH]
-    args = [binary, "-e", RINEX] + where + ["-r", "iqfile", "-d", str(seconds), "--disable-almanac"]
+    args = [binary, "-e", rinex] + where + ["-r", "iqfile", "-d", str(seconds), "--disable-almanac"]
     if iq16:
         args.append("--iq16")
     env = dict(os.environ, LINES="50", COLUMNS="160", TERM="xterm")

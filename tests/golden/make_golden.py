@@ -258,6 +258,20 @@ def make_program_golden():
     blk = (FS // 10) * 4
     sha["sha16_circle"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
     print("program circle iq16", len(data), "bytes", hashlib.sha256(data).hexdigest())
+    # the BASELINE constants (oracle/_ref/gps-sim-ref-2M6: TX_SAMPLERATE 2600000, MAX_CHAN 16) on a file with 16
+    # satellites in view: BASELINE config 1 as the reference itself renders it, int8
+    from _program import RINEX16
+    from gpsiq.scenario import llh_to_ecef, synth_rinex_records, write_rinex_nav
+    utc = dict(alpha=[0.1118e-07, -0.7451e-08, -0.5961e-07, 0.1192e-06], beta=[0.1167e+06, -0.2294e+06, -0.1311e+06, 0.1049e+07],
+               A0=-0.931322574615e-09, A1=-0.355271367880e-14, tot=233472, wnt=2190, dtls=18)
+    write_rinex_nav(RINEX16, synth_rinex_records(16, llh_to_ecef(35.681298, 139.766247, 10.0), 2190, 270000.0, seed=78, sets=2), utc, 2)
+    ref26 = program("gps-sim-ref-2M6")
+    assert ref26, "oracle/_ref/gps-sim-ref-2M6 missing (make -C oracle progs)"
+    with tempfile.TemporaryDirectory() as td:
+        data = run_program(ref26, td, 30, False, fs=2600000, rinex=RINEX16)
+    blk = 260000 * 2
+    sha["sha8_2M6_16ch"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
+    print("program 2.6 Msps 16 ch int8", len(data), "bytes", hashlib.sha256(data).hexdigest())
     np.savez_compressed(os.path.join(HERE, "program_static_30s.npz"), fs=FS, seconds=30, **sha)
 
 

@@ -10,13 +10,13 @@ import os
 import numpy as np
 import pytest
 
-from _program import FS, program, run_program, write_circle_motion
+from _program import FS, RINEX16, program, run_program, write_circle_motion
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "program_static_30s.npz")
 
 
-def block_digests(data, iq16):
-    blk = (FS // 10) * 2 * (2 if iq16 else 1)
+def block_digests(data, iq16, fs=FS):
+    blk = (fs // 10) * 2 * (2 if iq16 else 1)
     return [hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)]
 
 
@@ -86,5 +86,29 @@ def test_patched_reference_thread_moving_receiver(tmp_path):
     z = np.load(GOLD)
     data = run_program(patched, str(tmp_path), 30, True, motion=write_circle_motion(str(tmp_path / "circle.csv"), 30))
     got, want = block_digests(data, True), [str(s) for s in z["sha16_circle"]]
+    bad = [b for b in range(299) if got[b] != want[b]]
+    assert len(got) == 299 and not bad, f"blocks {bad[:10]} differ from the reference program's output"
+
+
+def test_unpatched_program_at_the_baseline_constants(tmp_path):
+    """BASELINE config 1 as the reference itself renders it: the reference program rebuilt with TX_SAMPLERATE 2600000
+    and MAX_CHAN 16 (its two compile-time constants, oracle/Makefile), 16 satellites in view, int8, 30 s."""
+    ref = program("gps-sim-ref-2M6")
+    if ref is None:
+        pytest.skip("oracle/_ref/gps-sim-ref-2M6 not built (no /root/reference here)")
+    z = np.load(GOLD)
+    data = run_program(ref, str(tmp_path), 30, False, fs=2600000, rinex=RINEX16)
+    assert block_digests(data, False, 2600000) == [str(s) for s in z["sha8_2M6_16ch"]]
+
+
+@pytest.mark.gpu
+def test_patched_reference_thread_at_the_baseline_constants(tmp_path):
+    """BASELINE config 2: the same static scenario on the GPU -- 2.6 Msps, int8, 16 channels -- bit-exact against the
+    CPU iqfile, with BOTH sides being the reference program: its gps thread on libgpsiq against its own loop."""
+    patched = program("gps-sim-gpsiq-2M6")
+    assert patched is not None
+    z = np.load(GOLD)
+    data = run_program(patched, str(tmp_path), 30, False, fs=2600000, rinex=RINEX16)
+    got, want = block_digests(data, False, 2600000), [str(s) for s in z["sha8_2M6_16ch"]]
     bad = [b for b in range(299) if got[b] != want[b]]
     assert len(got) == 299 and not bad, f"blocks {bad[:10]} differ from the reference program's output"
