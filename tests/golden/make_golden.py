@@ -272,6 +272,12 @@ def make_program_golden():
     blk = 260000 * 2
     sha["sha8_2M6_16ch"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
     print("program 2.6 Msps 16 ch int8", len(data), "bytes", hashlib.sha256(data).hexdigest())
+    # 65 s: across two of the reference's 30 s refreshes (generateNavMsg roll + allocateChannel, gps.c:2878-2909)
+    with tempfile.TemporaryDirectory() as td:
+        data = run_program(ref, td, 65, False)
+    blk = (FS // 10) * 2
+    sha["sha8_65s"] = np.array([hashlib.sha256(data[i:i + blk]).hexdigest() for i in range(0, len(data), blk)])
+    print("program 65 s int8", len(data), "bytes", hashlib.sha256(data).hexdigest())
     np.savez_compressed(os.path.join(HERE, "program_static_30s.npz"), fs=FS, seconds=30, **sha)
 
 

@@ -112,3 +112,24 @@ def test_patched_reference_thread_at_the_baseline_constants(tmp_path):
     got, want = block_digests(data, False, 2600000), [str(s) for s in z["sha8_2M6_16ch"]]
     bad = [b for b in range(299) if got[b] != want[b]]
     assert len(got) == 299 and not bad, f"blocks {bad[:10]} differ from the reference program's output"
+
+
+def test_unpatched_program_across_nav_refreshes(tmp_path):
+    """65 s of the reference program: its 30 s refreshes (navigation-message roll, allocateChannel) happen twice."""
+    ref = program("gps-sim-ref")
+    if ref is None:
+        pytest.skip("oracle/_ref/gps-sim-ref not built (no /root/reference here)")
+    z = np.load(GOLD)
+    assert block_digests(run_program(ref, str(tmp_path), 65, False), False) == [str(s) for s in z["sha8_65s"]]
+
+
+@pytest.mark.gpu
+def test_patched_reference_thread_across_nav_refreshes(tmp_path):
+    """The patched thread over 649 blocks incl. two of the reference's own 30 s refreshes: the same file."""
+    patched = program("gps-sim-gpsiq")
+    assert patched is not None
+    z = np.load(GOLD)
+    got = block_digests(run_program(patched, str(tmp_path), 65, False), False)
+    want = [str(s) for s in z["sha8_65s"]]
+    bad = [b for b in range(len(want)) if got[b] != want[b]]
+    assert len(got) == 649 and not bad, f"blocks {bad[:10]} differ from the reference program's output"
