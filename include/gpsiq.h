@@ -261,6 +261,8 @@ int gpsiq_set_patches(gpsiq_ctx_t *ctx, const gpsiq_patch_t *patches, int n);
  * variant selects the kernel: 0 = default, see gpsiq_variant_name(). */
 int gpsiq_launch(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, int sample_size,
                  void *dst, size_t block_stride_bytes, void *hip_stream, int variant);
+/* (The "segm" variant and the patches of GPSIQ_NCO_REFERENCE use buffers owned by the context: launches of one
+ * context that use them belong on one stream at a time.  The default kernels have no such state.) */
 int gpsiq_synchronize(gpsiq_ctx_t *ctx, void *hip_stream);
 /* Time iters back-to-back launches with HIP events on hip_stream; returns the mean
  * kernel-launch duration in milliseconds in *ms_per_launch. */

@@ -284,7 +284,7 @@ using namespace gpsiq;
 
 extern "C" {
 
-const char *gpsiq_version(void) { return "gpsiq 0.1 (gfx950)"; }
+const char *gpsiq_version(void) { return "gpsiq 0.2 (gfx950)"; }
 
 const char *gpsiq_last_error(void) { return g_err; }
 

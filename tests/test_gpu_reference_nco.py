@@ -165,3 +165,46 @@ def test_mode_switch_and_patch_validation(rctx):
         rctx.set_nco_mode(7)
     rctx.set_nco_mode(NCO_FIXED)
     rctx.set_nco_mode(NCO_REFERENCE)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_reference_nco_fuzz(rctx, oracle, seed):
+    """Random rates, block lengths, channel counts, Doppler ranges, dyadic steps (exact rounding ties), phases on powers
+    of two and LUT boundaries, integer code phases, slots going out of view: gpsiq_generate_batch in
+    GPSIQ_NCO_REFERENCE == the float loop, every element, and the phase handed out == the loop's."""
+    rng = np.random.default_rng(seed)
+    for _ in range(25):
+        fs = float(rng.choice([1.2e6, 2.048e6, 2.6e6, 3e6, 4.092e6, 10e6, 16.368e6, 25e6]))
+        ns, nc, nb, ss = int(rng.integers(1, 90000)), int(rng.integers(1, 17)), int(rng.integers(1, 4)), int(rng.integers(1, 3))
+        d = synth_blocks(nb, nc, seed=int(rng.integers(0, 1 << 30)), doppler_hz=float(rng.choice([5000.0, 10000.0, 50.0, 0.001])))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            k = rng.integers(8, 40, size=nc)
+            d["f_carr"] = (fs * (rng.integers(1, 8, size=nc) * 2.0 - 7) / 2.0 ** k)[None, :]
+        elif kind == 1:
+            d["carr_phase"] = (rng.integers(0, 512, size=nc) / 512.0)[None, :]
+        elif kind == 2:
+            d["carr_phase"] = (2.0 ** -rng.integers(1, 60, size=nc).astype(float))[None, :]
+        elif kind == 3:
+            d["code_phase"] = np.floor(d["code_phase"])
+        d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+        if rng.random() < 0.3:
+            d["prn"][nb // 2:, 0] = 0
+        want, carr_want = float_run_ns(oracle, d, fs, ns, ss)
+        carr = np.zeros(nc)
+        got = rctx.generate_batch(d, ns, fs, ss, carr_out=carr)
+        assert np.array_equal(got, want), (fs, ns, nc, nb, ss, kind)
+        act = d[-1]["prn"] > 0
+        assert np.array_equal(carr[act], carr_want[act]), (fs, ns, kind)
+
+
+def float_run_ns(oracle, d, fs, ns, ss):
+    out, carr, prev = [], None, None
+    for b in range(len(d)):
+        db = d[b].copy()
+        if b:
+            db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+        o, carr = oracle.block_float(db, ns, fs, ss)
+        out.append(o)
+        prev = db["prn"].copy()
+    return np.stack(out), carr
