@@ -501,6 +501,21 @@ def extra_legs(ctx, ring, stream, args, first):
         ex[label] = {"what": "gpsiq_generate_block -> page-locked host memory, one 0.1 s block per call, carr_phase handed back in "
                              "(the patched gps thread's call)", "median_us": round(lat[len(lat) // 2] * 1e6, 1),
                      "max_us": round(lat[-1] * 1e6, 1), "x_realtime": round(0.1 / lat[len(lat) // 2], 1)}
+    # the same call without waiting: 50 blocks queued back to back, one wait at the end
+    ctx.set_nco_mode(NCO_FIXED)
+    many = [torch.empty(blk, dtype=torch.uint8).pin_memory() for _ in range(8)]
+    carr = None
+    for rep in range(2):
+        t1 = time.perf_counter()
+        for k in range(50):
+            ch1 = d_h[k].copy()
+            if carr is not None:
+                ch1["carr_phase"] = carr
+            carr = ctx.generate_block_async(ch1, nsamp, fs, ss, many[k % 8].data_ptr())
+        ctx.wait()
+        dt = time.perf_counter() - t1
+    ex["block_call_async"] = {"what": "gpsiq_generate_block_async, 50 blocks queued back to back into page-locked buffers + gpsiq_wait",
+                              "us_per_block": round(dt / 50 * 1e6, 1), "x_realtime": round(0.1 * 50 / dt, 1)}
     # GPSIQ_NCO_REFERENCE over a batch: bound by the serial carrier walk on the host
     ctx.set_nco_mode(NCO_REFERENCE)
     nb_r = 1000

@@ -211,6 +211,17 @@ int gpsiq_generate_block(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, double *carr_phase_out);
 
+/* The same call without waiting for the device (GPSIQ_NCO_FIXED only): it returns once the descriptor upload, the
+ * kernel and the copy into dst are queued; carr_phase_out is final on return (the host computes it), dst -- which
+ * must be page-locked (gpsiq_host_alloc) -- is complete after gpsiq_wait().  Calls queue in order on the context's
+ * stream, so a generator thread can prepare block k+1 (host model, fifo hand-off of block k-1) while block k is
+ * synthesised and copied; at most four blocks are in flight, the fifth call waits for the first. */
+int gpsiq_generate_block_async(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
+                               int nsamp, double fs, int sample_size,
+                               void *dst_pinned, double *carr_phase_out);
+/* Wait until everything queued by gpsiq_generate_block_async has landed. */
+int gpsiq_wait(gpsiq_ctx_t *ctx);
+
 /* Run-ahead form of the 10 Hz loop (gps.c:2703): ch is [nblocks][nchan], all blocks
  * prepared by the host model first (it never reads the loop's output except
  * carr_phase).  Block 0 seeds the carrier from ch[0][i].carr_phase under the same rule as

@@ -57,6 +57,16 @@ struct gpsiq_ctx {
     void          *d_out = nullptr;
     size_t         out_cap = 0;
     hipEvent_t     chunk_done[2] = {nullptr, nullptr};
+    // gpsiq_generate_block_async: a small ring of per-block descriptor / output staging, each with the event that
+    // says its block has landed
+    struct AsyncSlot {
+        gpsiq_qchan_t *d = nullptr, *h = nullptr;
+        void          *out = nullptr;
+        size_t         out_cap = 0;
+        hipEvent_t     done = nullptr;
+        bool           busy = false;
+    } aslot[4];
+    int anext = 0;
     // carrier carry per slot (gpsiq_generate_block)
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     double   handed[GPSIQ_MAX_CHAN] = {};
@@ -160,6 +170,12 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_patch) (void) hipFree(c->d_patch);
     if (c->d_scratch) (void) hipFree(c->d_scratch);
+    for (auto &a : c->aslot) {
+        if (a.d) (void) hipFree(a.d);
+        if (a.h) (void) hipHostFree(a.h);
+        if (a.out) (void) hipFree(a.out);
+        if (a.done) (void) hipEventDestroy(a.done);
+    }
     for (int i = 0; i < 2; ++i) {
         if (c->buf[i].d) (void) hipFree(c->buf[i].d);
         if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
@@ -512,6 +528,76 @@ int gpsiq_generate_block(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int 
         c->handed[i] = ch[i].prn > 0 ? carr_phase_to_double(next[i]) : 0.0;
         if (carr_phase_out) carr_phase_out[i] = ch[i].prn > 0 ? c->handed[i] : ch[i].carr_phase;
     }
+    return GPSIQ_OK;
+}
+
+int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
+                               int sample_size, void *dst, double *carr_phase_out)
+{
+    if (!dst) return fail(GPSIQ_E_ARG, "null argument");
+    int rc = check_gen_args(c, ch, dst, 1, nchan, nsamp, fs, sample_size);
+    if (rc) return rc;
+    if (c->nco_mode != GPSIQ_NCO_FIXED) return fail(GPSIQ_E_STATE, "the asynchronous block call serves the fixed-point NCO model only");
+    HIP_TRY(hipSetDevice(c->device));
+    gpsiq_qchan_t q[GPSIQ_MAX_CHAN];
+    uint64_t next[GPSIQ_MAX_CHAN] = {};
+    const double delt = 1.0 / fs;
+    for (int i = 0; i < nchan; ++i) {
+        const bool cont = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
+        rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[i], &next[i]);
+        if (rc) return rc;
+    }
+    gpsiq_ctx::AsyncSlot &a = c->aslot[c->anext];
+    if (a.busy) { HIP_TRY(hipEventSynchronize(a.done)); a.busy = false; }     // the ring is full: wait for its oldest block
+    if (!a.d) {
+        HIP_TRY(hipMalloc((void **) &a.d, GPSIQ_MAX_CHAN * sizeof(gpsiq_qchan_t)));
+        HIP_TRY(hipHostMalloc((void **) &a.h, GPSIQ_MAX_CHAN * sizeof(gpsiq_qchan_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    }
+    // compact (active channels first) and take the launch parameters, as gpsiq_set_descriptors does for a batch
+    int na = 0;
+    long amp = 0;
+    uint64_t max_step = 0;
+    for (int i = 0; i < nchan; ++i) {
+        if (!q[i].prn) continue;
+        if (!(q[i].gain > -4.0e6 && q[i].gain < 4.0e6)) return fail(GPSIQ_E_RANGE, "gain %g outside the NCO format", q[i].gain);
+        if (q[i].code_step > max_step) max_step = q[i].code_step;
+        amp += (long) (250.0 * std::fabs(q[i].gain));
+        a.h[na++] = q[i];
+    }
+    for (int i = na; i < nchan; ++i) std::memset(&a.h[i], 0, sizeof(gpsiq_qchan_t));
+    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
+    const size_t stride = (blk_bytes + 15) & ~(size_t) 15;
+    if (stride > a.out_cap) {
+        if (a.out) HIP_TRY(hipFree(a.out));
+        a.out = nullptr; a.out_cap = 0;
+        HIP_TRY(hipMalloc(&a.out, stride ? stride : 16));
+        a.out_cap = stride ? stride : 16;
+    }
+    if (nsamp > 0) {
+        const int v = max_step <= kRowsMaxCodeStep ? kSeg : max_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
+        HIP_TRY(hipMemcpyAsync(a.d, a.h, (size_t) nchan * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_variant(v, a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, c->stream, na, amp, nullptr));
+        HIP_TRY(hipMemcpyAsync(dst, a.out, blk_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(a.done, c->stream));
+        a.busy = true;
+        c->anext = (c->anext + 1) & 3;
+    }
+    for (int i = 0; i < nchan; ++i) {
+        c->carry_prn[i] = ch[i].prn > 0 ? ch[i].prn : 0;
+        c->carry[i] = next[i];
+        c->handed[i] = ch[i].prn > 0 ? carr_phase_to_double(next[i]) : 0.0;
+        if (carr_phase_out) carr_phase_out[i] = ch[i].prn > 0 ? c->handed[i] : ch[i].carr_phase;
+    }
+    return GPSIQ_OK;
+}
+
+int gpsiq_wait(gpsiq_ctx_t *c)
+{
+    if (!c) return fail(GPSIQ_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &a : c->aslot) a.busy = false;
     return GPSIQ_OK;
 }
 

@@ -70,6 +70,8 @@ _quantize = _sig("gpsiq_quantize", _i, _vp, _i, _d, _i, _vp, _vp, _vp)
 _create = _sig("gpsiq_create", _i, C.POINTER(_vp), _i)
 _destroy = _sig("gpsiq_destroy", None, _vp)
 _generate_block = _sig("gpsiq_generate_block", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp)
+_generate_block_async = _sig("gpsiq_generate_block_async", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp)
+_wait = _sig("gpsiq_wait", _i, _vp)
 _generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i, _vp)
 _generate_quantized = _sig("gpsiq_generate_quantized", _i, _vp, _vp, _i, _i, _i, _i, _vp, _i)
 _quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp)
@@ -353,6 +355,17 @@ class Context:
         out = np.zeros(2 * nsamp, dtype=elem_dtype(sample_size))
         _check(_generate_block(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _p(out), _p(carr)))
         return out, carr
+
+    def generate_block_async(self, ch, nsamp, fs, sample_size, host_ptr):
+        """gpsiq_generate_block_async: queue one block into the page-locked buffer at host_ptr; returns the carrier
+        phases to hand back in (final at once).  The samples are there after wait()."""
+        ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)
+        carr = np.zeros(len(ch), dtype=np.float64)
+        _check(_generate_block_async(self._h, _p(ch), len(ch), int(nsamp), float(fs), int(sample_size), _vp(host_ptr), _p(carr)))
+        return carr
+
+    def wait(self):
+        _check(_wait(self._h))
 
     def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None, host_ptr=None, carr_out=None):
         """carr_out: optional float64[nchan] array that receives the carrier phase after the

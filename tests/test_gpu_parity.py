@@ -484,3 +484,38 @@ def test_bad_arguments_are_errors(ctx):
         ctx.generate_batch(bad, 100, 2.6e6, SC16)
     with pytest.raises(gpsiq.GpsiqError):
         ctx.generate_batch(d, 100, 2.6e6, 3)
+
+
+def test_asynchronous_block_calls(ctx, oracle):
+    """gpsiq_generate_block_async: blocks queued back to back into separate page-locked buffers (more than the ring of
+    four holds), the carrier handed back in at once, interleaved with a synchronous call: after gpsiq_wait every
+    buffer holds what the synchronous calls produce, i.e. the oracle's blocks with the exact carry."""
+    import torch
+    fs, ns, nb, nc = 2.6e6, 52000, 11, 9
+    d = synth_blocks(nb, nc, seed=83)
+    d["prn"][5:, 4] = 0
+    d["prn"][8:, 6] = 30
+    d["carr_phase"][8:, 6] = 0.8125
+    qo = oracle.quantize_blocks(d, fs, ns)
+    for ss in (SC08, SC16):
+        want = np.stack([oracle.block_fixed(qo[b], ns, ss) for b in range(nb)])
+        bufs = [torch.zeros(2 * ns * ss, dtype=torch.uint8).pin_memory() for _ in range(nb)]
+        carr = None
+        for b in range(nb):
+            db = d[b].copy()
+            if carr is not None:
+                keep = d[b]["prn"] == d[b - 1]["prn"]
+                db["carr_phase"] = np.where(keep, carr, db["carr_phase"])
+            if b == 6:                                   # a synchronous call in between queues behind the asynchronous ones
+                out, carr = ctx.generate_block(db, ns, fs, ss)
+                bufs[b].numpy().view(out.dtype)[:] = out
+            else:
+                carr = ctx.generate_block_async(db, ns, fs, ss, bufs[b].data_ptr())
+        ctx.wait()
+        for b in range(nb):
+            got = bufs[b].numpy().view(np.int8 if ss == SC08 else np.int16)
+            assert np.array_equal(got, want[b]), (ss, b)
+    ctx.set_nco_mode(1)
+    with pytest.raises(gpsiq.GpsiqError):
+        ctx.generate_block_async(d[0], ns, fs, SC08, bufs[0].data_ptr())
+    ctx.set_nco_mode(0)
