@@ -142,3 +142,44 @@ def test_scenario_to_samples_end_to_end(oracle):
         assert np.array_equal(out[b], oracle.block_fixed(q[b], ns, SC16, seq=True))
     assert np.ptp(desc["f_carr"], axis=0).max() > 50.0      # 105 m/s circle: hundreds of Hz of Doppler swing
     ctx.close()
+
+
+def test_refresh_epochs_equals_one_call_per_epoch():
+    """gpsiq_refresh_epochs (several navigation-message epochs in one threaded pass) == gpsiq_refresh_batch called once
+    per epoch with the word buffer of that epoch, for random epoch cuts; and its argument checks."""
+    import gpsiq
+    from gpsiq.abi import CHAN_DTYPE, TRACK_DTYPE
+    from gpsiq.scenario import circle_track, llh_to_ecef, synth_constellation, synth_iono, synth_tracks
+    pos = llh_to_ecef(35.681298, 139.766247, 10.0)
+    week, sec, nb, nc = 2190, 270000.0, 700, 9
+    eph = synth_constellation(nc, pos, sec, seed=31)
+    iono = synth_iono()
+    xyz = circle_track(pos, nb, radius_m=120.0, period_s=40.0)
+    rng = np.random.default_rng(4)
+    for trial in range(4):
+        cuts = [0] + sorted(set(int(c) for c in rng.integers(1, nb, size=int(rng.integers(0, 5)))))
+        trk0 = synth_tracks(nc, week, sec, seed=trial)
+        gpsiq.track_init(eph, iono, week, sec, xyz[0], trk0)
+        trk_ep = np.stack([trk0.copy() for _ in cuts])
+        for e in range(1, len(cuts)):                               # another word buffer and g0 per epoch
+            trk_ep[e]["dwrd"] = rng.integers(0, 1 << 30, size=(nc, 60), dtype=np.uint32)
+            trk_ep[e]["g0_sec"] = trk0["g0_sec"] + 30.0 * e
+        got = gpsiq.refresh_epochs(eph, iono, week, sec, xyz[1:], np.ascontiguousarray(trk_ep), cuts)
+        trk = trk0.copy()
+        want = np.zeros((nb, nc), dtype=CHAN_DTYPE)
+        for e, b0 in enumerate(cuts):
+            b1 = cuts[e + 1] if e + 1 < len(cuts) else nb
+            trk["dwrd"], trk["g0_week"], trk["g0_sec"] = trk_ep[e]["dwrd"], trk_ep[e]["g0_week"], trk_ep[e]["g0_sec"]
+            t = round(round(sec * 1000.0) + 100.0 * b0) / 1000.0
+            want[b0:b1] = gpsiq.refresh_batch(eph, iono, week, t, xyz[1 + b0:1 + b1], trk)
+        assert got.tobytes() == want.tobytes(), cuts
+        for f in ("rho0_week", "rho0_sec", "rho0_range"):
+            assert np.array_equal(trk_ep[0][f], trk[f])
+    bad = np.ascontiguousarray(np.stack([trk0, trk0]))
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.refresh_epochs(eph, iono, week, sec, xyz[1:], bad, [5, 10])          # must start at block 0
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.refresh_epochs(eph, iono, week, sec, xyz[1:], bad, [0, nb + 1])      # past the end
+    bad[1]["prn"][0] = 31
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.refresh_epochs(eph, iono, week, sec, xyz[1:], bad, [0, 100])         # another satellite in an epoch
