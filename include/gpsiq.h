@@ -18,6 +18,7 @@
  *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
  *   gps.c:2731-2765  per-block host refresh              -> gpsiq_refresh_batch(), gpsiq_track_init()
  *   gps.c:2142-2162  checkSatVisibility()                -> gpsiq_sat_visibility()
+ *   gps.c:361-447, 2253-2277  xyz2llh / llh2xyz / readUserMotion -> gpsiq_ecef_to_llh(), gpsiq_llh_to_ecef(), gpsiq_motion_read_csv()
  *   gps.c:617-884, 1008-1072, 2066-2140  nav words     -> gpsiq_nav_subframes/_message/_parity()
  *   gps.c:1131-1891  readRinex2 / readRinex3             -> gpsiq_rinex_read(), gpsiq_rinex_select()
  *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
@@ -323,6 +324,16 @@ int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int wee
  * (allocateChannel() itself always passes a mask of 0 degrees, gps.c:2175.) */
 int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const double xyz[3],
                          double elv_mask_deg, double azel[2]);
+
+/* Where the receiver is: the two inputs gps_thread_ep() turns into its xyz[] array before the block loop.
+ * gpsiq_llh_to_ecef = llh2xyz() (gps.c:412-447) for the static position `-l lat,lon,h` (gps.c:2480-2490 converts the
+ * degrees to radians first): llh = latitude and longitude in RADIANS, height in metres.  gpsiq_ecef_to_llh = xyz2llh()
+ * (gps.c:361-410).  gpsiq_motion_read_csv = readUserMotion() (gps.c:2253-2277): a text file with one line
+ * "t,x,y,z" per 0.1 s (ECEF metres, t ignored), at most max_points lines; returns the number of points read, -1 if
+ * the file cannot be opened. */
+void gpsiq_llh_to_ecef(const double llh[3], double xyz[3]);
+void gpsiq_ecef_to_llh(const double xyz[3], double llh[3]);
+int  gpsiq_motion_read_csv(const char *path, double *xyz /* [max_points][3] */, int max_points);
 
 /* Blocks k = 0..nblocks-1 at receiver times t_k = incGpsTime^(k+1)(week, sec) (the reference
  * advances grx by 0.1 s before the first block, gps.c:2692, and after every block, gps.c:2932)

@@ -314,6 +314,44 @@ int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int wee
     return GPSIQ_OK;
 }
 
+void gpsiq_ecef_to_llh(const double xyz[3], double llh[3])
+{
+    const Site s = site_from_ecef(xyz);                                       // gps.c:361-410
+    llh[0] = s.llh[0]; llh[1] = s.llh[1]; llh[2] = s.llh[2];
+}
+
+void gpsiq_llh_to_ecef(const double llh[3], double xyz[3])
+{
+    // gps.c:412-447: prime-vertical radius from e*sin(lat), then the three projections
+    const double a = kWgs84A, e = kWgs84E, e2 = e * e;
+    const double clat = cos_only(llh[0]), slat = sin_only(llh[0]);
+    const double clon = cos_only(llh[1]), slon = sin_only(llh[1]);
+    const double d = e * slat;
+    const double n = a / std::sqrt(1.0 - d * d);
+    const double nph = n + llh[2];
+    const double tmp = nph * clat;
+    xyz[0] = tmp * clon;
+    xyz[1] = tmp * slon;
+    xyz[2] = ((1.0 - e2) * n + llh[2]) * slat;
+}
+
+int gpsiq_motion_read_csv(const char *path, double *xyz, int max_points)
+{
+    if (!path || !xyz || max_points < 0) return fail(GPSIQ_E_ARG, "bad argument");
+    FILE *fp = std::fopen(path, "rt");
+    if (!fp) { (void) fail(GPSIQ_E_ARG, "cannot open %s", path); return -1; }          // gps.c:2259-2260
+    char line[100];                                                                     // MAX_CHAR, gps.h:30
+    int n = 0;
+    double t = 0.0, x = 0.0, y = 0.0, z = 0.0;
+    for (; n < max_points; ++n) {
+        if (!std::fgets(line, sizeof line, fp)) break;
+        if (std::sscanf(line, "%lf,%lf,%lf,%lf", &t, &x, &y, &z) == EOF) break;         // gps.c:2266: only EOF ends the file;
+        xyz[3 * n] = x; xyz[3 * n + 1] = y; xyz[3 * n + 2] = z;                         // a short line keeps the last values, as there
+    }
+    std::fclose(fp);
+    return n;
+}
+
 int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const double xyz[3],
                          double elv_mask_deg, double azel[2])
 {

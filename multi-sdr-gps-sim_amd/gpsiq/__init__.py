@@ -92,6 +92,9 @@ _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
 _sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
+_llh_to_ecef = _sig("gpsiq_llh_to_ecef", None, _vp, _vp)
+_ecef_to_llh = _sig("gpsiq_ecef_to_llh", None, _vp, _vp)
+_motion_read_csv = _sig("gpsiq_motion_read_csv", _i, C.c_char_p, _vp, _i)
 _nav_parity = _sig("gpsiq_nav_parity", C.c_uint32, C.c_uint32, _i)
 _nav_subframes = _sig("gpsiq_nav_subframes", _i, _vp, _vp, _vp, _vp)
 _nav_message = _sig("gpsiq_nav_message", _i, _vp, _i, _d, _i, _vp)
@@ -249,6 +252,31 @@ def refresh_epochs(eph, iono, week, sec, xyz, trk_epochs, first_block, gain_x2=F
     _check(_refresh_epochs(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), nc, int(bool(gain_x2)),
                            _p(trk_epochs), _p(first), ne, _p(out), int(nthreads)))
     return out
+
+
+def llh_to_ecef(lat_rad, lon_rad, h):
+    """llh2xyz() (reference gps.c:412-447): radians, metres -> ECEF metres."""
+    llh = np.array([lat_rad, lon_rad, h], dtype=np.float64)
+    xyz = np.zeros(3)
+    _llh_to_ecef(_p(llh), _p(xyz))
+    return xyz
+
+
+def ecef_to_llh(xyz):
+    """xyz2llh() (reference gps.c:361-410)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    llh = np.zeros(3)
+    _ecef_to_llh(_p(xyz), _p(llh))
+    return llh
+
+
+def motion_read_csv(path, max_points=3000):
+    """readUserMotion() (reference gps.c:2253-2277): -> xyz[n][3]; raises if the file cannot be opened."""
+    xyz = np.zeros((max_points, 3), dtype=np.float64)
+    n = _motion_read_csv(os.fsencode(path), _p(xyz), int(max_points))
+    if n < 0:
+        raise GpsiqError(n, _last_error().decode())
+    return xyz[:n].copy()
 
 
 def nav_parity(source, nib=False):

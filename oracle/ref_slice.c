@@ -61,6 +61,7 @@ static int ref_nchan = 12;
 #include "ref_navmsg.inc"            /* gps.c:2066-2140 generateNavMsg() */
 #include "ref_allocsat.inc"          /* gps.c:236       allocatedSat[] */
 #include "ref_allocate.inc"          /* gps.c:2142-2235 checkSatVisibility(), allocateChannel() */
+#include "ref_usermotion.inc"        /* gps.c:2253-2277 readUserMotion() */
 
 /* ---- capturing fifo (the tap SURVEY.md section 0 fact 6 asks for) --------- */
 static struct {
@@ -554,5 +555,16 @@ int ref_read_rinex(int version, const char *path, gpsiq_rinex_eph_t *out /* [13]
     utc->beta[0] = io.beta0; utc->beta[1] = io.beta1; utc->beta[2] = io.beta2; utc->beta[3] = io.beta3;
     utc->A0 = io.A0; utc->A1 = io.A1;
     if (date21) memcpy(date21, rinex_date, 21);
+    return n;
+}
+
+/* ---- where the receiver is: the reference's geodetic conversions and its user-motion reader ---- */
+void ref_llh2xyz(const double *llh, double *xyz) { llh2xyz(llh, xyz); }
+void ref_xyz2llh(const double *xyz, double *llh) { xyz2llh(xyz, llh); }
+int ref_read_user_motion(const char *path, double *xyz_out, int max_points)
+{
+    static double xyz[USER_MOTION_SIZE][3];
+    int n = readUserMotion(xyz, path);
+    for (int k = 0; k < n && k < max_points; k++) { xyz_out[3 * k] = xyz[k][0]; xyz_out[3 * k + 1] = xyz[k][1]; xyz_out[3 * k + 2] = xyz[k][2]; }
     return n;
 }

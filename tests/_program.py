@@ -20,7 +20,7 @@ def program(name):
 
 
 def write_circle_motion(path, seconds=30):
-    """A user-motion file in the reference's format (readUserMotion, gps.c:2253-2280: one line 't,x,y,z' per 0.1 s,
+    """A user-motion file in the reference's format (readUserMotion, gps.c:2253-2277: one line 't,x,y,z' per 0.1 s,
     ECEF metres): a 150 m circle around the static BASELINE position, 50 s per lap -- BASELINE config 4's kind of
     scenario (per-block range/Doppler refresh on the host), written by this repository's own track generator."""
     import sys

@@ -183,3 +183,39 @@ def test_refresh_epochs_equals_one_call_per_epoch():
     bad[1]["prn"][0] = 31
     with pytest.raises(gpsiq.GpsiqError):
         gpsiq.refresh_epochs(eph, iono, week, sec, xyz[1:], bad, [0, 100])         # another satellite in an epoch
+
+
+def test_receiver_position_inputs_match_reference(ref, tmp_path):
+    """gpsiq_llh_to_ecef / gpsiq_ecef_to_llh == llh2xyz / xyz2llh (gps.c:361-447) bit for bit, and
+    gpsiq_motion_read_csv == readUserMotion (gps.c:2253-2277) on well-formed and damaged files."""
+    import ctypes as C
+    import gpsiq
+    L = ref.lib
+    L.ref_llh2xyz.argtypes = [C.c_void_p, C.c_void_p]
+    L.ref_xyz2llh.argtypes = [C.c_void_p, C.c_void_p]
+    L.ref_read_user_motion.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(8)
+    for _ in range(300):
+        llh = np.array([rng.uniform(-np.pi / 2, np.pi / 2), rng.uniform(-np.pi, np.pi), rng.uniform(-500.0, 20000.0)])
+        want = np.zeros(3)
+        L.ref_llh2xyz(llh.ctypes.data, want.ctypes.data)
+        got = gpsiq.llh_to_ecef(*llh)
+        assert got.tobytes() == want.tobytes()
+        back, back_ref = gpsiq.ecef_to_llh(got), np.zeros(3)
+        L.ref_xyz2llh(got.ctypes.data, back_ref.ctypes.data)
+        assert back.tobytes() == back_ref.tobytes()
+    assert gpsiq.ecef_to_llh([0.0, 0.0, 0.0]).tolist() == [0.0, 0.0, -6378137.0]            # the reference's "invalid vector" answer
+    from gpsiq.scenario import circle_track, llh_to_ecef
+    xyz = circle_track(llh_to_ecef(35.681298, 139.766247, 10.0), 50)
+    good = tmp_path / "good.csv"
+    good.write_text("".join("%5.1f,%.3f,%.3f,%.3f\n" % (0.1 * k, *p) for k, p in enumerate(xyz)))
+    damaged = tmp_path / "damaged.csv"
+    damaged.write_text("0.0,1.5,2.5,3.5\n0.1,4.5\n\nnot a number\n0.4,7.0,8.0,9.0\n0.5, 10 , 11 ,12\n")
+    for path in (good, damaged):
+        want = np.zeros((3000, 3))
+        n_ref = L.ref_read_user_motion(str(path).encode(), want.ctypes.data, 3000)
+        got = gpsiq.motion_read_csv(str(path), 3000)
+        assert len(got) == n_ref and got.tobytes() == want[:n_ref].tobytes(), path
+    assert len(gpsiq.motion_read_csv(str(good), 7)) == 7
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.motion_read_csv(str(tmp_path / "missing.csv"))
