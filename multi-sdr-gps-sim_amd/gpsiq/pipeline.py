@@ -70,17 +70,26 @@ class RunAhead:
         self.trk["g0_week"], self.trk["g0_sec"] = self.nav["g0_week"], self.nav["g0_sec"]
 
     def seek(self, block, xyz_prev):
-        """Put the host state where the loop has it just before block `block`, without refreshing the
-        blocks in front of it: a rank of a time-sharded run starts here.  The navigation words are rolled
-        at every 30 s edge passed (cheap: one generateNavMsg per channel and edge); the previous block's
-        pseudorange (chan.rho0, gps.c:2063) is recomputed at its time and position xyz_prev -- a block's
-        range depends on nothing but time and position, so this is what the refresh would have left."""
-        assert self.blocks_done == 0 and block >= 0
-        if block == 0:
+        """Put the host state where the loop has it just before block `block` (at or after the current one),
+        without refreshing the blocks in between: a rank of a time-sharded run starts here, and skips the other
+        ranks' blocks here between its rounds.  Navigation words: a frame depends on its time, the week and the
+        page counter only (words 2 and 10 are solved so that every subframe ends on parity bits 00, gps.c:2093,
+        2127, so nothing of the chain crosses a subframe), and the word buffer holds the previous frame's
+        subframe 5 and the current frame (gps.c:2098-2103) -- so however many 30 s edges are passed, the last
+        two rolls with the page counter moved on give the buffer all of them would.  The previous block's
+        pseudorange (chan.rho0, gps.c:2063) is recomputed at its time and position xyz_prev -- a block's range
+        depends on nothing but time and position, so this is what the refresh would have left."""
+        n = block - self.blocks_done
+        assert n >= 0
+        if n == 0:
             return
-        for _, b1, roll in epoch_plan(self.sec, block):
-            if roll:
-                self._roll(gps_time_after(self.sec, b1))
+        first = 300 - int(round(gps_time_after(self.sec, self.blocks_done) * 10.0)) % 300     # epoch_plan's first edge
+        if n >= first:
+            edges = 1 + (n - first) // 300
+            if edges > 2:
+                self.nav["ipage"] = (self.nav["ipage"] + (edges - 2)) % 25
+            for k in range(max(0, edges - 2), edges):
+                self._roll(gps_time_after(self.sec, self.blocks_done + first + 300 * k))
         carr = self.trk["carr_phase"].copy()
         track_init(self.orbit, self.iono, self.week, gps_time_after(self.sec, block), np.asarray(xyz_prev, dtype=np.float64), self.trk)
         self.trk["carr_phase"] = carr                    # the loop's state, not the host model's (gps.c:2821)

@@ -22,21 +22,32 @@ def shard_descriptors(desc_all, fs, nsamp, rank, world):
     return np.ascontiguousarray(q_all[b0:b1]), (b0, b1)
 
 
-def quantize_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes):
+def quantize_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes, history=None):
     """Quantise ONLY this rank's blocks (desc_own = its rows of the timeline) and seed its carrier from
     the ranks before it.  all_gather_bytes(bytes) -> [bytes of rank 0, ..., bytes of rank world-1] is the
     one exchange needed (32 bytes per channel and rank; torch.distributed, MPI, a pipe -- anything).
-    The result equals shard_descriptors() of the whole timeline."""
+    The result equals shard_descriptors() of the whole timeline.
+
+    history: a list the caller keeps between calls when the timeline goes on in rounds (round m gives rank
+    r the blocks after those of rank r-1 of round m and after everything of round m-1): the carries of all
+    earlier ranges, in timeline order; this call appends its round's.  The host side of round m+1 can then
+    run while the GPUs are busy with round m."""
     q, _ = quantize_blocks(desc_own, fs, nsamp)               # block 0 seeded from its own carr_phase
     mine = shard_carry(q, nsamp)
     parts = all_gather_bytes(mine.tobytes())
     assert len(parts) == world
-    allc = np.stack([np.frombuffer(p, dtype=SHARD_CARRY_DTYPE) for p in parts])
-    return shard_seed(np.ascontiguousarray(q), nsamp, allc, rank)
+    now = [np.frombuffer(p, dtype=SHARD_CARRY_DTYPE) for p in parts]
+    before = [] if history is None else history
+    seeded = shard_seed(np.ascontiguousarray(q), nsamp, np.stack(before + now), len(before) + rank)
+    if history is not None:
+        history.extend(now)
+    return seeded
 
 
-def torch_all_gather_bytes(dist, device="cpu"):
-    """all_gather_bytes over a torch.distributed process group (gloo on CPU tensors, RCCL on GPU tensors)."""
+def torch_all_gather_bytes(dist, device="cpu", group=None):
+    """all_gather_bytes over a torch.distributed process group (gloo on CPU tensors, RCCL on GPU tensors).
+    A run that prepares its next round while the GPUs are busy wants a gloo group here: an RCCL collective
+    queues behind the kernels already launched on the device."""
     import torch
 
     def gather(b):
@@ -44,7 +55,7 @@ def torch_all_gather_bytes(dist, device="cpu"):
             return [b]
         t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(device)
         outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-        dist.all_gather(outs, t)
+        dist.all_gather(outs, t, group=group)
         return [bytes(o.cpu().numpy().tobytes()) for o in outs]
     return gather
 

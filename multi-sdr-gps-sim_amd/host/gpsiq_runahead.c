@@ -13,10 +13,16 @@
  *   gpsiq_nav_message(roll), next ephemeris set,
  *   allocate()                                   the 30 s refresh, gps.c:2870-2909
  *
- *   gpsiq_runahead <rinex> <2|3> <week> <sec> <xyz.bin> <nblocks> <nchan> <fs> <1|2> <out.bin>
+ *   gpsiq_runahead <rinex> <2|3> <week> <sec> <position> <nblocks> <nchan> <fs> <1|2> <out.bin>
  *
- * xyz.bin: double[nblocks+1][3] ECEF metres, row 0 = start position (the one allocateChannel()
- * always uses, gps.c:2675, 2909), row k+1 = position of block k.  out.bin: the iqfile stream.
+ * position, one of
+ *   xyz.bin        double[nblocks+1][3] ECEF metres, row 0 = start position (the one allocateChannel()
+ *                  always uses, gps.c:2675, 2909), row k+1 = position of block k
+ *   motion.csv     the reference's user-motion file (-m, gps.c:2253-2277, 2495-2505): "t,x,y,z" per 0.1 s,
+ *                  same row meaning; a file shorter than nblocks+1 points shortens the run as the
+ *                  reference's numd does
+ *   lat,lon,h      a static receiver, degrees and metres (-l, gps.c:2337-2340, 2359-2363)
+ * out.bin: the iqfile stream.
  */
 #include <math.h>
 #include <stdint.h>
@@ -117,10 +123,11 @@ static int refresh_ephemeris(struct host_state *h, double t)
 int main(int argc, char **argv)
 {
     if (argc != 11) {
-        fprintf(stderr, "usage: %s rinex 2|3 week sec xyz.bin nblocks nchan fs 1|2 out.bin\n", argv[0]);
+        fprintf(stderr, "usage: %s rinex 2|3 week sec xyz.bin|motion.csv|lat,lon,h nblocks nchan fs 1|2 out.bin\n", argv[0]);
         return 2;
     }
-    const int version = atoi(argv[2]), week = atoi(argv[3]), nblocks = atoi(argv[6]), nchan = atoi(argv[7]), ss = atoi(argv[9]);
+    const int version = atoi(argv[2]), week = atoi(argv[3]), nchan = atoi(argv[7]), ss = atoi(argv[9]);
+    int nblocks = atoi(argv[6]);
     const double sec0 = atof(argv[4]), fs = atof(argv[8]);
     const int nsamp = (int) floor(fs / 10.0 + 0.5);                           /* NUM_IQ_SAMPLES, sdr.h:26 */
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN || (ss != 1 && ss != 2)) { fprintf(stderr, "bad arguments\n"); return 2; }
@@ -133,9 +140,22 @@ int main(int argc, char **argv)
     if (ieph < 0) { fprintf(stderr, "gpsiq_runahead: no ephemeris for the start time\n"); return 1; }
 
     double *xyz = malloc(sizeof(double) * 3 * ((size_t) nblocks + 1));
-    FILE *fx = fopen(argv[5], "rb");
-    if (!xyz || !fx || fread(xyz, sizeof(double) * 3, (size_t) nblocks + 1, fx) != (size_t) nblocks + 1) { fprintf(stderr, "bad xyz file\n"); return 2; }
-    fclose(fx);
+    if (!xyz) { fprintf(stderr, "cannot allocate positions\n"); return 1; }
+    const size_t plen = strlen(argv[5]);
+    double llh[3];
+    if (plen > 4 && strcmp(argv[5] + plen - 4, ".csv") == 0) {
+        const int npoints = gpsiq_motion_read_csv(argv[5], xyz, nblocks + 1);
+        if (npoints <= 0) { fprintf(stderr, "gpsiq_runahead: cannot read motion file %s\n", argv[5]); return 1; }   /* gps.c:2497-2500 */
+        if (npoints - 1 < nblocks) nblocks = npoints - 1;                     /* numd points give numd - 1 blocks, gps.c:2703 */
+    } else if (sscanf(argv[5], "%lf,%lf,%lf", &llh[0], &llh[1], &llh[2]) == 3) {
+        llh[0] /= 57.2957795131; llh[1] /= 57.2957795131;                       /* R2D, gps.h:98 */
+        gpsiq_llh_to_ecef(llh, xyz);
+        for (int k = 1; k <= nblocks; ++k) memcpy(xyz + 3 * (size_t) k, xyz, sizeof(double) * 3);
+    } else {
+        FILE *fx = fopen(argv[5], "rb");
+        if (!fx || fread(xyz, sizeof(double) * 3, (size_t) nblocks + 1, fx) != (size_t) nblocks + 1) { fprintf(stderr, "bad xyz file\n"); return 2; }
+        fclose(fx);
+    }
 
     h.nchan = nchan; h.week = week; h.eph = eph[ieph]; h.sets = &eph[0][0]; h.nsets = nsets; h.ieph = ieph;
     memcpy(h.xyz0, xyz, sizeof h.xyz0);

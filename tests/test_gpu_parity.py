@@ -519,3 +519,30 @@ def test_asynchronous_block_calls(ctx, oracle):
     with pytest.raises(gpsiq.GpsiqError):
         ctx.generate_block_async(d[0], ns, fs, SC08, bufs[0].data_ptr())
     ctx.set_nco_mode(0)
+
+
+def test_descriptor_sets_swap_under_running_launches(ctx, oracle):
+    """A stream of rounds without a synchronisation in between: every round uploads a new descriptor set and
+    launches on the caller's stream while the launches of the rounds before are still running (the sets
+    alternate between two device buffers; the third set waits for the first one's launch only).  Every round's
+    output equals what the same set gives on its own, and the oracle."""
+    import torch
+    fs, ns, nb, nc, rounds = 2.6e6, 260000, 96, 16, 7
+    blk = 2 * ns
+    sets = [gpsiq.quantize_blocks(synth_blocks(nb, nc, seed=300 + m), fs, ns)[0] for m in range(rounds)]
+    out = torch.zeros(rounds * nb * blk, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for m in range(rounds):
+            ctx.set_descriptors(sets[m])
+            # two launches per set, so that a set is still in use when the next but one arrives
+            ctx.launch(0, nb // 2, ns, SC08, out.data_ptr() + m * nb * blk, blk, stream=side.cuda_stream)
+            ctx.launch(nb // 2, nb - nb // 2, ns, SC08, out.data_ptr() + (m * nb + nb // 2) * blk, blk, stream=side.cuda_stream)
+    side.synchronize()
+    got = out.cpu().numpy().view(np.int8).reshape(rounds, nb, blk)
+    for m in range(rounds):
+        ctx.set_descriptors(sets[m])
+        alone = run_device(ctx, sets[m], ns, SC08, "auto")
+        assert np.array_equal(got[m], alone), m
+        for b in (0, nb // 2 - 1, nb // 2, nb - 1):
+            assert np.array_equal(got[m, b], oracle.block_fixed(sets[m][b], ns, SC08)), (m, b)

@@ -91,6 +91,47 @@ def test_a_rank_can_start_anywhere(tmp_path, sec, moving):
         assert part.tobytes() == full[b0:b1].tobytes(), b0
 
 
+def test_seek_jumps_any_number_of_epochs_and_goes_on_from_anywhere(tmp_path):
+    """seek() rolls the navigation words only twice however many 30 s edges it passes (the page counter is moved
+    on instead) and may be called again after descriptors(): the rounds of a time-sharded run.  8 100 blocks = 27
+    edges, past the wrap of the 25-page counter."""
+    sec, nblocks = 270020.0, 8100
+    _, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving=False)
+    full = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    for b0 in (1500, 7790, 7800, 8050):
+        ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+        ra.seek(b0, xyz[b0])
+        assert ra.descriptors(xyz[1 + b0:1 + b0 + 50]).tobytes() == full[b0:b0 + 50].tobytes(), b0
+    ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+    for b0, n in ((0, 120), (120, 1), (400, 350), (2900, 100), (3000, 20), (7600, 500)):
+        ra.seek(b0, xyz[b0])
+        assert ra.descriptors(xyz[1 + b0:1 + b0 + n]).tobytes() == full[b0:b0 + n].tobytes(), b0
+
+
+def test_rounds_of_a_time_sharded_run_quantise_like_one_timeline(tmp_path):
+    """quantize_own_shard(history=...): round m gives rank r the blocks after rank r-1's of round m and after all
+    of round m-1; every rank's rows equal the rows of the whole timeline quantised in one go."""
+    from gpsiq.shard import quantize_own_shard
+    sec, world, nb, rounds, fs, ns = 270000.0, 3, 70, 4, 2.6e6, 260000
+    _, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, world * nb * rounds, moving=True)
+    full = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors(xyz[1:])
+    want, _ = gpsiq.quantize_blocks(full, fs, ns)
+    ras = [RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]) for _ in range(world)]
+    hist = [[] for _ in range(world)]
+    for m in range(rounds):
+        own, carries = [], []
+        for r in range(world):
+            b0 = (m * world + r) * nb
+            ras[r].seek(b0, xyz[b0])
+            own.append(ras[r].descriptors(xyz[1 + b0:1 + b0 + nb]))
+            carries.append(gpsiq.shard_carry(gpsiq.quantize_blocks(own[r], fs, ns)[0], ns).tobytes())
+        for r in range(world):
+            b0 = (m * world + r) * nb
+            got = quantize_own_shard(own[r], fs, ns, r, world, lambda mine: carries, history=hist[r])
+            assert got.tobytes() == want[b0:b0 + nb].tobytes(), (m, r)
+    assert all(len(h) == world * rounds for h in hist)
+
+
 def test_golden_multi_epoch_capture(tmp_path):
     """Committed capture of the reference loop incl. its nav refresh (runs without /root/reference):
     every block's descriptors by SHA-256, the blocks either side of each refresh byte for byte."""
@@ -284,6 +325,40 @@ def test_c_runahead_program_equals_the_python_pipeline(oracle, tmp_path):
     q = oracle.quantize_blocks(desc, fs, ns)
     for b in (0, 99, 100, 399, 400, 429):
         assert np.array_equal(got[b], oracle.block_fixed(q[b], ns, SC08)), b
+
+
+@pytest.mark.gpu
+def test_c_runahead_position_argument_forms(tmp_path):
+    """gpsiq_runahead's position argument: the reference's user-motion CSV (-m) and a static "lat,lon,h" (-l)
+    give the stream the same positions give as an xyz.bin; a short CSV shortens the run (numd, gps.c:2502-2505)."""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-sdr-gps-sim_amd", "host")
+    subprocess.run(["make", "-s", "-C", host], check=True)
+    nblocks, nchan, fs, ns = 6, 8, 2.6e6, 260000
+    path, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=8, sec=270000.0)
+    xyz = np.round(xyz, 4)                                        # what the CSV's %.4f keeps
+    def run(position, n=nblocks):
+        out = str(tmp_path / "o.bin")
+        r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), position, str(n), str(nchan),
+                            repr(fs), "1", out], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return np.fromfile(out, dtype=np.int8)
+    xyz.tofile(str(tmp_path / "xyz.bin"))
+    want = run(str(tmp_path / "xyz.bin"))
+    assert want.size == nblocks * 2 * ns
+    with open(tmp_path / "m.csv", "w") as f:
+        for k, p in enumerate(xyz):
+            f.write("%.1f,%.4f,%.4f,%.4f\n" % (0.1 * k, p[0], p[1], p[2]))
+    assert np.array_equal(run(str(tmp_path / "m.csv")), want)
+    assert np.array_equal(run(str(tmp_path / "m.csv"), n=50), want), "a 7-point file gives 6 blocks whatever was asked"
+    llh = (35.681298, 139.766247, 10.0)
+    static = np.tile(gpsiq.llh_to_ecef(np.array([llh[0] / 57.2957795131, llh[1] / 57.2957795131, llh[2]])), (nblocks + 1, 1))
+    static.tofile(str(tmp_path / "s.bin"))
+    assert np.array_equal(run("%r,%r,%r" % llh), run(str(tmp_path / "s.bin")))
+    r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "none.csv"), "2", "8",
+                        repr(fs), "1", str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "motion file" in r.stderr
 
 
 def late_scenario(tmp_path, nblocks, sec=270000.0, seed=11):
