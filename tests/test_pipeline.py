@@ -353,7 +353,7 @@ def test_c_runahead_position_argument_forms(tmp_path):
     assert np.array_equal(run(str(tmp_path / "m.csv")), want)
     assert np.array_equal(run(str(tmp_path / "m.csv"), n=50), want), "a 7-point file gives 6 blocks whatever was asked"
     llh = (35.681298, 139.766247, 10.0)
-    static = np.tile(gpsiq.llh_to_ecef(np.array([llh[0] / 57.2957795131, llh[1] / 57.2957795131, llh[2]])), (nblocks + 1, 1))
+    static = np.tile(gpsiq.llh_to_ecef(llh[0] / 57.2957795131, llh[1] / 57.2957795131, llh[2]), (nblocks + 1, 1))
     static.tofile(str(tmp_path / "s.bin"))
     assert np.array_equal(run("%r,%r,%r" % llh), run(str(tmp_path / "s.bin")))
     r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "none.csv"), "2", "8",
