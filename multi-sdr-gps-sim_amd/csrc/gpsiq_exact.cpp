@@ -52,6 +52,12 @@ struct Nco {
     long   n, wraps;  // wraps: number of wraps on the way to sample n (code: code periods completed)
     int    kind;
 
+    // Per binade of x (indexed by the exponent difference to the addend), filled on first use: the settled step dm in
+    // ulps (state 2: not usable -- exact tie, or step zero), and the run length from the binade's entry edge written as
+    // span = k*dm + rem, so that a run entered within one step of the edge needs a comparison instead of a division.
+    struct Piece { int64_t dm, span, k, rem, kdm; int state; };       // state 0: not built, 1: usable, 2: take the probing path
+    Piece piece[55] = {};
+
     inline double step(double v, int *wrapped) const
     {
         double y = v + c;
@@ -87,6 +93,37 @@ struct Nco {
         return cap;                                      // the addend is below half an ulp: the phase stands still
     }
 
+    void build_piece(Piece &p, int64_t shift, int64_t ex, int64_t mc, bool neg) const
+    {
+        // x + c inside x's binade is x + S with S = rnd(c/u) ulps, whatever x is -- unless c/u ends in exactly one
+        // half, where the rounding goes to even and depends on x's parity (left to the probing path of advance())
+        int64_t dm = shift == 0 ? mc : (shift >= 53 ? 0 : mc >> shift);
+        bool tie = false;
+        if (shift > 0 && shift <= 53) {
+            const int64_t rem = mc & (((int64_t) 1 << shift) - 1), half = (int64_t) 1 << (shift - 1);
+            if (rem > half) ++dm;
+            else if (rem == half) tie = true;
+        }
+        p.state = (tie || dm == 0) ? 2 : 1;
+        if (p.state == 2) return;
+        p.dm = dm;
+        if (!neg) {
+            // the run ends on the last mantissa of the binade -- or of the code period: the wrap comes before the binade
+            // ends only in the code phase's top binade [512, 1024), 1023 = 1023 * 2^43 ulps there (the carrier's top
+            // binade [0.5, 1) ends exactly at its wrap)
+            int64_t lim = (int64_t) 1 << 53;
+            if (kind == 0 && ex == 1023 + 9) lim = (int64_t) GPSIQ_CA_SEQ_LEN << 43;
+            p.span = lim - 1 - ((int64_t) 1 << 52);                       // from the first mantissa 2^52
+        } else {
+            // downwards the run must stay strictly above the binade's first value 2^52 ulps: a sum that falls below it is
+            // rounded on the finer grid of the binade underneath, so the last step onto (or from) 2^52 is a real addition
+            p.span = ((int64_t) 1 << 52) - 2;                             // from the last mantissa 2^53 - 1 down to 2^52 + 1
+        }
+        p.k = p.span / dm;
+        p.kdm = p.k * dm;
+        p.rem = p.span - p.kdm;
+    }
+
     // Move to sample `target` (>= n).
     void advance(long target)
     {
@@ -96,25 +133,22 @@ struct Nco {
         while (n < target) {
             const uint64_t bx = bits_of(x);
             const int64_t ex = (int64_t) (bx >> 52);
-            if (ex != 0 && ec != 0 && ex >= ec) {
-                // x + c inside x's binade is x + S with S = rnd(c/u) ulps, whatever x is -- unless c/u ends in exactly
-                // one half, where the rounding goes to even and depends on x's parity (handled by probing below)
-                const int64_t shift = ex - ec;
-                int64_t dm = 0;
-                bool tie = false;
-                if (shift == 0) dm = mc;
-                else if (shift <= 53) {
-                    dm = shift == 53 ? 0 : mc >> shift;
-                    const int64_t rem = mc & (((int64_t) 1 << shift) - 1), half = (int64_t) 1 << (shift - 1);
-                    if (rem > half) ++dm;
-                    else if (rem == half) tie = true;
-                }
-                if (!tie) {
+            if (ex != 0 && ec != 0 && ex >= ec && ex - ec <= 54) {
+                Piece &p = piece[ex - ec];
+                if (p.state == 0) build_piece(p, ex - ec, ex, mc, neg);
+                if (p.state == 1) {
                     const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1));
+                    // distance of x from the edge the run was measured from; the run is (span - off) / dm steps long
+                    const int64_t off = neg ? (((int64_t) 1 << 53) - 1) - mx : mx - ((int64_t) 1 << 52);
+                    int64_t run, moved;
+                    if (off <= p.rem) { run = p.k; moved = p.kdm; }
+                    else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
+                    else if (off > p.span) { run = 0; moved = 0; }
+                    else { run = (p.span - off) / p.dm; moved = run * p.dm; }
                     const long cap = target - n;
-                    const long run = run_length(mx, neg ? -dm : dm, (uint64_t) ex, cap);
+                    if (run >= cap) { run = cap; moved = run * p.dm; }
                     if (run > 0) {
-                        x = from_bits((bx & ~kMant) | ((uint64_t) (mx + (int64_t) run * (neg ? -dm : dm)) & kMant));
+                        x = from_bits((bx & ~kMant) | ((uint64_t) (neg ? mx - moved : mx + moved) & kMant));
                         n += run;
                         if (run == cap) return;
                     }
@@ -130,6 +164,7 @@ struct Nco {
             // consecutive additions inside one binade have shown the settled step
             int wy;
             const double y = step(x, &wy);
+            if (y == x && !wy) { n = target; return; }           // the addend no longer moves x: it never will again
             const uint64_t by = bits_of(y);
             if (wy || (bx >> 52) != (by >> 52) || (bx >> 52) == 0) {
                 x = y; ++n; wraps += wy;

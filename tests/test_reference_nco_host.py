@@ -66,3 +66,27 @@ def test_corners_of_the_double_arithmetic(oracle):
             o, cin = oracle.block_float_closed(db, ns, fs, SC16)
             assert np.array_equal(o, want[b]), (fs, ns, b)
         assert np.array_equal(cin, carr_want)
+
+
+def test_carrier_walk_fuzz_against_the_plain_loop(oracle):
+    """The carrier phase gpsiq_reference_batch hands on after a block (per-binade run lengths from a table, real
+    additions at the crossings) against the plain loop of additions, over addends from far below an ulp to half a
+    cycle per sample, both signs, and start phases on and next to powers of two."""
+    rng = np.random.default_rng(77)
+    fs = 2.6e6
+    for it in range(250):
+        ns = int(rng.integers(1, 30000))
+        d = synth_blocks(1, 16, seed=1000 + it)
+        mag = 10.0 ** rng.uniform(-13.0, np.log10(0.49 * fs), 16)
+        d["f_carr"][0] = mag * rng.choice([-1.0, 1.0], 16)
+        if it % 5 == 0:                                   # addends that are exact binary fractions of a cycle: ties
+            d["f_carr"][0, :8] = fs * 2.0 ** -rng.integers(8, 60, 8) * rng.choice([-1.0, 1.0, 1.5, -3.0], 8)
+        d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+        ph = rng.uniform(0.0, 1.0, 16)
+        k = rng.integers(1, 40, 16)
+        edge = 2.0 ** -k.astype(np.float64)
+        ph = np.where(rng.random(16) < 0.3, edge * (1.0 + rng.integers(-2, 3, 16) * 2.0 ** -52), ph)
+        d["carr_phase"][0] = np.clip(ph, 0.0, np.nextafter(1.0, 0.0))
+        _, want = oracle.block_float(d[0], ns, fs, SC08)
+        _, _, got = gpsiq.reference_blocks(d, fs, ns)
+        assert got.tobytes() == want.tobytes(), (it, ns, d["f_carr"][0][got != want], d["carr_phase"][0][got != want])
