@@ -23,6 +23,22 @@ def host_built():
     return HOST
 
 
+def run_sanitized(cmd, **kw):
+    """Run a sanitizer build.  The sanitizer runtimes reserve fixed address ranges and on kernels with wide address
+    space randomisation now and then die at start-up (killed by a signal, or 'unexpected memory mapping', before main
+    runs): such a run is repeated with randomisation off (setarch -R) and, if the runtime still cannot start, skipped.
+    A run that reaches main and fails, or reports anything, is returned as it is."""
+    r = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    startup = ("FATAL: ThreadSanitizer", "unexpected memory mapping", "Shadow memory range interleaves", "ReserveShadowMemoryRange failed")
+    died_early = lambda q: (q.returncode < 0 and not q.stdout and "Sanitizer:" not in q.stderr.replace("FATAL: ThreadSanitizer", "")) \
+        or any(m in q.stderr for m in startup)
+    if died_early(r) and shutil.which("setarch"):
+        r = subprocess.run(["setarch", os.uname().machine, "-R", *cmd], capture_output=True, text=True, **kw)
+    if died_early(r):
+        pytest.skip("the sanitizer runtime cannot start in this container: rc %d %s" % (r.returncode, r.stderr.strip()[-160:]))
+    return r
+
+
 def test_fifo_is_drop_free_and_ordered(host_built):
     r = subprocess.run([os.path.join(host_built, "fifo_selftest"), "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
@@ -34,10 +50,8 @@ def test_fifo_under_thread_sanitizer(tmp_path):
                         os.path.join(HOST, "fifo_selftest.c"), os.path.join(HOST, "fifo.c")], capture_output=True, text=True)
     if b.returncode != 0:
         pytest.skip("no ThreadSanitizer runtime here: " + b.stderr[-200:])
-    r = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=600)
-    if "FATAL: ThreadSanitizer" in r.stderr or "unexpected memory mapping" in r.stderr:
-        pytest.skip("ThreadSanitizer cannot run in this container: " + r.stderr.strip()[-160:])
-    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-2000:]
+    r = run_sanitized([exe, "3000"], timeout=600)
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, "rc %d\n%s" % (r.returncode, (r.stdout + r.stderr)[-2000:])
 
 
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
@@ -70,11 +84,7 @@ def test_host_half_under_sanitizers(tmp_path, san):
     recs = synth_rinex_records(10, pos, 2190, 270000.0, seed=13, sets=2)
     for version in (2, 3):
         path = write_rinex_nav(str(tmp_path / f"in.v{version}"), recs, utc, version)
-        r = subprocess.run([exe, path, str(tmp_path / "cut"), str(version)], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
-        if ("Shadow memory range interleaves" in r.stderr or "ReserveShadowMemoryRange failed" in r.stderr
-                or "FATAL: ThreadSanitizer" in r.stderr or "unexpected memory mapping" in r.stderr):
-            pytest.skip("the sanitizer runtime cannot map its shadow memory in this container")
+        r = run_sanitized([exe, path, str(tmp_path / "cut"), str(version)], timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
         assert r.returncode == 0 and r.stdout.strip() == "ok" and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
 
 
