@@ -9,7 +9,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <ctime>
 #include <pthread.h>
 #include <unistd.h>
 #include <vector>
@@ -30,13 +29,10 @@ int fail(int code, const char *fmt, ...)
 // ---- parallel_for: a small persistent worker pool -----------------------------
 // Spawning threads per call costs more than the work of a 4000-block batch on a 256-core
 // host (measured: 65 pthread_create/join ~ 2.4 ms vs 0.6 ms of quantising), so the workers
-// are created once, on first use, and sleep on a condition variable between jobs -- after
-// watching the job counter for a few tens of microseconds first: a batch call is a handful of
-// jobs back to back (refresh passes, quantise, validate) of a few hundred microseconds each, and
-// waking fifteen sleepers through the kernel costs 30-80 us per job (GPSIQ_SPIN_US, default 60,
-// 0 = sleep at once).  Ranges are handed out in chunks from a shared counter; the caller works
-// too.  One job at a time: a second caller (or a nested call) simply runs its range inline.  The
-// workers are detached and never exit; the library is not meant to be dlclose()d.
+// are created once, on first use, and sleep on a condition variable between jobs.  Ranges are
+// handed out in chunks from a shared counter; the caller works too.  One job at a time: a
+// second caller (or a nested call) simply runs its range inline.  The workers are detached
+// and never exit; the library is not meant to be dlclose()d.
 namespace {
 constexpr int kMaxWorkers = 63;
 struct Pool {
@@ -52,40 +48,6 @@ struct Pool {
 };
 Pool g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
                0, 0, {}, 0, 0, nullptr, nullptr, 0, 0, 0};
-
-inline void cpu_relax()
-{
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#else
-    __asm__ __volatile__("" ::: "memory");
-#endif
-}
-
-long spin_ns()
-{
-    static const long ns = [] { const char *e = std::getenv("GPSIQ_SPIN_US"); const long us = e ? std::atol(e) : 60; return (us < 0 ? 0 : us) * 1000L; }();
-    return ns;
-}
-
-// Poll until (*word == value) == until_equal, for up to spin_ns(); false if the budget ran out first.
-template <typename T> bool spin_until(const T *word, T value, bool until_equal)
-{
-    const long budget = spin_ns();
-    if (budget == 0) return false;
-    timespec t0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (;;) {
-        for (int k = 0; k < 32; ++k) {
-            const T v = __atomic_load_n(word, __ATOMIC_ACQUIRE);
-            if ((v == value) == until_equal) return true;
-            cpu_relax();
-        }
-        timespec t1;
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > budget) return false;
-    }
-}
 
 void pool_run_chunks()
 {
@@ -104,16 +66,15 @@ void *pool_worker(void *arg)
     const int idx = (int) (intptr_t) arg;
     unsigned long seen = p.start_gen[idx];
     for (;;) {
-        spin_until(&p.gen, seen, false);                 // the next job usually follows at once
         pthread_mutex_lock(&p.m);
-        while (__atomic_load_n(&p.gen, __ATOMIC_RELAXED) == seen) pthread_cond_wait(&p.go, &p.m);
-        seen = __atomic_load_n(&p.gen, __ATOMIC_RELAXED);
+        while (p.gen == seen) pthread_cond_wait(&p.go, &p.m);
+        seen = p.gen;
         const bool mine = idx < p.want;
         pthread_mutex_unlock(&p.m);
         if (!mine) continue;
         pool_run_chunks();
         pthread_mutex_lock(&p.m);
-        if (__atomic_sub_fetch(&p.pending, 1, __ATOMIC_ACQ_REL) == 0) pthread_cond_signal(&p.done);
+        if (--p.pending == 0) pthread_cond_signal(&p.done);
         pthread_mutex_unlock(&p.m);
     }
     return nullptr;
@@ -167,15 +128,13 @@ void parallel_for(int n, int nthreads, int grain, void (*fn)(void *, int, int), 
     p.fn = fn; p.ctx = ctx; p.n = n; p.next = 0;
     const long per = ((long) n + (long) (helpers + 1) * 4 - 1) / ((long) (helpers + 1) * 4);
     p.chunk = per > grain ? per : grain;
-    p.want = helpers;
-    __atomic_store_n(&p.pending, helpers, __ATOMIC_RELAXED);
-    __atomic_store_n(&p.gen, p.gen + 1, __ATOMIC_RELEASE);
+    p.want = p.pending = helpers;
+    ++p.gen;
     pthread_cond_broadcast(&p.go);
     pthread_mutex_unlock(&p.m);
     pool_run_chunks();
-    spin_until(&p.pending, 0, true);                     // the helpers finish within microseconds of the caller
-    pthread_mutex_lock(&p.m);                            // (and the last one may still be inside its signal: wait for the mutex)
-    while (__atomic_load_n(&p.pending, __ATOMIC_ACQUIRE)) pthread_cond_wait(&p.done, &p.m);
+    pthread_mutex_lock(&p.m);
+    while (p.pending) pthread_cond_wait(&p.done, &p.m);
     pthread_mutex_unlock(&p.m);
     pthread_mutex_unlock(&p.submit);
 }
