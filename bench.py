@@ -383,7 +383,7 @@ def main():
         side = None
         cpu_gather = gather
         exchange = backend if dist is not None else None
-        if dist is not None and backend == "nccl":
+        if dist is not None:                              # always a side group (also under gloo): one code path, tested on CPU
             try:                                          # 32 B per channel of host data: a CPU collective, so that it
                 side = dist.new_group(backend="gloo")     # does not queue behind the kernels on the device
                 cpu_gather = torch_all_gather_bytes(dist, "cpu", group=side)
