@@ -204,6 +204,17 @@ class Scenario:
         from gpsiq.pipeline import RunAhead
         return RunAhead(self.eph[self.ieph], self.utc, self.svs, WEEK, SEC0, self.pos)
 
+    def quantised(self, b0, b1, fs, nsamp, ra=None):
+        """gpsiq_qchan_t rows [b0, b1) of the run (self-seeded), refresh and quantiser fused in C
+        (gpsiq_refresh_epochs_quantized); ra as in descriptors()."""
+        from gpsiq.abi import QCHAN_DTYPE
+        ra = ra or self.runahead()
+        ra.seek(b0, self.pos)
+        xyz = np.repeat(self.pos[None, :], b1 - b0, axis=0)
+        if getattr(self, "_qbuf", None) is None or self._qbuf.shape != (b1 - b0, len(self.svs)):
+            self._qbuf = np.empty((b1 - b0, len(self.svs)), dtype=QCHAN_DTYPE)
+        return ra.descriptors_quantized(xyz, fs, nsamp, out=self._qbuf)
+
     def descriptors(self, b0, b1, nthreads=0, ra=None):
         """gpsiq_chan_t rows [b0, b1) of the run, computing only those (RunAhead.seek); ra: a RunAhead that
         has got as far as some block <= b0 (the rounds of the streamed leg), default a fresh one."""
@@ -255,7 +266,7 @@ def main():
     import torch
     import gpsiq
     from gpsiq.scenario import synth_blocks
-    from gpsiq.shard import max_over_ranks, quantize_own_shard, shard_range, torch_all_gather_bytes
+    from gpsiq.shard import max_over_ranks, quantize_own_shard, seed_own_shard, shard_range, torch_all_gather_bytes
     dev = 0
     if not dry:
         if not torch.cuda.is_available():
@@ -349,9 +360,9 @@ def main():
         for _ in range(2):                                # the second pass has warm thread pools and buffers
             sync_all()
             ta = time.perf_counter()
-            d_e = scen.descriptors(g0, g1)
+            q_e = scen.quantised(g0, g1, fs, nsamp)
             tb = time.perf_counter()
-            q_e = quantize_own_shard(d_e, fs, nsamp, rank, world, gather)
+            q_e = seed_own_shard(q_e, nsamp, rank, world, gather)
             tc = time.perf_counter()
             if not dry:
                 ctx.set_descriptors(q_e)
@@ -369,12 +380,12 @@ def main():
         e2e = {"value": None if dry else round(nb_e * world * nsamp / tot / 1e6, 1), "unit": "Msamples/s",
                "blocks_per_gpu": nb_e, "channels": len(scen.svs), "seconds": round(tot, 5),
                "x_realtime": None if dry else round(nb_e * world * 0.1 / tot, 1),
-               "host_refresh_ms": round(parts[0] * 1e3, 2), "quantise_and_seed_exchange_ms": round(parts[1] * 1e3, 2),
+               "host_refresh_and_quantise_ms": round(parts[0] * 1e3, 2), "seed_exchange_ms": round(parts[1] * 1e3, 2),
                "validate_upload_ms": round(parts[2] * 1e3, 2), "kernel_ms": round(parts[3] * 1e3, 2),
                "host_cpus": effective_cpus(),
                "what": "static receiver (BASELINE config 1/2 geometry), RINEX-derived ephemeris; per rank: RunAhead.seek to its first block, "
-                       "nav words rolled over its 30 s epochs (gpsiq_nav_roll), gpsiq_refresh_epochs of its own blocks only, gpsiq_quantize_batch, "
-                       "32 B/channel carrier-seed all-gather, gpsiq_set_descriptors, one gpsiq_launch; slowest rank, best of 2 passes"}
+                       "nav words rolled over its 30 s epochs (gpsiq_nav_roll), gpsiq_refresh_epochs_quantized of its own blocks only "
+                       "(refresh and quantiser in one pass), 32 B/channel carrier-seed all-gather, gpsiq_set_descriptors, one gpsiq_launch; slowest rank, best of 2 passes"}
         # ---- the same chain as a stream of rounds: round m gives this rank the blocks after rank-1's of round m
         # and after all of round m-1; launches are asynchronous, so the host side of round m+1 (refresh, quantise,
         # seed exchange on a gloo group, validate + upload into the other descriptor buffer) runs while the GPU is
@@ -399,8 +410,7 @@ def main():
             for m in range(R):
                 th = time.perf_counter()
                 g0 = (m * world + rank) * nb_e
-                d_e = scen.descriptors(g0, g0 + nb_e, ra=ra)
-                q_e = quantize_own_shard(d_e, fs, nsamp, rank, world, cpu_gather, history=hist)
+                q_e = seed_own_shard(scen.quantised(g0, g0 + nb_e, fs, nsamp, ra=ra), nsamp, rank, world, cpu_gather, history=hist)
                 host_busy += time.perf_counter() - th
                 if not dry:
                     ctx.set_descriptors(q_e)

@@ -354,6 +354,16 @@ int gpsiq_refresh_epochs(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int
                          gpsiq_track_t *trk_epochs /* [nepochs][nchan] */, const int *first_block /* [nepochs] */,
                          int nepochs, gpsiq_chan_t *out, int nthreads);
 
+/* gpsiq_refresh_epochs followed by gpsiq_quantize_batch(carry_in = NULL) in one pass over the blocks: the same
+ * out[nblocks][nchan] gpsiq_qchan_t those two calls give (block 0 of a slot seeded from trk_epochs[0][c].carr_phase,
+ * later blocks chained with the exact carrier prefix), without the double-precision descriptors -- 296 bytes per
+ * channel and block, mostly the nav-word buffer -- ever being written to memory.  For a run-ahead host that feeds
+ * gpsiq_set_descriptors / gpsiq_generate_quantized. */
+int gpsiq_refresh_epochs_quantized(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                                   const double *xyz, int nblocks, int nchan, int gain_x2,
+                                   gpsiq_track_t *trk_epochs /* [nepochs][nchan] */, const int *first_block /* [nepochs] */,
+                                   int nepochs, double fs, int nsamp, gpsiq_qchan_t *out, int nthreads);
+
 /* ---- navigation message words ------------------- */
 /* The 60-word rolling buffer dwrd[] the sample loop reads its data bits from
  * (gps.c:2811) is built by the reference from the broadcast ephemeris: eph2sbf()

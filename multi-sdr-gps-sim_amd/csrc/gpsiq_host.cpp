@@ -258,7 +258,14 @@ int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double del
             }
     }, &qj);
     if (qj.rc != GPSIQ_OK) return fail(qj.rc, "%s", qj.err);
-    // pass 2, serial and touching only q (cache-resident): p_{k+1} = p_k + nsamp*step_k (mod 2^59)
+    chain_carrier(q, nblocks, nchan, nsamp, cont0, carry0, carry_end, last_prn);
+    return GPSIQ_OK;
+}
+
+// serial and touching only q (cache-resident): p_{k+1} = p_k + nsamp*step_k (mod 2^59)
+void chain_carrier(gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp, const bool *cont0, const uint64_t *carry0,
+                   uint64_t *carry_end, int *last_prn)
+{
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     int prev_prn[GPSIQ_MAX_CHAN] = {};
     const uint64_t mask = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1;
@@ -275,7 +282,6 @@ int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double del
         if (carry_end) carry_end[i] = carry[i];
         if (last_prn) last_prn[i] = prev_prn[i];
     }
-    return GPSIQ_OK;
 }
 
 }  // namespace gpsiq

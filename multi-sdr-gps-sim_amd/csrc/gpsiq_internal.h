@@ -23,6 +23,10 @@ int  quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t
 // chain the carrier exactly: block 0 slot i starts from carry0[i] where cont0[i] is set, a later
 // block continues the previous one while the slot keeps its PRN, and re-seeds from its own
 // carr_phase otherwise.  carry_end / last_prn (may be null) receive the state after the last block.
+// The serial half of quantize_timeline: p_{k+1} = p_k + nsamp*step_k (mod 2^59) down each slot of an already
+// quantised (self-seeded) timeline; cont0/carry0 as in quantize_timeline.
+void chain_carrier(gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp, const bool *cont0, const uint64_t *carry0,
+                   uint64_t *carry_end, int *last_prn);
 int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
                       const bool *cont0, const uint64_t *carry0, gpsiq_qchan_t *q,
                       uint64_t *carry_end, int *last_prn);

@@ -238,6 +238,10 @@ struct Job {
     // several navigation-message epochs in one batch: epoch e covers blocks [first[e], first[e+1]) and reads its
     // word buffer and g0 from trk[e*nchan + c]; prn / rho0 / carr_phase always come from trk[0..nchan)
     const int *first = nullptr; int nepochs = 1;
+    // fused with the quantiser (gpsiq_refresh_epochs_quantized): the descriptor of a block is built on the stack and
+    // quantised at once; out is not written
+    gpsiq_qchan_t *qout = nullptr; double delt = 0.0; int nsamp = 0;
+    mutable int rc = GPSIQ_OK; mutable char err[320] = "";
 };
 
 void work(void *p, int b0, int b1)
@@ -253,11 +257,15 @@ void work(void *p, int b0, int b1)
             int ep = 0;
             if (j.nepochs > 1) { while (ep + 1 < j.nepochs && j.first[ep + 1] <= b) ++ep; }
             const gpsiq_track_t *nav = j.trk + (size_t) ep * j.nchan;      // word buffer and g0 of this block's epoch
+            gpsiq_chan_t tmp;
             for (int c = 0; c < j.nchan; ++c) {
-                gpsiq_chan_t &o = j.out[(size_t) b * j.nchan + c];
+                gpsiq_chan_t &o = j.qout ? tmp : j.out[(size_t) b * j.nchan + c];
                 std::memset(&o, 0, sizeof o);
                 o.prn = j.trk[c].prn > 0 ? j.trk[c].prn : 0;
-                if (o.prn == 0) continue;
+                if (o.prn == 0) {
+                    if (j.qout) std::memset(&j.qout[(size_t) b * j.nchan + c], 0, sizeof(gpsiq_qchan_t));
+                    continue;
+                }
                 const Range &r0 = j.rng[(size_t) b * j.nchan + c], &r1 = j.rng[(size_t) (b + 1) * j.nchan + c];
                 // time of the previous range (chan.rho0.g): the carried-in one for the first block
                 const GpsTime t0 = b == 0 ? GpsTime{j.trk[c].rho0_week, j.trk[c].rho0_sec} : j.t[b];
@@ -281,6 +289,11 @@ void work(void *p, int b0, int b1)
                 if (j.gain_x2) g *= 2;
                 o.gain = g;
                 std::memcpy(o.dwrd, nav[c].dwrd, sizeof o.dwrd);
+                if (j.qout) {
+                    const int rc = gpsiq::quantize_one(o, j.delt, j.nsamp, nullptr, &j.qout[(size_t) b * j.nchan + c], nullptr);
+                    if (rc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, rc))
+                        std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error());
+                }
             }
         }
     }
@@ -372,7 +385,22 @@ int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const d
 
 static int refresh_impl(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
                         const double *xyz, int nblocks, int nchan, int gain_x2,
-                        gpsiq_track_t *trk, const int *first, int nepochs, gpsiq_chan_t *out, int nthreads);
+                        gpsiq_track_t *trk, const int *first, int nepochs, gpsiq_chan_t *out, int nthreads,
+                        gpsiq_qchan_t *qout = nullptr, double fs = 0.0, int nsamp = 0);
+
+static int check_epochs(const gpsiq_track_t *trk_epochs, const int *first_block, int nepochs, int nblocks, int nchan)
+{
+    if (!first_block || nepochs < 1) return fail(GPSIQ_E_ARG, "bad epoch list");
+    for (int e = 0; e < nepochs; ++e)
+        if (first_block[e] < 0 || first_block[e] > nblocks || (e == 0 ? first_block[0] != 0 : first_block[e] < first_block[e - 1]))
+            return fail(GPSIQ_E_ARG, "epoch %d starts at block %d: not an ascending cover of [0, %d)", e, first_block[e], nblocks);
+    if (trk_epochs)
+        for (int e = 1; e < nepochs; ++e)
+            for (int c = 0; c < nchan && c < GPSIQ_MAX_CHAN; ++c)
+                if (trk_epochs[(size_t) e * nchan + c].prn != trk_epochs[c].prn)
+                    return fail(GPSIQ_E_ARG, "epoch %d slot %d holds another satellite: one call covers one allocation", e, c);
+    return GPSIQ_OK;
+}
 
 int gpsiq_refresh_batch(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
                         const double *xyz, int nblocks, int nchan, int gain_x2,
@@ -386,23 +414,30 @@ int gpsiq_refresh_epochs(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int
                          gpsiq_track_t *trk_epochs, const int *first_block, int nepochs,
                          gpsiq_chan_t *out, int nthreads)
 {
-    if (!first_block || nepochs < 1) return fail(GPSIQ_E_ARG, "bad epoch list");
-    for (int e = 0; e < nepochs; ++e)
-        if (first_block[e] < 0 || first_block[e] > nblocks || (e == 0 ? first_block[0] != 0 : first_block[e] < first_block[e - 1]))
-            return fail(GPSIQ_E_ARG, "epoch %d starts at block %d: not an ascending cover of [0, %d)", e, first_block[e], nblocks);
-    if (trk_epochs)
-        for (int e = 1; e < nepochs; ++e)
-            for (int c = 0; c < nchan && c < GPSIQ_MAX_CHAN; ++c)
-                if (trk_epochs[(size_t) e * nchan + c].prn != trk_epochs[c].prn)
-                    return fail(GPSIQ_E_ARG, "epoch %d slot %d holds another satellite: one call covers one allocation", e, c);
+    const int rc = check_epochs(trk_epochs, first_block, nepochs, nblocks, nchan);
+    if (rc) return rc;
     return refresh_impl(eph, iono, week, sec, xyz, nblocks, nchan, gain_x2, trk_epochs, first_block, nepochs, out, nthreads);
+}
+
+int gpsiq_refresh_epochs_quantized(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
+                                   const double *xyz, int nblocks, int nchan, int gain_x2,
+                                   gpsiq_track_t *trk_epochs, const int *first_block, int nepochs,
+                                   double fs, int nsamp, gpsiq_qchan_t *out, int nthreads)
+{
+    if (!out) return fail(GPSIQ_E_ARG, "null argument");
+    const int rc = check_epochs(trk_epochs, first_block, nepochs, nblocks, nchan);
+    if (rc) return rc;
+    return refresh_impl(eph, iono, week, sec, xyz, nblocks, nchan, gain_x2, trk_epochs, first_block, nepochs, nullptr, nthreads,
+                        out, fs, nsamp);
 }
 
 static int refresh_impl(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int week, double sec,
                         const double *xyz, int nblocks, int nchan, int gain_x2,
-                        gpsiq_track_t *trk, const int *first, int nepochs, gpsiq_chan_t *out, int nthreads)
+                        gpsiq_track_t *trk, const int *first, int nepochs, gpsiq_chan_t *out, int nthreads,
+                        gpsiq_qchan_t *qout, double fs, int nsamp)
 {
-    if (!eph || !iono || !xyz || !trk || !out) return fail(GPSIQ_E_ARG, "null argument");
+    if (!eph || !iono || !xyz || !trk || (!out && !qout)) return fail(GPSIQ_E_ARG, "null argument");
+    if (qout && (!(fs > 0.0) || nsamp < 0)) return fail(GPSIQ_E_ARG, "bad fs %g / nsamp %d", fs, nsamp);
     if (nchan < 1 || nchan > GPSIQ_MAX_CHAN || nblocks < 0) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     if (nblocks == 0) return GPSIQ_OK;
     double ant_pat[37];
@@ -422,11 +457,14 @@ static int refresh_impl(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int 
     t[0] = GpsTime{week, sec};
 
     Job job = {eph, iono, xyz, t.data(), nchan, gain_x2, trk, ant_pat, rng.data(), out, 0, first, nepochs};
+    job.qout = qout; job.delt = qout ? 1.0 / fs : 0.0; job.nsamp = nsamp;
     // pass 0 costs ~4 us per block (16 satellite positions with light-time iteration), waking the pool ~20 us:
     // 64 blocks per thread keep a 300-block epoch of the run-ahead loop (gpsiq/pipeline.py) on several cores
     parallel_for(nblocks, nthreads, 64, work, &job);
     job.pass = 1;
     parallel_for(nblocks, nthreads, 256, work, &job);
+    if (job.rc != GPSIQ_OK) return fail(job.rc, "%s", job.err);
+    if (qout) chain_carrier(qout, nblocks, nchan, nsamp, nullptr, nullptr, nullptr, nullptr);
 
     for (int c = 0; c < nchan; ++c) {                      // chan.rho0 = rho1 (gps.c:2063)
         if (trk[c].prn <= 0) continue;

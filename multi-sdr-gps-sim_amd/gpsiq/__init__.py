@@ -92,6 +92,7 @@ _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
 _sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
+_refresh_epochs_q = _sig("gpsiq_refresh_epochs_quantized", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _vp, _i)
 _llh_to_ecef = _sig("gpsiq_llh_to_ecef", None, _vp, _vp)
 _ecef_to_llh = _sig("gpsiq_ecef_to_llh", None, _vp, _vp)
 _motion_read_csv = _sig("gpsiq_motion_read_csv", _i, C.c_char_p, _vp, _i)
@@ -251,6 +252,23 @@ def refresh_epochs(eph, iono, week, sec, xyz, trk_epochs, first_block, gain_x2=F
     assert out.dtype == CHAN_DTYPE and out.shape == (len(xyz), nc) and out.flags.c_contiguous
     _check(_refresh_epochs(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), nc, int(bool(gain_x2)),
                            _p(trk_epochs), _p(first), ne, _p(out), int(nthreads)))
+    return out
+
+
+def refresh_epochs_quantized(eph, iono, week, sec, xyz, trk_epochs, first_block, fs, nsamp, gain_x2=False, nthreads=0, out=None):
+    """gpsiq_refresh_epochs_quantized: refresh_epochs + quantize_blocks(carry0=None) in one pass -> QCHAN_DTYPE[nblocks][nchan]."""
+    eph = np.ascontiguousarray(eph, dtype=EPHEM_DTYPE)
+    iono = np.ascontiguousarray(iono, dtype=IONO_DTYPE)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    assert trk_epochs.dtype == TRACK_DTYPE and trk_epochs.flags.c_contiguous and trk_epochs.ndim == 2
+    first = np.ascontiguousarray(first_block, dtype=np.int32)
+    ne, nc = trk_epochs.shape
+    assert len(first) == ne
+    if out is None:
+        out = np.empty((len(xyz), nc), dtype=QCHAN_DTYPE)
+    assert out.dtype == QCHAN_DTYPE and out.shape == (len(xyz), nc) and out.flags.c_contiguous
+    _check(_refresh_epochs_q(_p(eph), _p(iono), int(week), float(sec), _p(xyz), len(xyz), nc, int(bool(gain_x2)),
+                             _p(trk_epochs), _p(first), ne, float(fs), int(nsamp), _p(out), int(nthreads)))
     return out
 
 

@@ -13,8 +13,8 @@ Every call below is one C-ABI entry point; this module is only the loop around t
 """
 import numpy as np
 
-from . import (CHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_roll, nav_subframes,
-               refresh_batch, refresh_epochs, sat_visibility, track_init)
+from . import (CHAN_DTYPE, QCHAN_DTYPE, EPHEM_DTYPE, IONO_DTYPE, NAV_STATE_DTYPE, TRACK_DTYPE, nav_message, nav_roll, nav_subframes,
+               refresh_batch, refresh_epochs, refresh_epochs_quantized, sat_visibility, track_init)
 
 
 def gps_time_after(sec, steps):
@@ -100,6 +100,15 @@ class RunAhead:
         block k).  carr_phase: what the previous Context.generate_batch call handed out
         (carr_out) when continuing a run; None on the first call = the allocation's value.
         Only block 0's carr_phase is read by the library, which carries it exactly from there."""
+        return self._refresh(xyz, carr_phase, gain_x2, nthreads, out, None)
+
+    def descriptors_quantized(self, xyz, fs, nsamp, carr_phase=None, gain_x2=False, nthreads=0, out=None):
+        """quantize_blocks(descriptors(xyz, ...), fs, nsamp)[0] in one pass in C (gpsiq_refresh_epochs_quantized): the
+        double-precision descriptors are never written out.  For hosts that feed Context.set_descriptors /
+        generate_quantized (the rounds of a time-sharded run)."""
+        return self._refresh(xyz, carr_phase, gain_x2, nthreads, out, (float(fs), int(nsamp)))
+
+    def _refresh(self, xyz, carr_phase, gain_x2, nthreads, out, quant):
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
         # The satellites are fixed, so the whole call is ONE threaded pass in C (gpsiq_refresh_epochs): the word
         # buffers of the 30 s epochs it crosses are rolled first (cheap), the ranges -- the expensive part -- do
@@ -107,7 +116,7 @@ class RunAhead:
         t_start = gps_time_after(self.sec, self.blocks_done)
         plan = epoch_plan(t_start, len(xyz))
         if not plan:
-            return np.zeros((0, len(self.svs)), dtype=CHAN_DTYPE)
+            return np.zeros((0, len(self.svs)), dtype=CHAN_DTYPE if quant is None else QCHAN_DTYPE)
         trk_ep = np.empty((len(plan), len(self.svs)), dtype=TRACK_DTYPE)
         done = self.blocks_done
         for e, (b0, b1, roll) in enumerate(plan):
@@ -115,17 +124,23 @@ class RunAhead:
             done += b1 - b0
             if roll:                                                          # gps.c:2878-2885
                 self._roll(gps_time_after(self.sec, done))
+        # the loop's own state (gps.c:2821), not the host model's; only block 0's value is read by the library
+        # (it carries the phase itself from there), the reference keeps it in chan[i] between blocks
+        carr0 = self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64)
         # out: a caller-owned [len(xyz)][nchan] array to fill (a fresh 20 MB array per call costs as much in page
         # faults as the refresh itself)
-        desc = refresh_epochs(self.orbit, self.iono, self.week, t_start, xyz, trk_ep, [p[0] for p in plan],
-                              gain_x2=gain_x2, nthreads=nthreads, out=out)
+        first = [p[0] for p in plan]
+        if quant is None:
+            desc = refresh_epochs(self.orbit, self.iono, self.week, t_start, xyz, trk_ep, first, gain_x2=gain_x2, nthreads=nthreads, out=out)
+            if len(desc):
+                desc["carr_phase"][0] = carr0
+        else:
+            trk_ep[0]["carr_phase"] = carr0                                   # the quantiser seeds block 0 from it
+            desc = refresh_epochs_quantized(self.orbit, self.iono, self.week, t_start, xyz, trk_ep, first, quant[0], quant[1],
+                                            gain_x2=gain_x2, nthreads=nthreads, out=out)
         for f in ("rho0_week", "rho0_sec", "rho0_range"):                     # chan.rho0 = rho1 (gps.c:2063)
             self.trk[f] = trk_ep[0][f]
         self.blocks_done = done
-        # the loop's own state (gps.c:2821), not the host model's; only block 0's value is read by the library
-        # (it carries the phase itself from there), the reference keeps it in chan[i] between blocks
-        if len(desc):
-            desc["carr_phase"][0] = self.carr_phase0 if carr_phase is None else np.asarray(carr_phase, dtype=np.float64)
         return desc
 
 

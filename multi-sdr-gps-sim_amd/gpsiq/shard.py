@@ -26,13 +26,19 @@ def quantize_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes, histo
     """Quantise ONLY this rank's blocks (desc_own = its rows of the timeline) and seed its carrier from
     the ranks before it.  all_gather_bytes(bytes) -> [bytes of rank 0, ..., bytes of rank world-1] is the
     one exchange needed (32 bytes per channel and rank; torch.distributed, MPI, a pipe -- anything).
-    The result equals shard_descriptors() of the whole timeline.
+    The result equals shard_descriptors() of the whole timeline.  history: see seed_own_shard."""
+    q, _ = quantize_blocks(desc_own, fs, nsamp)               # block 0 seeded from its own carr_phase
+    return seed_own_shard(q, nsamp, rank, world, all_gather_bytes, history)
+
+
+def seed_own_shard(q, nsamp, rank, world, all_gather_bytes, history=None):
+    """The second half of quantize_own_shard for rows that are quantised already (self-seeded: quantize_blocks, or
+    RunAhead.descriptors_quantized): exchange the 32-byte carries and add the exact prefix.  In place; returns q.
 
     history: a list the caller keeps between calls when the timeline goes on in rounds (round m gives rank
     r the blocks after those of rank r-1 of round m and after everything of round m-1): the carries of all
     earlier ranges, in timeline order; this call appends its round's.  The host side of round m+1 can then
     run while the GPUs are busy with round m."""
-    q, _ = quantize_blocks(desc_own, fs, nsamp)               # block 0 seeded from its own carr_phase
     mine = shard_carry(q, nsamp)
     parts = all_gather_bytes(mine.tobytes())
     assert len(parts) == world

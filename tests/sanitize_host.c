@@ -139,6 +139,8 @@ int main(int argc, char **argv)
         const gpsiq_rinex_eph_t *set = eph[ieph >= 0 ? ieph : 0];
         static uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF];
         gpsiq_ephem_t orbit[GPSIQ_MAX_CHAN]; gpsiq_track_t trk[GPSIQ_MAX_CHAN]; gpsiq_iono_t iono;
+        static gpsiq_track_t trk_first[GPSIQ_MAX_CHAN];
+        memset(trk_first, 0, sizeof trk_first);
         memset(trk, 0, sizeof trk); memset(&iono, 0, sizeof iono);
         iono.enable = 1; iono.vflg = utc.vflg; memcpy(iono.alpha, utc.alpha, sizeof iono.alpha); memcpy(iono.beta, utc.beta, sizeof iono.beta);
         const double xyz0[3] = {-3959000.0, 3350000.0, 3699000.0};
@@ -150,6 +152,8 @@ int main(int argc, char **argv)
             gpsiq_nav_state_t st; memset(&st, 0, sizeof st);
             CHECK(gpsiq_nav_subframes(&set[sv].nav, &utc, NULL, sbf) == GPSIQ_OK);
             CHECK(gpsiq_nav_message(sbf, week, 270000.0, 1, &st) == GPSIQ_OK);
+            trk_first[n].prn = sv + 1; trk_first[n].g0_week = st.g0_week; trk_first[n].g0_sec = st.g0_sec;   /* the frame of the start time */
+            memcpy(trk_first[n].dwrd, st.dwrd, sizeof st.dwrd);
             for (int k = 1; k < 26; ++k) CHECK(gpsiq_nav_message(sbf, week, 270000.0 + 30.0 * k, 0, &st) == GPSIQ_OK);
             trk[n].prn = sv + 1; trk[n].g0_week = st.g0_week; trk[n].g0_sec = st.g0_sec; memcpy(trk[n].dwrd, st.dwrd, sizeof st.dwrd);
             orbit[n++] = set[sv].orbit;
@@ -160,7 +164,27 @@ int main(int argc, char **argv)
         double *xyz = malloc(sizeof(double) * 3 * nblk);
         for (int k = 0; k < nblk; ++k) { xyz[3 * k] = xyz0[0] + 0.3 * k; xyz[3 * k + 1] = xyz0[1]; xyz[3 * k + 2] = xyz0[2] - 0.1 * k; }
         gpsiq_chan_t *out = malloc(sizeof *out * (size_t) nblk * n);
+        gpsiq_track_t trk0[GPSIQ_MAX_CHAN];
+        memcpy(trk0, trk, sizeof trk0);                           /* the state before the first block ... */
+        for (int c = 0; c < n; ++c) {                             /* ... with the word buffer of the start time */
+            trk0[c].g0_week = trk_first[c].g0_week; trk0[c].g0_sec = trk_first[c].g0_sec;
+            memcpy(trk0[c].dwrd, trk_first[c].dwrd, sizeof trk0[c].dwrd);
+        }
         for (int threads = 0; threads <= 3; threads += 3) CHECK(gpsiq_refresh_batch(orbit, &iono, week, 270000.0, xyz, nblk, n, 0, trk, out, threads) == GPSIQ_OK);
+        /* several epochs in one pass, plain and fused with the quantiser */
+        gpsiq_track_t trk_ep[3][GPSIQ_MAX_CHAN];
+        const int nq = 290, first[3] = {0, nq / 3, nq / 3 + 1};      /* one word buffer lasts 30 s = 300 blocks */
+        for (int e = 0; e < 3; ++e) memcpy(trk_ep[e], trk0, sizeof(gpsiq_track_t) * (size_t) n);
+        gpsiq_track_t *te = malloc(sizeof(gpsiq_track_t) * 3 * (size_t) n);
+        for (int e = 0; e < 3; ++e) memcpy(te + (size_t) e * n, trk_ep[e], sizeof(gpsiq_track_t) * (size_t) n);
+        CHECK(gpsiq_refresh_epochs(orbit, &iono, week, 270000.0, xyz, nq, n, 0, te, first, 3, out, 0) == GPSIQ_OK);
+        gpsiq_qchan_t *qa = malloc(sizeof *qa * (size_t) nblk * n), *qb = malloc(sizeof *qb * (size_t) nblk * n);
+        CHECK(gpsiq_quantize_batch(out, nq, n, 2.6e6, 260000, qa, NULL, NULL) == GPSIQ_OK);
+        for (int e = 0; e < 3; ++e) memcpy(te + (size_t) e * n, trk_ep[e], sizeof(gpsiq_track_t) * (size_t) n);
+        CHECK(gpsiq_refresh_epochs_quantized(orbit, &iono, week, 270000.0, xyz, nq, n, 0, te, first, 3, 2.6e6, 260000, qb, 3) == GPSIQ_OK);
+        CHECK(memcmp(qa, qb, sizeof *qa * (size_t) nq * n) == 0);
+        CHECK(gpsiq_refresh_epochs_quantized(orbit, &iono, week, 270000.0, xyz, nq, n, 0, te, first, 3, 0.0, 260000, qb, 0) == GPSIQ_E_ARG);
+        free(qa); free(qb); free(te);
         free(out); free(xyz);
     }
     free(q); free(ch);

@@ -429,3 +429,25 @@ def test_split_batches_continue_the_carrier(tmp_path):
     assert np.array_equal(b["carr_phase"][0][~kept], whole["carr_phase"][cut][~kept])
     b["carr_phase"][0] = whole["carr_phase"][cut]
     assert b.tobytes() == whole[cut:].tobytes()
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_fused_refresh_and_quantise_equals_the_two_calls(tmp_path, moving):
+    """gpsiq_refresh_epochs_quantized == gpsiq_refresh_epochs followed by gpsiq_quantize_batch, byte for byte, over
+    several navigation-message epochs, from the start and after a seek, with a carrier handed in, Pluto gain, a
+    slot left unused -- and it reports what the quantiser reports."""
+    sec, nblocks, fs, ns = 270012.0, 900, 2.6e6, 260000
+    _, eph, utc, ieph, svs, xyz = scenario(tmp_path, sec, nblocks, moving)
+    for b0, n, carr, x2 in ((0, 900, None, False), (123, 500, np.linspace(0.01, 0.95, len(svs)), True), (600, 1, None, False)):
+        a, b = (RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]) for _ in range(2))
+        a.seek(b0, xyz[b0]); b.seek(b0, xyz[b0])
+        want, _ = gpsiq.quantize_blocks(a.descriptors(xyz[1 + b0:1 + b0 + n], carr_phase=carr, gain_x2=x2), fs, ns)
+        got = b.descriptors_quantized(xyz[1 + b0:1 + b0 + n], fs, ns, carr_phase=carr, gain_x2=x2)
+        assert got.tobytes() == want.tobytes(), (b0, n)
+        assert a.trk.tobytes() == b.trk.tobytes() and a.blocks_done == b.blocks_done
+    ra = RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0])
+    ra.trk["prn"][2] = 0                                           # an unused slot stays an all-zero descriptor
+    q = ra.descriptors_quantized(xyz[1:41], fs, ns)
+    assert not q[:, 2].tobytes().strip(b"\0") and (q["prn"][:, 3] > 0).all()
+    with pytest.raises(gpsiq.GpsiqError):                          # 0.3 Msps: more than two chips per sample
+        RunAhead(eph[ieph], utc, svs, WEEK, sec, xyz[0]).descriptors_quantized(xyz[1:5], 0.3e6, 30000)
