@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (other configs, drop-in calls)")
     ap.add_argument("--cpu-blocks", type=int, default=299, help="blocks of the CPU baseline sample (299 = 30 s, config 1)")
-    ap.add_argument("--rounds", type=int, default=8, help="rounds of the streamed end-to-end leg")
+    ap.add_argument("--rounds", type=int, default=16, help="rounds of the streamed end-to-end leg")
     ap.add_argument("--sweep", action="store_true", help="also time every kernel variant (extra stderr lines)")
     ap.add_argument("--dry-run", action="store_true",
                     help="host side only (launch logic, rendezvous, sharded refresh/quantise, seed exchange); no device, value null")

@@ -27,7 +27,7 @@ def test_gpus_2_starts_two_ranks_by_itself():
     assert out["config"]["blocks_per_gpu_per_step"] == 60
     e = out["end_to_end"]
     assert e["blocks_per_gpu"] == 30 and e["channels"] == 16 and e["host_refresh_and_quantise_ms"] > 0.0
-    assert e["streamed"]["rounds"] == 8 and e["streamed"]["blocks_per_gpu_per_round"] == 30 and e["streamed"]["seconds"] > 0.0
+    assert e["streamed"]["rounds"] == 16 and e["streamed"]["blocks_per_gpu_per_round"] == 30 and e["streamed"]["seconds"] > 0.0
 
 
 def test_world_size_must_agree_with_gpus():
