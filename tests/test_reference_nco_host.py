@@ -74,10 +74,12 @@ def test_carrier_walk_fuzz_against_the_plain_loop(oracle):
     cycle per sample, both signs, and start phases on and next to powers of two."""
     rng = np.random.default_rng(77)
     fs = 2.6e6
-    for it in range(250):
+    for it in range(400):
         ns = int(rng.integers(1, 30000))
         d = synth_blocks(1, 16, seed=1000 + it)
         mag = 10.0 ** rng.uniform(-13.0, np.log10(0.49 * fs), 16)
+        if it % 3 == 1:                                   # Doppler-sized addends: the chain's own walk (carrier_after)
+            mag = rng.uniform(1.0, 9000.0, 16)
         d["f_carr"][0] = mag * rng.choice([-1.0, 1.0], 16)
         if it % 5 == 0:                                   # addends that are exact binary fractions of a cycle: ties
             d["f_carr"][0, :8] = fs * 2.0 ** -rng.integers(8, 60, 8) * rng.choice([-1.0, 1.0, 1.5, -3.0], 8)
