@@ -92,3 +92,22 @@ def test_carrier_walk_fuzz_against_the_plain_loop(oracle):
         _, want = oracle.block_float(d[0], ns, fs, SC08)
         _, _, got = gpsiq.reference_blocks(d, fs, ns)
         assert got.tobytes() == want.tobytes(), (it, ns, d["f_carr"][0][got != want], d["carr_phase"][0][got != want])
+
+
+def test_carrier_wrap_that_rounds_to_one(oracle):
+    """A negative addend taking the phase a hair below zero: the wrap y + 1.0 rounds to exactly 1.0 (the reference
+    then indexes its table at 512, see block_patches) and the walk goes on from 1.0, outside every binade of [0, 1)."""
+    fs, ns = 2.6e6, 5000
+    d = synth_blocks(1, 16, seed=9)
+    i = np.arange(16)
+    c = -(2.0 ** -(8.0 + i % 5))
+    d["f_carr"][0] = c * fs
+    assert np.array_equal(d["f_carr"][0] / fs, c)
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    x0 = np.nextafter(-c, 0.0)
+    x0[i % 3 == 1] = np.nextafter(x0[i % 3 == 1], 0.0)            # one or two ulps (2^-61..2^-65) short of |c|: the first sum
+    d["carr_phase"][0] = x0                                       # is that much below zero, and + 1.0 rounds to 1.0
+    assert ((d["carr_phase"][0] + c) + 1.0 == 1.0).all() and (d["carr_phase"][0] + c < 0.0).all()
+    _, want = oracle.block_float(d[0], ns, fs, SC08)
+    _, _, got = gpsiq.reference_blocks(d, fs, ns)
+    assert got.tobytes() == want.tobytes()
