@@ -549,11 +549,10 @@ int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan
     }
     gpsiq_ctx::AsyncSlot &a = c->aslot[c->anext];
     if (a.busy) { HIP_TRY(hipEventSynchronize(a.done)); a.busy = false; }     // the ring is full: wait for its oldest block
-    if (!a.d) {
-        HIP_TRY(hipMalloc((void **) &a.d, GPSIQ_MAX_CHAN * sizeof(gpsiq_qchan_t)));
-        HIP_TRY(hipHostMalloc((void **) &a.h, GPSIQ_MAX_CHAN * sizeof(gpsiq_qchan_t), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
-    }
+    // each piece on its own: a call that failed half-way must not leave a slot that looks complete
+    if (!a.d) HIP_TRY(hipMalloc((void **) &a.d, GPSIQ_MAX_CHAN * sizeof(gpsiq_qchan_t)));
+    if (!a.h) HIP_TRY(hipHostMalloc((void **) &a.h, GPSIQ_MAX_CHAN * sizeof(gpsiq_qchan_t), hipHostMallocDefault));
+    if (!a.done) HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
     // compact (active channels first) and take the launch parameters, as gpsiq_set_descriptors does for a batch
     int na = 0;
     long amp = 0;
