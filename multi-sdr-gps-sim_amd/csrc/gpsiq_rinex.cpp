@@ -211,6 +211,30 @@ int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsi
     return nsets > GPSIQ_EPHEM_SETS ? GPSIQ_EPHEM_SETS : nsets;
 }
 
+void gpsiq_date_to_gps(int year, int month, int day, int hour, int minute, double second, int *week, double *sec)
+{
+    const GpsTime g = to_gps(year, month, day, hour, minute, second);
+    if (week) *week = g.week;
+    if (sec) *sec = g.sec;
+}
+
+void gpsiq_gps_to_date(int week, double sec, int *year, int *month, int *day, int *hour, int *minute, double *second)
+{
+    // gps.c:339-355: Julian day number of the GPS day, then the usual calendar arithmetic on it
+    const int c = (int) (7 * week + std::floor(sec / 86400.0) + 2444245.0) + 1537;
+    const int d = (int) ((c - 122.1) / 365.25);
+    const int e = 365 * d + d / 4;
+    const int f = (int) ((c - e) / 30.6001);
+    const int dd = c - e - (int) (30.6001 * f);
+    const int mo = f - 1 - 12 * (f / 14);
+    if (day) *day = dd;
+    if (month) *month = mo;
+    if (year) *year = d - 4715 - ((7 + mo) / 10);
+    if (hour) *hour = ((int) (sec / 3600.0)) % 24;
+    if (minute) *minute = ((int) (sec / 60.0)) % 60;
+    if (second) *second = sec - 60.0 * std::floor(sec / 60.0);
+}
+
 int gpsiq_rinex_select(const gpsiq_rinex_eph_t *eph, int nsets, int week, double sec)
 {
     if (!eph) return -1;

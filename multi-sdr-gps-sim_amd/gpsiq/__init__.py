@@ -92,6 +92,8 @@ _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
 _sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
+_date_to_gps = _sig("gpsiq_date_to_gps", None, _i, _i, _i, _i, _i, _d, _vp, _vp)
+_gps_to_date = _sig("gpsiq_gps_to_date", None, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp)
 _refresh_epochs_q = _sig("gpsiq_refresh_epochs_quantized", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _vp, _i)
 _llh_to_ecef = _sig("gpsiq_llh_to_ecef", None, _vp, _vp)
 _ecef_to_llh = _sig("gpsiq_ecef_to_llh", None, _vp, _vp)
@@ -295,6 +297,21 @@ def motion_read_csv(path, max_points=3000):
     if n < 0:
         raise GpsiqError(n, _last_error().decode())
     return xyz[:n].copy()
+
+
+def date_to_gps(year, month, day, hour=0, minute=0, second=0.0):
+    """date2gps() (reference gps.c:315-337) -> (week, seconds of the week)."""
+    w, sec = C.c_int(0), C.c_double(0.0)
+    _date_to_gps(int(year), int(month), int(day), int(hour), int(minute), float(second), C.byref(w), C.byref(sec))
+    return w.value, sec.value
+
+
+def gps_to_date(week, sec):
+    """gps2date() (reference gps.c:339-355) -> (year, month, day, hour, minute, second)."""
+    v = [C.c_int(0) for _ in range(5)]
+    s = C.c_double(0.0)
+    _gps_to_date(int(week), float(sec), *[C.byref(x) for x in v], C.byref(s))
+    return tuple(x.value for x in v) + (s.value,)
 
 
 def nav_parity(source, nib=False):

@@ -15,6 +15,8 @@
  *
  *   gpsiq_runahead <rinex> <2|3> <week> <sec> <position> <nblocks> <nchan> <fs> <1|2> <out.bin>
  *
+ * start time: GPS <week> <sec>, or the reference's -t form "YYYY/MM/DD,hh:mm:ss" as <week> with "-" as <sec>
+ * (gps-sim.c:104; date2gps, gps.c:315-337, 2295: no leap seconds applied, as there).
  * position, one of
  *   xyz.bin        double[nblocks+1][3] ECEF metres, row 0 = start position (the one allocateChannel()
  *                  always uses, gps.c:2675, 2909), row k+1 = position of block k
@@ -126,9 +128,16 @@ int main(int argc, char **argv)
         fprintf(stderr, "usage: %s rinex 2|3 week sec xyz.bin|motion.csv|lat,lon,h nblocks nchan fs 1|2 out.bin\n", argv[0]);
         return 2;
     }
-    const int version = atoi(argv[2]), week = atoi(argv[3]), nchan = atoi(argv[7]), ss = atoi(argv[9]);
-    int nblocks = atoi(argv[6]);
-    const double sec0 = atof(argv[4]), fs = atof(argv[8]);
+    const int version = atoi(argv[2]), nchan = atoi(argv[7]), ss = atoi(argv[9]);
+    int nblocks = atoi(argv[6]), week = atoi(argv[3]);
+    double sec0 = atof(argv[4]);
+    const double fs = atof(argv[8]);
+    if (strchr(argv[3], '/')) {                                                /* the -t form */
+        int y, mo, d, hh, mi;
+        double s;
+        if (sscanf(argv[3], "%d/%d/%d,%d:%d:%lf", &y, &mo, &d, &hh, &mi, &s) != 6) { fprintf(stderr, "bad start time %s\n", argv[3]); return 2; }
+        gpsiq_date_to_gps(y, mo, d, hh, mi, s, &week, &sec0);                 /* gps-sim.c:104, gps.c:2295 */
+    }
     const int nsamp = (int) floor(fs / 10.0 + 0.5);                           /* NUM_IQ_SAMPLES, sdr.h:26 */
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN || (ss != 1 && ss != 2)) { fprintf(stderr, "bad arguments\n"); return 2; }
 

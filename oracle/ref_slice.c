@@ -45,6 +45,7 @@ static int ref_nchan = 12;
 #include "ref_vec.inc"               /* gps.c:243-266  subVect, normVect, dotProd */
 #include "ref_codegen.inc"           /* gps.c:272-309  codegen() */
 #include "ref_date2gps.inc"          /* gps.c:315-337  date2gps() */
+#include "ref_gps2date.inc"          /* gps.c:339-355  gps2date() */
 #include "ref_geo.inc"               /* gps.c:361-499  xyz2llh, llh2xyz, ltcmat, ecef2neu, neu2azel */
 #include "ref_satpos.inc"            /* gps.c:508-611  satpos() */
 #include "ref_subgpstime.inc"        /* gps.c:1096-1103 subGpsTime() */
@@ -559,6 +560,20 @@ int ref_read_rinex(int version, const char *path, gpsiq_rinex_eph_t *out /* [13]
 }
 
 /* ---- where the receiver is: the reference's geodetic conversions and its user-motion reader ---- */
+void ref_date2gps(int y, int m, int d, int hh, int mm, double sec, int *week, double *sow)
+{
+    datetime_t t = {y, m, d, hh, mm, sec};
+    gpstime_t g;
+    date2gps(&t, &g);
+    *week = g.week; *sow = g.sec;
+}
+void ref_gps2date(int week, double sow, int *y, int *m, int *d, int *hh, int *mm, double *sec)
+{
+    gpstime_t g = {week, sow};
+    datetime_t t;
+    gps2date(&g, &t);
+    *y = t.y; *m = t.m; *d = t.d; *hh = t.hh; *mm = t.mm; *sec = t.sec;
+}
 void ref_llh2xyz(const double *llh, double *xyz) { llh2xyz(llh, xyz); }
 void ref_xyz2llh(const double *xyz, double *llh) { xyz2llh(xyz, llh); }
 int ref_read_user_motion(const char *path, double *xyz_out, int max_points)

@@ -356,6 +356,13 @@ def test_c_runahead_position_argument_forms(tmp_path):
     static = np.tile(gpsiq.llh_to_ecef(llh[0] / 57.2957795131, llh[1] / 57.2957795131, llh[2]), (nblocks + 1, 1))
     static.tofile(str(tmp_path / "s.bin"))
     assert np.array_equal(run("%r,%r,%r" % llh), run(str(tmp_path / "s.bin")))
+    # the start time in the reference's -t form (2021/12/29 03:00:00 = week 2190, 270 000 s)
+    y, mo, d, hh, mi, s = gpsiq.gps_to_date(WEEK, sec)
+    out = str(tmp_path / "t.bin")
+    r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", "%d/%d/%d,%d:%d:%g" % (y, mo, d, hh, mi, s), "-", str(tmp_path / "xyz.bin"),
+                        str(nblocks), str(nchan), repr(fs), "1", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(out, dtype=np.int8), want)
     r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "none.csv"), "2", "8",
                         repr(fs), "1", str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "motion file" in r.stderr

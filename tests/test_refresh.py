@@ -219,3 +219,31 @@ def test_receiver_position_inputs_match_reference(ref, tmp_path):
     assert len(gpsiq.motion_read_csv(str(good), 7)) == 7
     with pytest.raises(gpsiq.GpsiqError):
         gpsiq.motion_read_csv(str(tmp_path / "missing.csv"))
+
+
+def test_time_conversions_match_reference(ref):
+    """gpsiq_date_to_gps / gpsiq_gps_to_date == date2gps / gps2date (gps.c:315-355): random dates 1981-2080 (and the epoch itself) incl. leap
+    days and week boundaries, exact doubles, and the round trip."""
+    import ctypes as C
+    import gpsiq
+    L = ref.lib
+    L.ref_date2gps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    L.ref_gps2date.argtypes = [C.c_int, C.c_double] + [C.c_void_p] * 6
+    rng = np.random.default_rng(15)
+    cases = [(1980, 1, 6, 0, 0, 0.0), (2000, 2, 29, 23, 59, 59.999), (2019, 4, 7, 0, 0, 0.0), (2021, 6, 20, 0, 0, 0.0), (2024, 12, 31, 12, 30, 30.5)]
+    for _ in range(2000):
+        y, m = int(rng.integers(1981, 2081)), int(rng.integers(1, 13))
+        d = int(rng.integers(1, 29 if m == 2 else 31))
+        cases.append((y, m, d, int(rng.integers(0, 24)), int(rng.integers(0, 60)), float(rng.choice([0.0, 0.1, 29.9, 59.0]) + rng.integers(0, 2) * rng.random())))
+    for y, m, d, hh, mm, sec in cases:
+        w, s = C.c_int(0), C.c_double(0.0)
+        L.ref_date2gps(y, m, d, hh, mm, sec, C.byref(w), C.byref(s))
+        got = gpsiq.date_to_gps(y, m, d, hh, mm, sec)
+        assert got == (w.value, s.value), (y, m, d, hh, mm, sec)
+        v = [C.c_int(0) for _ in range(5)]
+        fs = C.c_double(0.0)
+        L.ref_gps2date(w.value, s.value, *[C.byref(x) for x in v], C.byref(fs))
+        back = gpsiq.gps_to_date(*got)
+        assert back == tuple(x.value for x in v) + (fs.value,), (y, m, d, hh, mm, sec)
+        assert back[:5] == (y, m, d, hh, mm) and abs(back[5] - sec) < 1e-6
+    assert gpsiq.date_to_gps(2021, 6, 20) == (2163, 0.0)          # a Sunday 00:00: the start of GPS week 2163
