@@ -2,7 +2,7 @@
 """Soak of the fixed-point kernels against the oracle on the GPU box: random QUANTISED descriptors (full-range carrier
 steps, code steps from 25 Msps-like up to the row kernels' limit, arbitrary fractions, nav bits, gains incl. the int16
 wrap region), random block lengths incl. ragged rows / tiles / chunks, 1-16 channels, int8 and int16, every kernel
-variant.  Not part of the test suite; prints one summary line.   usage: gpu_soak_fixed.py [seconds]"""
+variant.  Not part of the test suite; prints one summary line.   usage: python tests/soak_fixed.py [seconds]"""
 import os
 import sys
 import time
@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # _oracle: checkers live under tests/
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
 import torch  # noqa: E402
 import _oracle  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of GPSIQ_NCO_REFERENCE against the reference's own loop (oracle/_ref/libgpsref.so) on the GPU box: random
 whole runs at several rates, every element and the carried phase compared.  Not part of the test suite (minutes of
-host CPU for the reference loop); prints one summary line.   usage: gpu_soak_reference.py [seconds]"""
+host CPU for the reference loop); prints one summary line.   usage: python tests/soak_reference.py [seconds]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # _oracle: checkers live under tests/
 sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
 import _oracle  # noqa: E402
 import gpsiq  # noqa: E402
