@@ -399,6 +399,7 @@ const char *gpsiq_variant_name(int v)
     case kSeg: return "seg";
     case kSegHalf: return "segh";
     case kSegMask: return "segm";
+    case kSegBoth: return "segb";
     default: return "?";
     }
 }

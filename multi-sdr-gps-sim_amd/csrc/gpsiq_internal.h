@@ -51,6 +51,7 @@ enum Variant {
     kSeg = 5,       // tile kernel, each wave running several consecutive 64-row chunks
     kSegHalf = 6,   // seg with one window per 32 samples: for sample rates down to 1.023 Msps
     kSegMask = 7,   // high sample rates: per-(channel,row) 64-bit sign masks from a pre-pass, applied as EXEC masks
+    kSegBoth = 8,   // seg's plain-add core with a both-polarity LUT (sign concatenated above the index), 16-wave workgroups
     kNumVariants
 };
 

@@ -403,17 +403,27 @@ __global__ __launch_bounds__(kRowsThreads) void synth_rowsx(
 //     (table[k+256] == -table[k], so is (int)(table*gain)), hence adding the sign bit to the top
 //     index bit of the phase word selects the negated entry.  The shifted window's higher bits land
 //     in the five spare bits above the index.  lshr, lshl_add, add replace bfe, or, pk_mad.
-template <int FMT, int NCH, int ROWS, int H, bool FAST>
-__global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
+//   * BOTH ("segb", with FAST): the LUT holds both polarities, entry sign*512 + k = entry (k + 256*sign) mod 512, so the
+//     chip sign is CONCATENATED above the index instead of added to it: with the phase word kept left-aligned (index in
+//     bits 23..31 of its high half) one v_alignbit_b32 puts {sign, index} at bits 2..11 and a plain v_and_b32 with a
+//     literal (2.5 issue cycles, where the SDWA form it replaces takes 4.3) makes the LDS address.  The table is 4 KB per
+//     channel, so a workgroup has WAVES = 16 waves (64 KB of LUT + 64 KB of windows, one workgroup per CU = the same four
+//     waves per SIMD).
+template <int FMT, int NCH, int ROWS, int H, bool FAST, int WAVES = kWaves, bool BOTH = false>
+__global__ __launch_bounds__(WAVES * 64, 4) void synth_tile(
     const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst,
     size_t block_stride, int block0, const DeviceTables *__restrict__ tab, int tiles_per_block,
     int wave_rows, int big_wgs, int big_blocks, int tiles_small)
 {
-    __shared__ uint32_t lut[NCH][512];
+    constexpr int kLutEntries = BOTH ? 1024 : 512;
+    constexpr int kThreads = WAVES * 64;
+    __shared__ uint32_t lut[NCH][kLutEntries];
     __shared__ uint32_t ext[NCH][kPrnExtWords];
-    __shared__ uint32_t win[kWaves][ROWS * H][NCH];     // one window per (row or half row, channel)
+    __shared__ uint32_t win[WAVES][ROWS * H][NCH];      // one window per (row or half row, channel)
     __shared__ gpsiq_qchan_t qs[NCH];
     static_assert(H == 1 || H == 2, "one window per row or per half row");
+    static_assert(!BOTH || FAST, "the both-polarity table is a form of the plain-add core");
+    static_assert(kLutEntries % kThreads == 0 || kThreads % kLutEntries == 0, "LUT build: whole passes");
     constexpr int kSpan = 64 / H;                        // samples per window
 
     const int tid = threadIdx.x;
@@ -431,13 +441,15 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
     }
     const gpsiq_qchan_t *q_blk = desc + (size_t) (block0 + blk) * nchan;
     const int nq = nchan < NCH ? nchan : NCH;
-    for (int i = tid; i < NCH * 12; i += kRowsThreads)
+    for (int i = tid; i < NCH * 12; i += kThreads)
         reinterpret_cast<uint32_t *>(qs)[i] = i < nq * 12 ? reinterpret_cast<const uint32_t *>(q_blk)[i] : 0u;
     __syncthreads();
-    {
-        // entry k = tid of every channel; unused slots have gain 0.0 -> entry 0
-        const double sk = (double) dev_sin512(tab->quarter_wave, tid);
-        const double ck = (double) dev_sin512(tab->quarter_wave, tid + 128);
+    for (int e = tid; e < kLutEntries; e += kThreads) {
+        // entry e of every channel (one pass: a thread per entry); unused slots have gain 0.0 -> entry 0.
+        // BOTH: the upper half is the table half a cycle on, i.e. the negated entries
+        const int k = BOTH ? (e + ((e >> 9) << 8)) & 511 : e;
+        const double sk = (double) dev_sin512(tab->quarter_wave, k);
+        const double ck = (double) dev_sin512(tab->quarter_wave, k + 128);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const double g = qs[c].gain;
@@ -449,12 +461,12 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
                 // the int8 output keeps bits 4..11 of I and Q only: 12-bit fields, I at bits 4..15 (its
                 // carries spill into bits 16..19, 16 channels x 12 bits), Q at bits 20..31; the output
                 // bytes are bytes 1 and 3 of the plain 32-bit sum, for any gain
-                lut[c][tid] = (((uint32_t) tc & 0xfffu) << 4) | ((uint32_t) ts << 20);
+                lut[c][e] = (((uint32_t) tc & 0xfffu) << 4) | ((uint32_t) ts << 20);
             else if (FAST)
                 // one integer; |tc|, |ts| <= 32767 here.  Slot 0 also carries the +0x8000 that keeps
                 // I + 32768 >= 0 in the sum (so a negative I never borrows from the Q half)
-                lut[c][tid] = (uint32_t) (tc + ts * 65536) + (c == 0 ? 0x8000u : 0u);
-            else      lut[c][tid] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
+                lut[c][e] = (uint32_t) (tc + ts * 65536) + (c == 0 ? 0x8000u : 0u);
+            else      lut[c][e] = (((uint32_t) tc << kPre) & 0xffffu) | ((uint32_t) ts << (16 + kPre));
         }
     }
     for (int e = tid; e < NCH * kPrnExtWords; e += kRowsThreads) {
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
 
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t wave_samples = (uint32_t) wave_rows * 64u;
-    const uint32_t n_wave = ((uint32_t) tile * kWaves + (uint32_t) wave) * wave_samples;
+    const uint32_t n_wave = ((uint32_t) tile * WAVES + (uint32_t) wave) * wave_samples;
     if (n_wave >= (uint32_t) nsamp) return;             // whole wave past the block end
 
     // ---- window builder: lane (c, g) prepares windows g, g+G, g+2G, ... of channel c ----
@@ -510,9 +522,11 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
         const uint64_t p0 = have ? q_blk[c].carr_phase : 0u, ps = have ? (uint64_t) q_blk[c].carr_step : 0u;
         const uint64_t f0 = have ? q_blk[c].code_frac : 0u, cs = have ? q_blk[c].code_step : 0u;
         const uint64_t c0 = have ? (uint64_t) q_blk[c].chip0 : 0u;
-        P[c] = p0 + ps * (uint64_t) n0;
+        // BOTH keeps the 59-bit phase left-aligned in the word (it then wraps by itself, index in the top nine bits)
+        constexpr int kAlign = BOTH ? 64 - GPSIQ_CARR_FRAC_BITS : 0;
+        P[c] = (p0 + ps * (uint64_t) n0) << kAlign;
         Q[c] = (c0 << GPSIQ_CODE_FRAC_BITS) + f0 + cs * (uint64_t) n0;
-        dP[c] = ps * 64u;
+        dP[c] = (ps * 64u) << kAlign;
         dQ[c] = cs * 64u;
     }
 
@@ -528,9 +542,15 @@ __global__ __launch_bounds__(kRowsThreads, 4) void synth_tile(
             for (int c = 0; c < NCH; ++c) {
                 const uint32_t w = w_row[r * (H * NCH) + c];
                 const uint32_t t = w >> ((uint32_t) (Q[c] >> 56) & 31u);        // bit 0 = chip ^ nav bit of this lane
-                const uint32_t x = (t << 26) + (uint32_t) (P[c] >> 32);          // + half a cycle when that bit is set
-                const uint32_t a = (x >> 16) & 0x7fcu;
-                sum += *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+                if (BOTH) {
+                    // {strays, sign, index, 2 fraction bits}: sign and index make the word address in the 4 KB table
+                    const uint32_t x = __builtin_amdgcn_alignbit(t, (uint32_t) (P[c] >> 32), 21u);
+                    sum += *reinterpret_cast<const uint32_t *>(lut_b + c * 4096 + (x & 0xffcu));
+                } else {
+                    const uint32_t x = (t << 26) + (uint32_t) (P[c] >> 32);      // + half a cycle when that bit is set
+                    const uint32_t a = (x >> 16) & 0x7fcu;
+                    sum += *reinterpret_cast<const uint32_t *>(lut_b + c * 2048 + a);
+                }
                 P[c] += dP[c];
                 Q[c] += dQ[c];
             }
@@ -893,6 +913,45 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
             else if (slots == 12) GPSIQ_LAUNCH_M(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_M(GPSIQ_SC08, 16);
         }
 #undef GPSIQ_LAUNCH_M
+        return hipGetLastError();
+    }
+    // the both-polarity table is a form of the plain-add core: sums that may leave the int16 range go to seg's packed core
+    if (variant == kSegBoth && !((sample_size == GPSIQ_SC08 || max_amplitude <= 32767) && seg_policy().allow_fast)) variant = kSeg;
+    if (variant == kSegBoth) {
+        // one 16-wave workgroup per CU (131 KB of LDS); otherwise seg's grid policy with 16 waves per workgroup
+        constexpr int kW = 16, rows = 64;
+        const SegPolicy &pol = seg_policy();
+        const int rows_total = (nsamp + 63) / 64;
+        const int tiles1 = (rows_total + kW * rows - 1) / (kW * rows);
+        int wave_rows = rows, tiles = tiles1, tail_blocks = 0;
+        double best = 0.0;
+        for (int nwg = 1; nwg <= tiles1; ++nwg) {
+            const int wr = (rows_total + kW * nwg - 1) / (kW * nwg);
+            if (wr > pol.max_wave_rows) continue;
+            if (wr < rows && nwg < tiles1) break;
+            const double fill = (double) rows_total / ((double) kW * nwg * wr);
+            const double amort = (double) wr / ((double) wr + pol.setup_rows);
+            const double rounds = (double) nblocks * nwg / (pol.resident_wgs / 2.0);
+            const double score = fill * amort * rounds / (rounds + pol.drain_rounds);
+            if (score > best) { best = score; wave_rows = wr > rows ? wr : rows; tiles = nwg; }
+        }
+        if (wave_rows > rows) {
+            tail_blocks = (pol.tail_wgs / 2 + tiles1 - 1) / tiles1;
+            if (tail_blocks > nblocks / 2) tail_blocks = nblocks / 2;
+        }
+        const int big_blocks = nblocks - tail_blocks;
+        const int big_wgs = tiles * big_blocks;
+        dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kW * 64);
+#define GPSIQ_LAUNCH_B(F, N) hipLaunchKernelGGL((synth_tile<F, N, 64, 1, true, 16, true>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1)
+        const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
+        if (sample_size == GPSIQ_SC16) {
+            if (slots == 4) GPSIQ_LAUNCH_B(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_B(GPSIQ_SC16, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_B(GPSIQ_SC16, 12); else GPSIQ_LAUNCH_B(GPSIQ_SC16, 16);
+        } else {
+            if (slots == 4) GPSIQ_LAUNCH_B(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_B(GPSIQ_SC08, 8);
+            else if (slots == 12) GPSIQ_LAUNCH_B(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_B(GPSIQ_SC08, 16);
+        }
+#undef GPSIQ_LAUNCH_B
         return hipGetLastError();
     }
     if (variant == kTile || variant == kSeg || variant == kSegHalf) {

@@ -12,7 +12,7 @@ from test_golden import CASES, check_fixed_block_against_golden, load_case, star
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["generic", "rows", "rowsx", "tile", "seg", "segh", "segm"]
+VARIANTS = ["generic", "rows", "rowsx", "tile", "seg", "segh", "segm", "segb"]
 
 
 @pytest.fixture(scope="module")
