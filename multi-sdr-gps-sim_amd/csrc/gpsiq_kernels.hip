@@ -918,38 +918,41 @@ hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int
     // the both-polarity table is a form of the plain-add core: sums that may leave the int16 range go to seg's packed core
     if (variant == kSegBoth && !((sample_size == GPSIQ_SC08 || max_amplitude <= 32767) && seg_policy().allow_fast)) variant = kSeg;
     if (variant == kSegBoth) {
-        // one 16-wave workgroup per CU (131 KB of LDS); otherwise seg's grid policy with 16 waves per workgroup
-        constexpr int kW = 16, rows = 64;
+        // 4 KB of LUT per channel: with 16 channels two 8-wave workgroups still fit a CU (the same four waves per SIMD as
+        // seg) when a chunk is 16 rows, i.e. 8 KB of windows per workgroup (64 + 8 + 3 KB, twice = 150 of 160 KB); a single
+        // 16-wave workgroup per CU with 64-row chunks measured 10 % SLOWER than seg although its waves ran 11 % faster
+        // (SQ_WAVE_CYCLES): with one workgroup per CU nothing fills the CU while that workgroup starts up or drains.
+        const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
+        const int rows = slots == 4 ? 64 : slots == 8 ? 32 : 16;     // rows per chunk: the lane groups of the window builder need 4 windows each
         const SegPolicy &pol = seg_policy();
         const int rows_total = (nsamp + 63) / 64;
-        const int tiles1 = (rows_total + kW * rows - 1) / (kW * rows);
+        const int tiles1 = (rows_total + kWaves * rows - 1) / (kWaves * rows);
         int wave_rows = rows, tiles = tiles1, tail_blocks = 0;
         double best = 0.0;
         for (int nwg = 1; nwg <= tiles1; ++nwg) {
-            const int wr = (rows_total + kW * nwg - 1) / (kW * nwg);
+            const int wr = (rows_total + kWaves * nwg - 1) / (kWaves * nwg);
             if (wr > pol.max_wave_rows) continue;
             if (wr < rows && nwg < tiles1) break;
-            const double fill = (double) rows_total / ((double) kW * nwg * wr);
+            const double fill = (double) rows_total / ((double) kWaves * nwg * wr);
             const double amort = (double) wr / ((double) wr + pol.setup_rows);
-            const double rounds = (double) nblocks * nwg / (pol.resident_wgs / 2.0);
+            const double rounds = (double) nblocks * nwg / pol.resident_wgs;
             const double score = fill * amort * rounds / (rounds + pol.drain_rounds);
             if (score > best) { best = score; wave_rows = wr > rows ? wr : rows; tiles = nwg; }
         }
         if (wave_rows > rows) {
-            tail_blocks = (pol.tail_wgs / 2 + tiles1 - 1) / tiles1;
+            tail_blocks = (pol.tail_wgs + tiles1 - 1) / tiles1;
             if (tail_blocks > nblocks / 2) tail_blocks = nblocks / 2;
         }
         const int big_blocks = nblocks - tail_blocks;
         const int big_wgs = tiles * big_blocks;
-        dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kW * 64);
-#define GPSIQ_LAUNCH_B(F, N) hipLaunchKernelGGL((synth_tile<F, N, 64, 1, true, 16, true>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1)
-        const int slots = max_active <= 4 ? 4 : max_active <= 8 ? 8 : max_active <= 12 ? 12 : 16;
+        dim3 grid((unsigned) (big_wgs + tiles1 * tail_blocks)), block(kRowsThreads);
+#define GPSIQ_LAUNCH_B(F, N, R) hipLaunchKernelGGL((synth_tile<F, N, R, 1, true, kWaves, true>), grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, tab, tiles, wave_rows, big_wgs, big_blocks, tiles1)
         if (sample_size == GPSIQ_SC16) {
-            if (slots == 4) GPSIQ_LAUNCH_B(GPSIQ_SC16, 4); else if (slots == 8) GPSIQ_LAUNCH_B(GPSIQ_SC16, 8);
-            else if (slots == 12) GPSIQ_LAUNCH_B(GPSIQ_SC16, 12); else GPSIQ_LAUNCH_B(GPSIQ_SC16, 16);
+            if (slots == 4) GPSIQ_LAUNCH_B(GPSIQ_SC16, 4, 64); else if (slots == 8) GPSIQ_LAUNCH_B(GPSIQ_SC16, 8, 32);
+            else if (slots == 12) GPSIQ_LAUNCH_B(GPSIQ_SC16, 12, 16); else GPSIQ_LAUNCH_B(GPSIQ_SC16, 16, 16);
         } else {
-            if (slots == 4) GPSIQ_LAUNCH_B(GPSIQ_SC08, 4); else if (slots == 8) GPSIQ_LAUNCH_B(GPSIQ_SC08, 8);
-            else if (slots == 12) GPSIQ_LAUNCH_B(GPSIQ_SC08, 12); else GPSIQ_LAUNCH_B(GPSIQ_SC08, 16);
+            if (slots == 4) GPSIQ_LAUNCH_B(GPSIQ_SC08, 4, 64); else if (slots == 8) GPSIQ_LAUNCH_B(GPSIQ_SC08, 8, 32);
+            else if (slots == 12) GPSIQ_LAUNCH_B(GPSIQ_SC08, 12, 16); else GPSIQ_LAUNCH_B(GPSIQ_SC08, 16, 16);
         }
 #undef GPSIQ_LAUNCH_B
         return hipGetLastError();
