@@ -22,6 +22,7 @@
  *   gps.c:617-884, 1008-1072, 2066-2140  nav words     -> gpsiq_nav_subframes/_message/_parity()
  *   gps.c:1131-1891  readRinex2 / readRinex3             -> gpsiq_rinex_read(), gpsiq_rinex_select()
  *   gps.c:315-355    date2gps / gps2date                 -> gpsiq_date_to_gps(), gpsiq_gps_to_date()
+ *   almanac.c:73-184 almanac_read_file (SEM)             -> gpsiq_almanac_read_sem()
  *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
  *
  * NCO definition ("identical fixed-point NCO word widths", BASELINE.json north_star).
@@ -405,6 +406,12 @@ uint32_t gpsiq_nav_parity(uint32_t source, int nib);
 int gpsiq_nav_subframes(const gpsiq_nav_eph_t *eph, const gpsiq_nav_utc_t *utc,
                         const gpsiq_nav_alm_sv_t *alm,
                         uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF]);
+/* almanac_read_file() (almanac.c:73-184): a SEM almanac file -> the 32 entries gpsiq_nav_subframes() takes, indexed by
+ * PRN - 1.  The reference's rules are kept: ids 0 / > 32 are clamped to 1 / 32, at most 32 records are read whatever the
+ * header announces, the week gets + 2048 (the reference's roll-over constant), a file that ends early keeps the records
+ * read so far (the last one possibly half filled and not valid), any other damage drops them all.
+ * Returns the number of valid entries, or GPSIQ_E_ARG when the file cannot be opened. */
+int gpsiq_almanac_read_sem(const char *path, gpsiq_nav_alm_sv_t alm[32] /* GPSIQ_MAX_SAT */);
 /* generateNavMsg(g = (week, sec), chan, init).  init != 0 at channel allocation (gps.c:2196),
  * 0 at every 30 s refresh (gps.c:2880-2885).  st->ipage selects the subframe 4/5 page and is advanced. */
 int gpsiq_nav_message(const uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], int week, double sec,

@@ -249,4 +249,49 @@ int gpsiq_nav_roll(const uint32_t *sbf, int nchan, int week, double sec, gpsiq_n
     return GPSIQ_OK;
 }
 
+int gpsiq_almanac_read_sem(const char *path, gpsiq_nav_alm_sv_t alm[GPSIQ_MAX_SAT])
+{
+    if (!path || !alm) return fail(GPSIQ_E_ARG, "null argument");
+    std::memset(alm, 0, sizeof(gpsiq_nav_alm_sv_t) * GPSIQ_MAX_SAT);                  // almanac_init(), almanac.c:29-53
+    std::FILE *fp = std::fopen(path, "rt");
+    if (!fp) return fail(GPSIQ_E_ARG, "cannot open %s", path);
+    char buf[100], title[32];
+    unsigned n = 0, week = 0, sec = 0;
+    // a line per field, in the file's order (almanac.c:85-147); `bad` = a read or a conversion failed
+    bool bad = !std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%u %24s", &n, title) != 2;
+    bad = bad || !std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%u %u", &week, &sec) != 2;
+    n -= 1;                                            // PRNs count from 1; an announced 0 wraps and is cut to 32 as well
+    if (n > 31) n = 31;
+    for (unsigned j = 0; !bad && j <= n; ++j) {
+        unsigned id = 0;
+        if (!std::fgets(buf, sizeof buf, fp)) { bad = true; break; }
+        if (buf[0] == '\n' || buf[0] == '\r')          // a blank line between records
+            if (!std::fgets(buf, sizeof buf, fp)) { bad = true; break; }
+        if (std::sscanf(buf, "%u", &id) != 1) { bad = true; break; }
+        if (id == 0) id = 1;
+        if (id > 32) id = 32;
+        gpsiq_nav_alm_sv_t &a = alm[id - 1];
+        a.svid = id;
+        unsigned short svn;
+        unsigned char code;
+        if (!std::fgets(buf, sizeof buf, fp)) { bad = true; break; }                    // SVN: optional, may be a blank line
+        if (!(buf[0] == '\n' || buf[0] == '\r') && std::sscanf(buf, "%hu", &svn) != 1) { bad = true; break; }
+        if (!std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%hhu", &code) != 1) { bad = true; break; }              // URA
+        if (!std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%lf %lf %lf", &a.e, &a.delta_i, &a.omegadot) != 3) { bad = true; break; }
+        if (!std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%lf %lf %lf", &a.sqrta, &a.omega0, &a.aop) != 3) { bad = true; break; }
+        if (!std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%lf %lf %lf", &a.m0, &a.af0, &a.af1) != 3) { bad = true; break; }
+        if (!std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%hhu", &code) != 1) { bad = true; break; }              // health
+        if (!std::fgets(buf, sizeof buf, fp) || std::sscanf(buf, "%hhu", &code) != 1) { bad = true; break; }              // configuration
+        a.toa_week = (int) week + 2048;                // almanac.c:160-163: the full week as read, plus one roll-over
+        a.toa_sec = (double) sec;
+        a.valid = 1;
+    }
+    // almanac.c:169-182: a file that simply ends early keeps what was read; anything else drops it all
+    if (bad && !std::feof(fp)) std::memset(alm, 0, sizeof(gpsiq_nav_alm_sv_t) * GPSIQ_MAX_SAT);
+    std::fclose(fp);
+    int valid = 0;
+    for (int sv = 0; sv < GPSIQ_MAX_SAT; ++sv) valid += alm[sv].valid ? 1 : 0;
+    return valid;
+}
+
 }  // extern "C"

@@ -92,6 +92,7 @@ _track_init = _sig("gpsiq_track_init", _i, _vp, _vp, _i, _d, _vp, _vp, _i)
 _sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
+_almanac_read_sem = _sig("gpsiq_almanac_read_sem", _i, C.c_char_p, _vp)
 _date_to_gps = _sig("gpsiq_date_to_gps", None, _i, _i, _i, _i, _i, _d, _vp, _vp)
 _gps_to_date = _sig("gpsiq_gps_to_date", None, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp)
 _refresh_epochs_q = _sig("gpsiq_refresh_epochs_quantized", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _vp, _i)
@@ -316,6 +317,15 @@ def gps_to_date(week, sec):
 
 def nav_parity(source, nib=False):
     return int(_nav_parity(int(source) & 0xFFFFFFFF, int(bool(nib))))
+
+
+def almanac_read_sem(path):
+    """almanac_read_file() (reference almanac.c:73-184) -> (NAV_ALM_DTYPE[32], number of valid entries)."""
+    alm = np.zeros(32, dtype=NAV_ALM_DTYPE)
+    n = _almanac_read_sem(str(path).encode(), _p(alm))
+    if n < 0:
+        _check(n)
+    return alm, n
 
 
 def nav_subframes(eph, utc, alm=None):

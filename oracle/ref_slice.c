@@ -63,6 +63,7 @@ static int ref_nchan = 12;
 #include "ref_allocsat.inc"          /* gps.c:236       allocatedSat[] */
 #include "ref_allocate.inc"          /* gps.c:2142-2235 checkSatVisibility(), allocateChannel() */
 #include "ref_usermotion.inc"        /* gps.c:2253-2277 readUserMotion() */
+#include "ref_almanac.inc"           /* almanac.c:19, 29-53, 73-184  almanac_init(), almanac_read_file() */
 
 /* ---- capturing fifo (the tap SURVEY.md section 0 fact 6 asks for) --------- */
 static struct {
@@ -560,6 +561,21 @@ int ref_read_rinex(int version, const char *path, gpsiq_rinex_eph_t *out /* [13]
 }
 
 /* ---- where the receiver is: the reference's geodetic conversions and its user-motion reader ---- */
+/* almanac_read_file() reads "almanac.sem" in the current directory; returns its CURLcode, the records in out[32] */
+int ref_almanac_read(gpsiq_nav_alm_sv_t *out)
+{
+    int rc = (int) almanac_read_file();
+    for (int sv = 0; sv < MAX_SAT; sv++) {
+        const almanac_prn_t *a = &almanac_gps.sv[sv];
+        memset(&out[sv], 0, sizeof out[sv]);
+        out[sv].svid = a->svid; out[sv].valid = a->valid;
+        out[sv].toa_week = a->toa.week; out[sv].toa_sec = a->toa.sec;
+        out[sv].e = a->e; out[sv].delta_i = a->delta_i; out[sv].omegadot = a->omegadot;
+        out[sv].sqrta = a->sqrta; out[sv].omega0 = a->omega0; out[sv].aop = a->aop;
+        out[sv].m0 = a->m0; out[sv].af0 = a->af0; out[sv].af1 = a->af1;
+    }
+    return rc;
+}
 void ref_date2gps(int y, int m, int d, int hh, int mm, double sec, int *week, double *sow)
 {
     datetime_t t = {y, m, d, hh, mm, sec};

@@ -142,3 +142,64 @@ def test_golden_nav_capture():
     for k in range(1, len(z["dwrd_seq"])):
         gpsiq.nav_message(sbf, int(z["week"]), float(z["sec"]) + 30.0 * k, False, st)
         assert np.array_equal(st[0]["dwrd"], z["dwrd_seq"][k])
+
+
+def _sem_text(records, announced=None, week=2189, sec=405504, blank=True, svn_blank=()):
+    lines = ["%d CURRENT.ALM" % (len(records) if announced is None else announced), " %d %d" % (week, sec)]
+    for k, r in enumerate(records):
+        if blank:
+            lines.append("")
+        lines += ["%d" % r["id"], "" if k in svn_blank else "%d" % (40 + r["id"]), "%d" % r.get("ura", 0),
+                  " %.14E %.14E %.14E" % (r["e"], r["di"], r["od"]), " %.14E %.14E %.14E" % (r["sq"], r["o0"], r["w"]),
+                  " %.14E %.14E %.14E" % (r["m0"], r["af0"], r["af1"]), "%d" % r.get("health", 0), "%d" % r.get("cfg", 11)]
+    return "\n".join(lines) + "\n"
+
+
+def test_sem_almanac_reader_matches_reference(ref, tmp_path):
+    """gpsiq_almanac_read_sem == almanac_read_file (almanac.c:73-184), entry for entry: a well-formed file, blank and
+    missing optional lines, ids 0 and > 32, more records than announced and fewer (end of file inside a record), a
+    damaged number in the middle (everything dropped), an empty file, no file."""
+    import ctypes as C
+    import os
+    from gpsiq.abi import NAV_ALM_DTYPE
+    L = ref.lib
+    L.ref_almanac_read.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(21)
+
+    def rec(i):
+        return dict(id=i, e=rng.uniform(0, 0.02), di=rng.uniform(-0.01, 0.01), od=rng.uniform(-3e-9, -2e-9), sq=rng.uniform(5153.0, 5154.0),
+                    o0=rng.uniform(-1, 1), w=rng.uniform(-1, 1), m0=rng.uniform(-1, 1), af0=rng.uniform(-1e-4, 1e-4), af1=rng.uniform(-1e-11, 1e-11),
+                    ura=int(rng.integers(0, 20)), health=int(rng.integers(0, 70)), cfg=int(rng.integers(0, 20)))
+    full = [rec(i) for i in range(1, 32)]
+    texts = {
+        "full": _sem_text(full),
+        "no_blank_lines": _sem_text(full[:9], blank=False),
+        "svn_blank": _sem_text(full[:6], svn_blank=(1, 4)),
+        "odd_ids": _sem_text([rec(0), rec(33), rec(7), rec(7)]),
+        "more_than_announced": _sem_text(full[:12], announced=5),
+        "fewer_than_announced": _sem_text(full[:4], announced=31),
+        "announced_zero": _sem_text(full[:3], announced=0),
+        "cut_inside_a_record": _sem_text(full[:5])[:-60],
+        "damaged_number": _sem_text(full[:8]).replace("E-", "X-", 7).replace("X-", "E-", 6),
+        "empty": "",
+        "header_only": "3 X.ALM\n",
+    }
+    cwd = os.getcwd()
+    try:
+        for name, text in texts.items():
+            d = tmp_path / name
+            d.mkdir()
+            (d / "almanac.sem").write_text(text)
+            os.chdir(d)                                            # the reference opens "almanac.sem" where it runs
+            want = np.zeros(32, dtype=NAV_ALM_DTYPE)
+            L.ref_almanac_read(want.ctypes.data)
+            got, n = gpsiq.almanac_read_sem(d / "almanac.sem")
+            assert got.tobytes() == want.tobytes(), name
+            assert n == int((want["valid"] != 0).sum()), name
+        assert gpsiq.almanac_read_sem(tmp_path / "full" / "almanac.sem")[1] == 31
+        assert gpsiq.almanac_read_sem(tmp_path / "damaged_number" / "almanac.sem")[1] == 0
+        assert gpsiq.almanac_read_sem(tmp_path / "cut_inside_a_record" / "almanac.sem")[1] == 4
+    finally:
+        os.chdir(cwd)
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.almanac_read_sem(tmp_path / "nothing.sem")
