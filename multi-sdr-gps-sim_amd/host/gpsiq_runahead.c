@@ -24,7 +24,9 @@
  *                  same row meaning; a file shorter than nblocks+1 points shortens the run as the
  *                  reference's numd does
  *   lat,lon,h      a static receiver, degrees and metres (-l, gps.c:2337-2340, 2359-2363)
- * out.bin: the iqfile stream.
+ * out.bin: the iqfile stream.  An optional eleventh argument names a SEM almanac file (the reference's almanac.sem,
+ * almanac.c:73-184): its entries fill the almanac pages of subframes 4 and 5; without it those pages are empty, as with
+ * the reference's --disable-almanac.
  */
 #include <math.h>
 #include <stdint.h>
@@ -46,6 +48,7 @@ static int die(const char *what)
 static double time_after(double sec, long steps) { return round(round(sec * 1000.0) + 100.0 * (double) steps) / 1000.0; }
 
 struct host_state {
+    const gpsiq_nav_alm_sv_t *alm;                   /* 32 almanac entries, or NULL (--disable-almanac) */
     int nchan, week;
     double xyz0[3];
     const gpsiq_rinex_eph_t *eph;         /* the set in use: 32 satellites */
@@ -81,7 +84,7 @@ static int allocate(struct host_state *h, double t)
                 }
                 h->trk[i].prn = sv + 1;
                 h->orbit[i] = e->orbit;
-                if (gpsiq_nav_subframes(&e->nav, &h->utc, NULL, h->sbf[i]) != GPSIQ_OK) return -1;          /* gps.c:2190 */
+                if (gpsiq_nav_subframes(&e->nav, &h->utc, h->alm, h->sbf[i]) != GPSIQ_OK) return -1;          /* gps.c:2190 */
                 if (gpsiq_nav_message(h->sbf[i], h->week, t, 1, &h->nav[i]) != GPSIQ_OK) return -1;         /* gps.c:2193 */
                 h->trk[i].g0_week = h->nav[i].g0_week; h->trk[i].g0_sec = h->nav[i].g0_sec;
                 memcpy(h->trk[i].dwrd, h->nav[i].dwrd, sizeof h->trk[i].dwrd);
@@ -113,7 +116,7 @@ static int refresh_ephemeris(struct host_state *h, double t)
             for (int i = 0; i < h->nchan; ++i) {
                 if (h->trk[i].prn == 0) continue;
                 const gpsiq_rinex_eph_t *e = &h->eph[h->trk[i].prn - 1];
-                if (gpsiq_nav_subframes(&e->nav, &h->utc, NULL, h->sbf[i]) != GPSIQ_OK) return -1;
+                if (gpsiq_nav_subframes(&e->nav, &h->utc, h->alm, h->sbf[i]) != GPSIQ_OK) return -1;
                 h->orbit[i] = e->orbit;
             }
         }
@@ -124,8 +127,8 @@ static int refresh_ephemeris(struct host_state *h, double t)
 
 int main(int argc, char **argv)
 {
-    if (argc != 11) {
-        fprintf(stderr, "usage: %s rinex 2|3 week sec xyz.bin|motion.csv|lat,lon,h nblocks nchan fs 1|2 out.bin\n", argv[0]);
+    if (argc != 11 && argc != 12) {
+        fprintf(stderr, "usage: %s rinex 2|3 week sec xyz.bin|motion.csv|lat,lon,h nblocks nchan fs 1|2 out.bin [almanac.sem]\n", argv[0]);
         return 2;
     }
     const int version = atoi(argv[2]), nchan = atoi(argv[7]), ss = atoi(argv[9]);
@@ -166,6 +169,17 @@ int main(int argc, char **argv)
         fclose(fx);
     }
 
+    static gpsiq_nav_alm_sv_t alm[GPSIQ_MAX_SAT];
+    if (argc == 12) {
+        const int nalm = gpsiq_almanac_read_sem(argv[11], alm);
+        if (nalm < 0) { fprintf(stderr, "gpsiq_runahead: %s\n", gpsiq_last_error()); return 1; }
+        if (nalm > 0) h.alm = alm;                                             /* no valid record: as without a file */
+        for (int sv = 0; sv < GPSIQ_MAX_SAT && h.alm; ++sv) {                  /* gps.c:2640-2650: within four weeks of the start */
+            if (!alm[sv].valid) continue;
+            const double dt = (alm[sv].toa_sec - sec0) + (double) (alm[sv].toa_week - week) * 604800.0;
+            if (dt < -4.0 * 604800.0 || dt > 4.0 * 604800.0) { fprintf(stderr, "gpsiq_runahead: invalid time of almanac\n"); return 1; }
+        }
+    }
     h.nchan = nchan; h.week = week; h.eph = eph[ieph]; h.sets = &eph[0][0]; h.nsets = nsets; h.ieph = ieph;
     memcpy(h.xyz0, xyz, sizeof h.xyz0);
     h.iono.enable = 1; h.iono.vflg = h.utc.vflg;

@@ -356,6 +356,30 @@ def test_c_runahead_position_argument_forms(tmp_path):
     static = np.tile(gpsiq.llh_to_ecef(llh[0] / 57.2957795131, llh[1] / 57.2957795131, llh[2]), (nblocks + 1, 1))
     static.tofile(str(tmp_path / "s.bin"))
     assert np.array_equal(run("%r,%r,%r" % llh), run(str(tmp_path / "s.bin")))
+    # a SEM almanac file as the optional last argument: the almanac pages of subframes 4/5 get filled (other words, other bits)
+    from gpsiq.pipeline import RunAheadAllocating
+    from test_nav import _sem_text
+    rng = np.random.default_rng(4)
+    recs = [dict(id=i, e=rng.uniform(0, 0.02), di=rng.uniform(-0.01, 0.01), od=-2.5e-9, sq=5153.6, o0=rng.uniform(-1, 1), w=rng.uniform(-1, 1),
+                 m0=rng.uniform(-1, 1), af0=rng.uniform(-1e-4, 1e-4), af1=0.0) for i in range(1, 32)]
+    (tmp_path / "almanac.sem").write_text(_sem_text(recs, week=WEEK - 2048, sec=405504))
+    alm, nalm = gpsiq.almanac_read_sem(tmp_path / "almanac.sem")
+    assert nalm == 31
+    out = str(tmp_path / "a.bin")
+    r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "xyz.bin"), str(nblocks), str(nchan),
+                        repr(fs), "1", out, str(tmp_path / "almanac.sem")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with_alm = np.fromfile(out, dtype=np.int8)
+    ctx = gpsiq.Context(0)
+    ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph, alm=alm)
+    assert np.array_equal(with_alm, ctx.generate_batch(ra.descriptors(xyz[1:]), ns, fs, SC08).reshape(-1))
+    ra0 = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph)
+    assert np.array_equal(want, ctx.generate_batch(ra0.descriptors(xyz[1:]), ns, fs, SC08).reshape(-1))
+    ctx.close()
+    (tmp_path / "old.sem").write_text(_sem_text(recs, week=WEEK - 2048 - 6, sec=405504))
+    r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "xyz.bin"), "2", str(nchan),
+                        repr(fs), "1", out, str(tmp_path / "old.sem")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "time of almanac" in r.stderr
     # the start time in the reference's -t form (2021/12/29 03:00:00 = week 2190, 270 000 s)
     y, mo, d, hh, mi, s = gpsiq.gps_to_date(WEEK, sec)
     out = str(tmp_path / "t.bin")
