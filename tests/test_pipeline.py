@@ -336,7 +336,7 @@ def test_c_runahead_position_argument_forms(tmp_path):
     host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-sdr-gps-sim_amd", "host")
     subprocess.run(["make", "-s", "-C", host], check=True)
     nblocks, nchan, fs, ns = 6, 8, 2.6e6, 260000
-    path, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=8, sec=270019.0)   # one second into subframe 4
+    path, eph, ieph, utc, xyz, sec = horizon_scenario(tmp_path, nblocks, seed=8, sec=270026.0)   # two seconds into subframe 5: the data words of an almanac page
     xyz = np.round(xyz, 4)                                        # what the CSV's %.4f keeps
     def run(position, n=nblocks):
         out = str(tmp_path / "o.bin")
@@ -370,7 +370,7 @@ def test_c_runahead_position_argument_forms(tmp_path):
                         repr(fs), "1", out, str(tmp_path / "almanac.sem")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     with_alm = np.fromfile(out, dtype=np.int8)
-    assert not np.array_equal(with_alm, want), "subframe 4's almanac page should differ from the empty one"
+    assert not np.array_equal(with_alm, want), "the almanac page of subframe 5 should differ from the empty one"
     ctx = gpsiq.Context(0)
     ra = RunAheadAllocating(eph, utc, nchan, WEEK, sec, xyz[0], ieph=ieph, alm=alm)
     assert np.array_equal(with_alm, ctx.generate_batch(ra.descriptors(xyz[1:]), ns, fs, SC08).reshape(-1))
@@ -381,7 +381,7 @@ def test_c_runahead_position_argument_forms(tmp_path):
     r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", str(WEEK), repr(sec), str(tmp_path / "xyz.bin"), "2", str(nchan),
                         repr(fs), "1", out, str(tmp_path / "old.sem")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "time of almanac" in r.stderr
-    # the start time in the reference's -t form (2021/12/29 03:00:19 = week 2190, 270 019 s)
+    # the start time in the reference's -t form (2021/12/29 03:00:26 = week 2190, 270 026 s)
     y, mo, d, hh, mi, s = gpsiq.gps_to_date(WEEK, sec)
     out = str(tmp_path / "t.bin")
     r = subprocess.run([os.path.join(host, "gpsiq_runahead"), path, "2", "%d/%d/%d,%d:%d:%g" % (y, mo, d, hh, mi, s), "-", str(tmp_path / "xyz.bin"),
