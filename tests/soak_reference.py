@@ -21,7 +21,8 @@ ref = _oracle.load_ref()
 assert ref is not None, "needs oracle/_ref/libgpsref.so"
 ctx = gpsiq.Context(0)
 ctx.set_nco_mode(NCO_REFERENCE)
-rng = np.random.default_rng(12345)
+seed = int(os.environ.get("GPSIQ_SOAK_SEED", str(int(time.time()))))
+rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 runs = blocks = samples = patches = 0
 while time.time() < t_end:
@@ -33,7 +34,7 @@ while time.time() < t_end:
     carr = np.zeros(nc)
     got = ctx.generate_batch(d, fs // 10, float(fs), ss, carr_out=carr)
     if not np.array_equal(got.reshape(-1), want) or not np.array_equal(carr, carr_ref[-1]):
-        print("MISMATCH", fs, nb, nc, ss, int((got.reshape(-1) != want).sum()))
+        print("MISMATCH seed", seed, fs, nb, nc, ss, int((got.reshape(-1) != want).sum()))
         np.save(os.path.join(ROOT, "gpurun_out", "soak_fail_desc.npy"), d)
         sys.exit(1)
     _, p, _ = gpsiq.reference_blocks(d, float(fs), fs // 10)
@@ -41,5 +42,5 @@ while time.time() < t_end:
     blocks += nb
     samples += nb * (fs // 10)
     patches += len(p)
-print(f"soak ok: {runs} runs, {blocks} blocks, {samples / 1e9:.2f} G samples x up to 16 channels, {patches} patched samples, "
+print(f"soak ok (seed {seed}): {runs} runs, {blocks} blocks, {samples / 1e9:.2f} G samples x up to 16 channels, {patches} patched samples, "
       f"all equal to the reference's own loop incl. the carried carr_phase ({budget:.0f} s)")
