@@ -16,7 +16,7 @@
  *   gps.c:272-309    codegen() C/A sequence             -> gpsiq_prn_code()   (table built in-library)
  *   gps.c:145-213    sinTable512 / cosTable512          -> gpsiq_carrier_table() (table built in-library)
  *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
- *   gps.c:2731-2765  per-block host refresh              -> gpsiq_refresh_batch(), gpsiq_track_init()
+ *   gps.c:2731-2765  per-block host refresh              -> gpsiq_refresh_batch() / _epochs() / _epochs_quantized(), gpsiq_track_init()
  *   gps.c:2142-2162  checkSatVisibility()                -> gpsiq_sat_visibility()
  *   gps.c:361-447, 2253-2277  xyz2llh / llh2xyz / readUserMotion -> gpsiq_ecef_to_llh(), gpsiq_llh_to_ecef(), gpsiq_motion_read_csv()
  *   gps.c:617-884, 1008-1072, 2066-2140  nav words     -> gpsiq_nav_subframes/_message/_parity()
