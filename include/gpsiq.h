@@ -21,6 +21,7 @@
  *   gps.c:361-447, 2253-2277  xyz2llh / llh2xyz / readUserMotion -> gpsiq_ecef_to_llh(), gpsiq_llh_to_ecef(), gpsiq_motion_read_csv()
  *   gps.c:617-884, 1008-1072, 2066-2140  nav words     -> gpsiq_nav_subframes/_message/_parity()
  *   gps.c:1131-1891  readRinex2 / readRinex3             -> gpsiq_rinex_read(), gpsiq_rinex_select()
+ *   gps.c:2534-2561  -T: overwrite toc / toe             -> gpsiq_rinex_overwrite_time()
  *   gps.c:315-355    date2gps / gps2date                 -> gpsiq_date_to_gps(), gpsiq_gps_to_date()
  *   almanac.c:73-184 almanac_read_file (SEM)             -> gpsiq_almanac_read_sem()
  *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
@@ -446,6 +447,11 @@ int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsi
 /* The set gps_thread_ep() would use for a start time (gps.c:2588-2608): first set with a
  * satellite whose toc is within one hour of (week, sec); -1 if none. */
 int gpsiq_rinex_select(const gpsiq_rinex_eph_t *eph, int nsets, int week, double sec);
+/* The reference's -T option (gps.c:2534-2561): move the times of clock and of ephemeris of every valid record, and its
+ * calendar time, by the distance from the first set's first time of clock (gps.c:2507-2513) to the start time cut to
+ * whole two hours, and set the UTC reference (wnt, tot) to that cut time: an old broadcast file then serves any start
+ * time.  eph is [nsets][GPSIQ_MAX_SAT] as gpsiq_rinex_read() filled it. */
+int gpsiq_rinex_overwrite_time(gpsiq_rinex_eph_t *eph, int nsets, gpsiq_nav_utc_t *utc, int week, double sec);
 /* date2gps() / gps2date() (gps.c:315-355): a calendar date and time of day <-> GPS week and seconds of the week, as the
  * reference converts its -t start time and RINEX epochs (no leap seconds either way; months outside 1..12 count as
  * January where the reference indexes past its table). */

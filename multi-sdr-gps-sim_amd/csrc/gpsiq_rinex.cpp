@@ -211,6 +211,43 @@ int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsi
     return nsets > GPSIQ_EPHEM_SETS ? GPSIQ_EPHEM_SETS : nsets;
 }
 
+int gpsiq_rinex_overwrite_time(gpsiq_rinex_eph_t *eph, int nsets, gpsiq_nav_utc_t *utc, int week, double sec)
+{
+    if (!eph || !utc || nsets < 1 || nsets > GPSIQ_EPHEM_SETS) return fail(GPSIQ_E_ARG, "bad argument");
+    // gmin: time of clock of the first valid satellite of the first set (gps.c:2507-2513); all zero if there is none
+    int gmin_week = 0;
+    double gmin_sec = 0.0;
+    for (int sv = 0; sv < GPSIQ_MAX_SAT; ++sv)
+        if (eph[sv].vflg) { gmin_week = eph[sv].toc_week; gmin_sec = eph[sv].nav.toc_sec; break; }
+    // the start time cut to whole two hours, and how far that is from gmin (gps.c:2536-2539)
+    const double cut = (double) (((int) sec) / 7200) * 7200.0;
+    const double dsec = (cut - gmin_sec) + (double) (week - gmin_week) * kSecWeek;        // subGpsTime, gps.c:1096-1103
+    utc->wnt = week;                                                                       // gps.c:2542-2543
+    utc->tot = (int) cut;
+    auto shifted = [dsec](int w, double s, int *w_out) {                                   // incGpsTime, gps.c:1105-1124
+        double t = s + dsec;
+        t = std::round(t * 1000.0) / 1000.0;
+        while (t >= kSecWeek) { t -= kSecWeek; ++w; }
+        while (t < 0.0) { t += kSecWeek; --w; }
+        *w_out = w;
+        return t;
+    };
+    for (int i = 0; i < nsets; ++i)
+        for (int sv = 0; sv < GPSIQ_MAX_SAT; ++sv) {
+            gpsiq_rinex_eph_t &e = eph[(size_t) i * GPSIQ_MAX_SAT + sv];
+            if (!e.vflg) continue;
+            int w;
+            const double toc = shifted(e.toc_week, e.nav.toc_sec, &w);                     // gps.c:2552-2555
+            e.toc_week = w;
+            e.nav.toc_sec = e.orbit.toc_sec = toc;
+            gpsiq_gps_to_date(w, toc, &e.t_y, &e.t_m, &e.t_d, &e.t_hh, &e.t_mm, &e.t_sec);
+            const double toe = shifted(e.nav.toe_week, e.nav.toe_sec, &w);                 // gps.c:2557-2558
+            e.nav.toe_week = w;
+            e.nav.toe_sec = e.orbit.toe_sec = toe;
+        }
+    return GPSIQ_OK;
+}
+
 void gpsiq_date_to_gps(int year, int month, int day, int hour, int minute, double second, int *week, double *sec)
 {
     const GpsTime g = to_gps(year, month, day, hour, minute, second);

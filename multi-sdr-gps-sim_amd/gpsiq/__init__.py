@@ -93,6 +93,7 @@ _sat_visibility = _sig("gpsiq_sat_visibility", _i, _vp, _i, _d, _vp, _d, _vp)
 _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i)
 _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
 _almanac_read_sem = _sig("gpsiq_almanac_read_sem", _i, C.c_char_p, _vp)
+_rinex_overwrite_time = _sig("gpsiq_rinex_overwrite_time", _i, _vp, _i, _vp, _i, _d)
 _date_to_gps = _sig("gpsiq_date_to_gps", None, _i, _i, _i, _i, _i, _d, _vp, _vp)
 _gps_to_date = _sig("gpsiq_gps_to_date", None, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp)
 _refresh_epochs_q = _sig("gpsiq_refresh_epochs_quantized", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _vp, _i)
@@ -362,6 +363,14 @@ def rinex_read(path, version=2):
     utc = np.zeros(1, dtype=NAV_UTC_DTYPE)
     n = _rinex_read(os.fsencode(path), int(version), _p(eph), _p(utc))
     return eph, utc[0], n
+
+
+def rinex_overwrite_time(eph, nsets, utc, week, sec):
+    """The reference's -T option (gps.c:2534-2561): shift toc / toe / calendar time of every valid record so that the
+    file serves the start time (week, sec); in place on eph[:nsets] and utc."""
+    assert eph.dtype == RINEX_EPH_DTYPE and eph.flags.c_contiguous and utc.dtype == NAV_UTC_DTYPE
+    _check(_rinex_overwrite_time(_p(eph), int(nsets), _p(utc), int(week), float(sec)))
+    return eph, utc
 
 
 def rinex_select(eph, nsets, week, sec):

@@ -560,6 +560,40 @@ int ref_read_rinex(int version, const char *path, gpsiq_rinex_eph_t *out /* [13]
     return n;
 }
 
+/* ---- the -T start-time overwrite (gps.c:2507-2513 gmin, gps.c:2534-2561 the shift of toc / toe / t and of the UTC reference) ---- */
+int ref_time_overwrite(gpsiq_rinex_eph_t *sets /* [13][32] */, int neph, gpsiq_nav_utc_t *utc, int week, double sec)
+{
+    static ephem_t eph[EPHEM_ARRAY_SIZE][MAX_SAT];
+    ionoutc_t ionoutc;
+    gpstime_t g0, gmin, gtmp;
+    datetime_t tmin, ttmp;
+    int sv, i;
+    memset(eph, 0, sizeof eph);
+    memset(&ionoutc, 0, sizeof ionoutc);
+    memset(&gmin, 0, sizeof gmin); memset(&tmin, 0, sizeof tmin);
+    for (i = 0; i < neph; i++)
+        for (sv = 0; sv < MAX_SAT; sv++)
+            if (sets[i * 32 + sv].vflg) load_full_eph(&eph[i][sv], &sets[i * 32 + sv]);
+    ionoutc.wnt = utc->wnt; ionoutc.tot = utc->tot;
+    g0.week = week; g0.sec = sec;
+#include "ref_gmin.inc"              /* gps.c:2507-2513 */
+    {
+#include "ref_overwrite.inc"         /* gps.c:2534-2561 */
+    }
+    for (i = 0; i < neph; i++)
+        for (sv = 0; sv < MAX_SAT; sv++) {
+            gpsiq_rinex_eph_t *o = &sets[i * 32 + sv];
+            const ephem_t *e = &eph[i][sv];
+            if (!o->vflg) continue;
+            o->t_y = e->t.y; o->t_m = e->t.m; o->t_d = e->t.d; o->t_hh = e->t.hh; o->t_mm = e->t.mm; o->t_sec = e->t.sec;
+            o->toc_week = e->toc.week; o->orbit.toc_sec = o->nav.toc_sec = e->toc.sec;
+            o->nav.toe_week = e->toe.week; o->orbit.toe_sec = o->nav.toe_sec = e->toe.sec;
+        }
+    utc->wnt = ionoutc.wnt; utc->tot = ionoutc.tot;
+    (void) tmin;
+    return 0;
+}
+
 /* ---- where the receiver is: the reference's geodetic conversions and its user-motion reader ---- */
 /* almanac_read_file() reads "almanac.sem" in the current directory; returns its CURLcode, the records in out[32] */
 int ref_almanac_read(gpsiq_nav_alm_sv_t *out)

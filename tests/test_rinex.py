@@ -135,3 +135,24 @@ def test_rinex_to_samples_on_gpu(oracle, tmp_path):
     for b in (0, 4, 9):
         assert np.array_equal(out[b], oracle.block_fixed(q[b], ns, SC08, seq=True))
     ctx.close()
+
+
+def test_start_time_overwrite_matches_reference(ref, tmp_path):
+    """gpsiq_rinex_overwrite_time == the reference's -T lines (gps.c:2507-2513, 2534-2561): every time of clock, time of
+    ephemeris, calendar time and the UTC reference, for start times years later, earlier, across week boundaries and
+    with fractional seconds; afterwards the first set serves the new start time."""
+    import ctypes as C
+    L = ref.lib
+    L.ref_time_overwrite.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double]
+    recs = synth_rinex_records(11, TOKYO, WEEK, SEC, seed=12, sets=3)
+    path = write_rinex_nav(str(tmp_path / "old.21n"), recs, UTC, 2)
+    for week, sec in ((2400, 123456.789), (2190, 270000.0), (2191, 5.5), (2189, 604799.999), (1000, 7199.0), (2500, 0.0)):
+        eph, utc, n = gpsiq.rinex_read(path, 2)
+        want, wutc = eph.copy(), np.asarray(utc).copy().reshape(1)
+        L.ref_time_overwrite(want.ctypes.data, n, wutc.ctypes.data, week, sec)
+        utc1 = np.asarray(utc).copy().reshape(1)
+        gpsiq.rinex_overwrite_time(eph, n, utc1, week, sec)
+        assert same(eph, want) and same(utc1, wutc), (week, sec)
+        assert utc1["wnt"][0] == week and utc1["tot"][0] == (int(sec) // 7200) * 7200
+        assert gpsiq.rinex_select(eph, n, week, float(int(sec) // 7200 * 7200) + 10.0) == 0
+        assert not same(eph, gpsiq.rinex_read(path, 2)[0]) or (week, sec) == (2190, 270000.0)
