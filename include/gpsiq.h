@@ -336,6 +336,11 @@ int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const d
  * the file cannot be opened. */
 void gpsiq_llh_to_ecef(const double llh[3], double xyz[3]);
 void gpsiq_ecef_to_llh(const double xyz[3], double llh[3]);
+/* Move an ECEF position by (north, east, up) metres in the local tangent frame of the geodetic point llh_ref (radians,
+ * metres): xyz += ltcmat(llh_ref)^T * neu, the three lines the reference uses for its target offset (-T distance, bearing:
+ * gps.c:2350-2356, neu = distance*cos, distance*sin, height) and for every step of its interactive mode (gps.c:2720-2728,
+ * neu = velocity*0.1*cos, velocity*0.1*sin, vertical_speed*0.1); the frame stays that of the START location, as there. */
+void gpsiq_ecef_add_neu(const double llh_ref[3], const double neu[3], double xyz[3]);
 int  gpsiq_motion_read_csv(const char *path, double *xyz /* [max_points][3] */, int max_points);
 
 /* Blocks k = 0..nblocks-1 at receiver times t_k = incGpsTime^(k+1)(week, sec) (the reference

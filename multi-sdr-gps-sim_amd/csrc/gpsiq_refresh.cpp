@@ -348,6 +348,17 @@ void gpsiq_llh_to_ecef(const double llh[3], double xyz[3])
     xyz[2] = ((1.0 - e2) * n + llh[2]) * slat;
 }
 
+void gpsiq_ecef_add_neu(const double llh_ref[3], const double neu[3], double xyz[3])
+{
+    // ltcmat (gps.c:449-468) of the reference point, then gps.c:2354-2356 / 2726-2728
+    const double slat = sin_only(llh_ref[0]), clat = cos_only(llh_ref[0]);
+    const double slon = sin_only(llh_ref[1]), clon = cos_only(llh_ref[1]);
+    const double t[3][3] = {{-slat * clon, -slat * slon, clat}, {-slon, clon, 0.0}, {clat * clon, clat * slon, slat}};
+    xyz[0] += t[0][0] * neu[0] + t[1][0] * neu[1] + t[2][0] * neu[2];
+    xyz[1] += t[0][1] * neu[0] + t[1][1] * neu[1] + t[2][1] * neu[2];
+    xyz[2] += t[0][2] * neu[0] + t[1][2] * neu[1] + t[2][2] * neu[2];
+}
+
 int gpsiq_motion_read_csv(const char *path, double *xyz, int max_points)
 {
     if (!path || !xyz || max_points < 0) return fail(GPSIQ_E_ARG, "bad argument");

@@ -94,6 +94,7 @@ _refresh_batch = _sig("gpsiq_refresh_batch", _i, _vp, _vp, _i, _d, _vp, _i, _i, 
 _refresh_epochs = _sig("gpsiq_refresh_epochs", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i)
 _almanac_read_sem = _sig("gpsiq_almanac_read_sem", _i, C.c_char_p, _vp)
 _rinex_overwrite_time = _sig("gpsiq_rinex_overwrite_time", _i, _vp, _i, _vp, _i, _d)
+_ecef_add_neu = _sig("gpsiq_ecef_add_neu", None, _vp, _vp, _vp)
 _date_to_gps = _sig("gpsiq_date_to_gps", None, _i, _i, _i, _i, _i, _d, _vp, _vp)
 _gps_to_date = _sig("gpsiq_gps_to_date", None, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp)
 _refresh_epochs_q = _sig("gpsiq_refresh_epochs_quantized", _i, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp, _i, _d, _i, _vp, _i)
@@ -282,6 +283,15 @@ def llh_to_ecef(lat_rad, lon_rad, h):
     xyz = np.zeros(3)
     _llh_to_ecef(_p(llh), _p(xyz))
     return xyz
+
+
+def ecef_add_neu(llh_ref, neu, xyz):
+    """xyz + ltcmat(llh_ref)^T * neu (reference gps.c:2354-2356, 2726-2728): a new array."""
+    llh = np.ascontiguousarray(llh_ref, dtype=np.float64)
+    d = np.ascontiguousarray(neu, dtype=np.float64)
+    out = np.array(xyz, dtype=np.float64).copy()
+    _ecef_add_neu(_p(llh), _p(d), _p(out))
+    return out
 
 
 def ecef_to_llh(xyz):

@@ -625,6 +625,15 @@ void ref_gps2date(int week, double sow, int *y, int *m, int *d, int *hh, int *mm
     *y = t.y; *m = t.m; *d = t.d; *hh = t.hh; *mm = t.mm; *sec = t.sec;
 }
 void ref_llh2xyz(const double *llh, double *xyz) { llh2xyz(llh, xyz); }
+/* the target offset / interactive step: ltcmat of the start location, then the three lines gps.c:2354-2356 (== 2726-2728) */
+void ref_add_neu(const double *llh, const double *neu_in, double *xyz_io)
+{
+    double tmat[3][3], neu[3] = {neu_in[0], neu_in[1], neu_in[2]};
+    double xyz[1][3] = {{xyz_io[0], xyz_io[1], xyz_io[2]}};
+    ltcmat(llh, tmat);
+#include "ref_addneu.inc"            /* gps.c:2354-2356 */
+    xyz_io[0] = xyz[0][0]; xyz_io[1] = xyz[0][1]; xyz_io[2] = xyz[0][2];
+}
 void ref_xyz2llh(const double *xyz, double *llh) { xyz2llh(xyz, llh); }
 int ref_read_user_motion(const char *path, double *xyz_out, int max_points)
 {

@@ -221,6 +221,32 @@ def test_receiver_position_inputs_match_reference(ref, tmp_path):
         gpsiq.motion_read_csv(str(tmp_path / "missing.csv"))
 
 
+def test_moving_in_the_local_frame_matches_reference(ref):
+    """gpsiq_ecef_add_neu == ltcmat + the three lines of the reference's target offset / interactive step
+    (gps.c:449-468, 2354-2356), bit for bit, incl. a chain of 0.1 s steps as the interactive mode makes them."""
+    import ctypes as C
+    import gpsiq
+    L = ref.lib
+    L.ref_add_neu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(31)
+    for _ in range(200):
+        llh = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-3.1, 3.1), rng.uniform(-100.0, 9000.0)])
+        xyz = gpsiq.llh_to_ecef(*llh)
+        want = xyz.copy()
+        for _ in range(5):                                    # five steps in the frame of the start location
+            neu = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-5, 5)])
+            L.ref_add_neu(llh.ctypes.data, neu.ctypes.data, want.ctypes.data)
+            xyz = gpsiq.ecef_add_neu(llh, neu, xyz)
+            assert xyz.tobytes() == want.tobytes()
+    # the -T form: distance and bearing (milli-degrees in the reference's struct) from the location
+    llh = np.array([35.681298 / 57.2957795131, 139.766247 / 57.2957795131, 10.0])
+    d, bearing_mdeg, h = 1500.0, 45000.0, 20.0
+    neu = np.array([d * np.cos((bearing_mdeg / 1000) / 57.2957795131), d * np.sin((bearing_mdeg / 1000) / 57.2957795131), h])
+    moved = gpsiq.ecef_add_neu(llh, neu, gpsiq.llh_to_ecef(*llh))
+    back = gpsiq.ecef_to_llh(moved)
+    assert abs(np.linalg.norm(moved - gpsiq.llh_to_ecef(*llh)) - np.hypot(d, h)) < 1e-6 and back[0] > llh[0] and back[1] > llh[1]
+
+
 def test_time_conversions_match_reference(ref):
     """gpsiq_date_to_gps / gpsiq_gps_to_date == date2gps / gps2date (gps.c:315-355): random dates 1981-2080 (and the epoch itself) incl. leap
     days and week boundaries, exact doubles, and the round trip."""
