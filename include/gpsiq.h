@@ -146,7 +146,11 @@ void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512[512]);
  * carry_in: if non-NULL, carry_in[i] replaces the phase derived from ch[i].carr_phase.
  * carry_out: if non-NULL, receives the exact carrier phase after nsamp samples
  *            (the only state the loop hands to the next block, gps.c:2821).
- * Unused slots (prn <= 0) produce prn = 0.  out has nchan entries. */
+ * Unused slots (prn <= 0) produce prn = 0.  out has nchan entries.
+ * Range checks (GPSIQ_E_RANGE), the same in every entry point that takes gpsiq_chan_t: |f_carr/fs| < 0.5,
+ * 0 < f_code/fs < 2, carr_phase in [0,1), code_phase in [0,1023), iword/ibit/icode inside dwrd, and gain finite
+ * with |gain| < 4e6 -- gpsiq_set_descriptors applies the same bound to descriptors quantised elsewhere, so a set
+ * quantised on one node is not rejected late on another. */
 int gpsiq_quantize(const gpsiq_chan_t *ch, int nchan, double fs, int nsamp,
                    gpsiq_qchan_t *out, const uint64_t *carry_in, uint64_t *carry_out);
 
@@ -267,7 +271,8 @@ void  gpsiq_host_free(void *p);
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
 /* Patches that go with the resident descriptors (gpsiq_reference_batch); every later gpsiq_launch
  * applies those of the blocks it synthesises, on the same stream, after the kernel.  n = 0 clears
- * them; gpsiq_set_descriptors clears them too. */
+ * them; gpsiq_set_descriptors clears them too.  A patch's slot counts its block's ACTIVE channels
+ * (prn != 0) from 0, not the caller's channel index: slot >= that count is GPSIQ_E_RANGE. */
 int gpsiq_set_patches(gpsiq_ctx_t *ctx, const gpsiq_patch_t *patches, int n);
 /* Launch synthesis of blocks [block0, block0+nblocks) of the resident descriptors into
  * the DEVICE buffer dst; block b is written at dst + (b-block0)*block_stride_bytes
@@ -277,7 +282,9 @@ int gpsiq_set_patches(gpsiq_ctx_t *ctx, const gpsiq_patch_t *patches, int n);
 int gpsiq_launch(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, int sample_size,
                  void *dst, size_t block_stride_bytes, void *hip_stream, int variant);
 /* (The "segm" variant and the patches of GPSIQ_NCO_REFERENCE use buffers owned by the context: launches of one
- * context that use them belong on one stream at a time.  The default kernels have no such state.) */
+ * context that use them belong on one stream at a time.  The default kernels have no such state: launches of one
+ * resident set may run on several streams at once, and gpsiq_set_descriptors waits for every one of them before it
+ * reuses the descriptor buffer they read.) */
 int gpsiq_synchronize(gpsiq_ctx_t *ctx, void *hip_stream);
 /* Time iters back-to-back launches with HIP events on hip_stream; returns the mean
  * kernel-launch duration in milliseconds in *ms_per_launch. */

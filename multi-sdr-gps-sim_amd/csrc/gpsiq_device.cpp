@@ -36,8 +36,14 @@ struct gpsiq_ctx {
     struct DescBuf {
         gpsiq_qchan_t *d = nullptr;  size_t cap = 0;      // device copy, in descriptors
         gpsiq_qchan_t *h = nullptr;  size_t hcap = 0;     // page-locked staging of the compacted descriptors
-        hipEvent_t     last_use = nullptr;                // recorded after every launch that reads d
+        // one event per stream that has launched on this buffer since it was last known idle: a launch on stream B must
+        // not hide a longer one still running on stream A (when more than kUses streams are in play the extra ones
+        // are chained behind the first, which then covers them)
+        struct Use { hipStream_t s = nullptr; hipEvent_t ev = nullptr; bool active = false; };
+        static constexpr int kUses = 4;
+        Use            use[kUses];
         bool           in_use = false;
+        std::vector<uint8_t> active_per_block;            // active channels of every resident block (patch validation)
     } buf[2];
     int            cur = 0;             // buf[cur] holds the resident set
     gpsiq_qchan_t *d_desc = nullptr;    // == buf[cur].d
@@ -86,6 +92,37 @@ static double wall_ms()
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double) ts.tv_sec * 1e3 + (double) ts.tv_nsec * 1e-6;
+}
+
+// Wait until no launch reads the buffer any more (every stream that used it), then forget the uses.
+static int wait_idle(gpsiq_ctx::DescBuf &b)
+{
+    if (!b.in_use) return GPSIQ_OK;
+    for (auto &u : b.use)
+        if (u.active) { HIP_TRY(hipEventSynchronize(u.ev)); u.active = false; }
+    b.in_use = false;
+    return GPSIQ_OK;
+}
+
+// Record that stream s has just launched work reading the buffer.
+static int mark_use(gpsiq_ctx::DescBuf &b, hipStream_t s)
+{
+    gpsiq_ctx::DescBuf::Use *slot = nullptr;
+    for (auto &u : b.use)
+        if (u.active && u.s == s) { slot = &u; break; }
+    if (!slot)
+        for (auto &u : b.use)
+            if (!u.active) { slot = &u; break; }
+    if (!slot) {
+        // more streams than events: put this stream behind the first tracked one, whose event it then re-records
+        slot = &b.use[0];
+        HIP_TRY(hipStreamWaitEvent(s, slot->ev, 0));
+    }
+    if (!slot->ev) HIP_TRY(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(slot->ev, s));
+    slot->s = s; slot->active = true;
+    b.in_use = true;
+    return GPSIQ_OK;
 }
 
 static int ensure_out(gpsiq_ctx *c, size_t bytes)
@@ -147,7 +184,6 @@ int gpsiq_create(gpsiq_ctx_t **out, int device)
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->buf[i].last_use, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipMalloc((void **) &c->d_tab, sizeof(DeviceTables));
@@ -179,7 +215,8 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     for (int i = 0; i < 2; ++i) {
         if (c->buf[i].d) (void) hipFree(c->buf[i].d);
         if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
-        if (c->buf[i].last_use) (void) hipEventDestroy(c->buf[i].last_use);
+        for (auto &u : c->buf[i].use)
+            if (u.ev) (void) hipEventDestroy(u.ev);
         if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
         if (c->copy_stream[i]) (void) hipStreamDestroy(c->copy_stream[i]);
     }
@@ -211,7 +248,7 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     gpsiq_ctx::DescBuf &nb = c->buf[c->cur ^ 1];        // the set not being read by the latest launches
     // the launch from two sets ago may still be reading this buffer (and its staging may still be
     // the source of an upload): wait for exactly that, not for the whole device
-    if (nb.in_use) { HIP_TRY(hipEventSynchronize(nb.last_use)); nb.in_use = false; }
+    { int wrc = wait_idle(nb); if (wrc) return wrc; }
     if (n > nb.hcap) {
         if (nb.h) HIP_TRY(hipHostFree(nb.h));
         nb.h = nullptr; nb.hcap = 0;
@@ -222,8 +259,9 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     // after them.  The sum over channels is commutative modulo 2^16, so slot order is free.
     // Validation + compaction run on host threads straight into the page-locked staging buffer,
     // BEFORE anything resident is touched: a rejected set leaves the previous one in place.
-    struct PJob { const gpsiq_qchan_t *q; gpsiq_qchan_t *out; int nchan; uint64_t mx; int max_active; long max_amp; int rc; size_t bad; };
-    PJob pj = {q, nb.h, nchan, 0, 0, 0, GPSIQ_OK, 0};
+    struct PJob { const gpsiq_qchan_t *q; gpsiq_qchan_t *out; uint8_t *active; int nchan; uint64_t mx; int max_active; long max_amp; int rc; size_t bad; };
+    nb.active_per_block.resize((size_t) nblocks);
+    PJob pj = {q, nb.h, nb.active_per_block.data(), nchan, 0, 0, 0, GPSIQ_OK, 0};
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
     parallel_for(nblocks, 0, 128, [](void *p, int b0, int b1) {
@@ -239,7 +277,7 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
                 const gpsiq_qchan_t &d = j.q[i];
                 if (!d.prn) continue;
                 if (d.prn > 32 || d.chip0 >= GPSIQ_CA_SEQ_LEN || d.icode >= 20 || (d.code_frac >> GPSIQ_CODE_FRAC_BITS) ||
-                    (d.code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(d.gain > -4.0e6 && d.gain < 4.0e6)) {
+                    (d.code_step >> (GPSIQ_CODE_FRAC_BITS + 1)) || !(d.gain > -kMaxGain && d.gain < kMaxGain)) {
                     if (__sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, d.prn > 32 ? GPSIQ_E_ARG : GPSIQ_E_RANGE)) j.bad = i;
                     continue;
                 }
@@ -248,6 +286,7 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
                 j.out[(size_t) b * j.nchan + na++] = d;
             }
             for (int s = na; s < j.nchan; ++s) std::memset(&j.out[(size_t) b * j.nchan + s], 0, sizeof(gpsiq_qchan_t));
+            j.active[b] = (uint8_t) na;
             if (na > max_active) max_active = na;
             if (amp > max_amp) max_amp = amp;
         }
@@ -288,15 +327,15 @@ int gpsiq_set_patches(gpsiq_ctx_t *c, const gpsiq_patch_t *patches, int n)
     if (n == 0) return GPSIQ_OK;
     for (int i = 0; i < n; ++i) {
         const gpsiq_patch_t &p = patches[i];
-        if ((int64_t) p.block >= c->nblocks || p.slot >= c->nchan || p.lut > 511 || p.neg > 1)
+        // slot counts the block's ACTIVE channels (device order), not the caller's channel index
+        if ((int64_t) p.block >= c->nblocks || p.slot >= c->buf[c->cur].active_per_block[p.block] || p.lut > 511 || p.neg > 1)
             return fail(GPSIQ_E_RANGE, "patch %d (block %u, slot %u, lut %u) outside the resident descriptors", i, p.block, p.slot, p.lut);
         if (i && (patches[i - 1].block > p.block || (patches[i - 1].block == p.block && patches[i - 1].sample > p.sample)))
             return fail(GPSIQ_E_ARG, "patches not sorted by (block, sample) at %d", i);
     }
     // the launches that may still read the previous list were issued on caller streams this context
     // does not track beyond the descriptor events: wait for those
-    for (int i = 0; i < 2; ++i)
-        if (c->buf[i].in_use) HIP_TRY(hipEventSynchronize(c->buf[i].last_use));
+    for (int i = 0; i < 2; ++i) { int wrc = wait_idle(c->buf[i]); if (wrc) return wrc; }
     if ((size_t) n > c->patch_cap) {
         if (c->d_patch) HIP_TRY(hipFree(c->d_patch));
         c->d_patch = nullptr; c->patch_cap = 0;
@@ -334,10 +373,7 @@ static int launch_on(gpsiq_ctx *c, int v, int block0, int nblocks, int nsamp, in
     if (e == hipSuccess && c->npatch)
         e = launch_patches(c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, c->d_patch, c->npatch, s);
     if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
-    if (nblocks > 0 && nsamp > 0) {
-        HIP_TRY(hipEventRecord(c->buf[c->cur].last_use, s));
-        c->buf[c->cur].in_use = true;
-    }
+    if (nblocks > 0 && nsamp > 0) return mark_use(c->buf[c->cur], s);
     return GPSIQ_OK;
 }
 
@@ -449,25 +485,36 @@ static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nbloc
         HIP_TRY(hipStreamSynchronize(c->stream));
         return GPSIQ_OK;
     }
-    // pieces: kernel on c->stream, copy of piece k on copy_stream[k & 1] once its kernel has finished
+    // pieces: kernel on c->stream, copy of piece k on copy_stream[k & 1] once its kernel has finished.
+    // On an error in the middle the earlier pieces may still be copying into the caller's buffer: whatever happens, the
+    // three streams are drained before this returns, so the caller may free or reuse dst.
     int k = 0;
-    for (int b0 = 0; b0 < nblocks; b0 += chunk, ++k) {
+    hipError_t e = hipSuccess;
+    const char *what = "";
+    for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK && e == hipSuccess; b0 += chunk, ++k) {
         const int nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
         uint8_t *piece = static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
         rc = gpsiq_launch(c, b0, nb, nsamp, sample_size, piece, stride, c->stream, kAuto);
-        if (rc) return rc;
+        if (rc) break;
         hipStream_t cs = c->copy_stream[k & 1];
-        HIP_TRY(hipEventRecord(c->chunk_done[k & 1], c->stream));
-        HIP_TRY(hipStreamWaitEvent(cs, c->chunk_done[k & 1], 0));
+        what = "piece hand-over";
+        e = hipEventRecord(c->chunk_done[k & 1], c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs, c->chunk_done[k & 1], 0);
+        if (e != hipSuccess) break;
+        what = "piece copy";
         if (stride == blk_bytes)                                  // rows are contiguous: one linear DMA
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, piece, blk_bytes * (size_t) nb, kind, cs));
+            e = hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, piece, blk_bytes * (size_t) nb, kind, cs);
         else
-            HIP_TRY(hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, piece, stride, blk_bytes,
-                                     (size_t) nb, kind, cs));
+            e = hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, piece, stride, blk_bytes,
+                                 (size_t) nb, kind, cs);
     }
-    HIP_TRY(hipStreamSynchronize(c->copy_stream[0]));
-    HIP_TRY(hipStreamSynchronize(c->copy_stream[1]));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const hipError_t s0 = hipStreamSynchronize(c->copy_stream[0]);
+    const hipError_t s1 = hipStreamSynchronize(c->copy_stream[1]);
+    const hipError_t s2 = hipStreamSynchronize(c->stream);
+    if (rc) return rc;                                            // gpsiq_launch has set the text
+    if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "%s: %s", what, hipGetErrorString(e));
+    if (s0 != hipSuccess || s1 != hipSuccess || s2 != hipSuccess)
+        return fail(GPSIQ_E_DEVICE, "batch pieces: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1 != hipSuccess ? s1 : s2));
     return GPSIQ_OK;
 }
 
@@ -560,7 +607,7 @@ int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan
     uint64_t max_step = 0;
     for (int i = 0; i < nchan; ++i) {
         if (!q[i].prn) continue;
-        if (!(q[i].gain > -4.0e6 && q[i].gain < 4.0e6)) return fail(GPSIQ_E_RANGE, "gain %g outside the NCO format", q[i].gain);
+        if (!(q[i].gain > -kMaxGain && q[i].gain < kMaxGain)) return fail(GPSIQ_E_RANGE, "gain %g outside the NCO format", q[i].gain);
         if (q[i].code_step > max_step) max_step = q[i].code_step;
         amp += (long) (250.0 * std::fabs(q[i].gain));
         a.h[na++] = q[i];

@@ -409,7 +409,8 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
                 if (d.prn <= 0) { prev = 0; carr = 0.0; continue; }
                 if (b == 0 || prev != d.prn) carr = d.carr_phase;
                 j.start[(size_t) b * j.nchan + i] = carr;
-                if (carr >= 0.0 && carr < 1.0 && std::fabs(d.f_carr * j.delt) < 0.5)     // else quantize_one reports it below
+                // carr == 1.0: a wrap of the block before rounded up to one (see block_patches); the reference goes on from it
+                if (carr >= 0.0 && carr <= 1.0 && std::fabs(d.f_carr * j.delt) < 0.5)    // else quantize_one reports it below
                     carr = carrier_after(carr, d.f_carr * j.delt, j.nsamp);
                 prev = d.prn;
             }
@@ -432,8 +433,12 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
             for (int i = 0; i < j.nchan; ++i) {
                 gpsiq_chan_t d = j.ch[(size_t) b * j.nchan + i];
                 gpsiq_qchan_t &qq = j.q[(size_t) b * j.nchan + i];
-                d.carr_phase = j.start[(size_t) b * j.nchan + i];
+                const double start = j.start[(size_t) b * j.nchan + i];
+                // a start of exactly 1.0 is phase 0 of the closed form (mod 1); block_patches walks the double from 1.0 and
+                // patches sample 0, where the reference indexes its table at 512
+                d.carr_phase = start == 1.0 ? 0.0 : start;
                 const int rc = quantize_one(d, j.delt, j.nsamp, nullptr, &qq, nullptr);
+                d.carr_phase = start;
                 if (rc != GPSIQ_OK) {
                     pthread_mutex_lock(&j.mu);
                     if (j.rc == GPSIQ_OK) { j.rc = rc; std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error()); }

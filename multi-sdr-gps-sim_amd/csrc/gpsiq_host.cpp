@@ -209,6 +209,8 @@ int quantize_one(const gpsiq_chan_t &ch, double delt, int nsamp, const uint64_t 
         return fail(GPSIQ_E_RANGE, "prn %d: code_phase %g outside [0,1023)", ch.prn, ch.code_phase);
     if (ch.iword < 0 || ch.iword >= GPSIQ_N_DWRD || ch.ibit < 0 || ch.ibit > 29 || ch.icode < 0 || ch.icode > 19)
         return fail(GPSIQ_E_RANGE, "prn %d: iword/ibit/icode = %d/%d/%d out of range", ch.prn, ch.iword, ch.ibit, ch.icode);
+    if (!(ch.gain > -kMaxGain && ch.gain < kMaxGain))       // also rejects NaN; the same bound gpsiq_set_descriptors applies
+        return fail(GPSIQ_E_RANGE, "prn %d: gain %g not finite or |gain| >= %g", ch.prn, ch.gain, kMaxGain);
 
     q->prn = (uint8_t) ch.prn;
     q->icode = (uint8_t) ch.icode;

@@ -41,6 +41,10 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
 // CPU, but at least `grain` items per thread).  Returns after all parts are done.
 void parallel_for(int n, int nthreads, int grain, void (*fn)(void *ctx, int begin, int end), void *ctx);
 
+// |gain| bound of every entry point that takes a gain: (int)(250*|gain|) of 16 channels must fit the 32-bit sums with
+// room to spare, and the LUT build converts table*gain to int.  (The reference's gains are below 2.)
+constexpr double kMaxGain = 4.0e6;
+
 // Kernel variants (gpsiq_launch's `variant`).
 enum Variant {
     kAuto = 0,      // fast when every resident descriptor allows it, else generic

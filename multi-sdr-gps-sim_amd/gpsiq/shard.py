@@ -39,12 +39,17 @@ def seed_own_shard(q, nsamp, rank, world, all_gather_bytes, history=None):
     r the blocks after those of rank r-1 of round m and after everything of round m-1): the carries of all
     earlier ranges, in timeline order; this call appends its round's.  The host side of round m+1 can then
     run while the GPUs are busy with round m."""
+    from .abi import QCHAN_DTYPE
+    if not (isinstance(q, np.ndarray) and q.dtype == QCHAN_DTYPE and q.flags.c_contiguous and q.flags.writeable):
+        # "in place" is the contract (a preallocated upload buffer keeps being seeded): a copy would silently leave the
+        # caller's rows self-seeded, i.e. a carrier phase step at every rank boundary
+        raise ValueError("seed_own_shard needs a writable C-contiguous QCHAN_DTYPE array (it seeds in place)")
     mine = shard_carry(q, nsamp)
     parts = all_gather_bytes(mine.tobytes())
     assert len(parts) == world
     now = [np.frombuffer(p, dtype=SHARD_CARRY_DTYPE) for p in parts]
     before = [] if history is None else history
-    seeded = shard_seed(np.ascontiguousarray(q), nsamp, np.stack(before + now), len(before) + rank)
+    seeded = shard_seed(q, nsamp, np.stack(before + now), len(before) + rank)
     if history is not None:
         history.extend(now)
     return seeded

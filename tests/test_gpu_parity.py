@@ -546,3 +546,29 @@ def test_descriptor_sets_swap_under_running_launches(ctx, oracle):
         assert np.array_equal(got[m], alone), m
         for b in (0, nb // 2 - 1, nb // 2, nb - 1):
             assert np.array_equal(got[m, b], oracle.block_fixed(sets[m][b], ns, SC08)), (m, b)
+
+
+def test_launches_of_one_set_on_two_streams_are_both_waited_for(ctx, oracle):
+    """a long launch on stream A, then a short one on stream B, then two new descriptor sets.  The second
+    gpsiq_set_descriptors reuses the buffer the first set lives in: it has to wait for A's launch too, not only for
+    the one recorded last (B's)."""
+    import torch
+    fs, ns, nb, nc = 2.6e6, 260000, 1536, 16
+    blk = 2 * ns
+    first = gpsiq.quantize_blocks(synth_blocks(nb, nc, seed=41), fs, ns)[0]
+    other = [gpsiq.quantize_blocks(synth_blocks(4, nc, seed=42 + k), fs, ns)[0] for k in range(2)]
+    out = torch.zeros(nb * blk, dtype=torch.uint8, device="cuda")
+    small = torch.zeros(2 * blk, dtype=torch.uint8, device="cuda")
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx.set_descriptors(first)
+    ctx.launch(0, nb, ns, SC08, out.data_ptr(), blk, stream=a.cuda_stream)            # ~1 ms of kernel
+    ctx.launch(0, 2, ns, SC08, small.data_ptr(), blk, stream=b.cuda_stream)           # a few microseconds
+    ctx.set_descriptors(other[0])          # the other buffer: no wait
+    ctx.set_descriptors(other[1])          # first's buffer: must not be overwritten under stream A's kernel
+    a.synchronize(); b.synchronize()
+    got = out.cpu().numpy().view(np.int8).reshape(nb, blk)
+    for blkno in (0, 1, nb // 2, nb - 2, nb - 1):
+        assert np.array_equal(got[blkno], oracle.block_fixed(first[blkno], ns, SC08)), blkno
+    ctx.set_descriptors(first)
+    alone = run_device(ctx, first, ns, SC08, "auto")
+    assert np.array_equal(got, alone)

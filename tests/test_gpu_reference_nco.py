@@ -161,6 +161,19 @@ def test_mode_switch_and_patch_validation(rctx):
     bad["block"], bad["lut"] = 0, 600
     with pytest.raises(gpsiq.GpsiqError):
         rctx.set_patches(bad)
+    # a slot counts the block's ACTIVE channels: with one of four channels unused, slot 3 does not exist
+    q2 = q.copy()
+    q2["prn"][1, 2] = 0
+    rctx.set_descriptors(q2)
+    bad["block"], bad["lut"], bad["slot"] = 1, 7, 3
+    with pytest.raises(gpsiq.GpsiqError):
+        rctx.set_patches(bad)
+    bad["slot"] = 2
+    rctx.set_patches(bad)
+    bad["block"] = 0
+    bad["slot"] = 3
+    rctx.set_patches(bad)
+    rctx.set_patches(bad[:0])
     with pytest.raises(gpsiq.GpsiqError):
         rctx.set_nco_mode(7)
     rctx.set_nco_mode(NCO_FIXED)

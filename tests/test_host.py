@@ -134,12 +134,37 @@ def test_shard_range_is_a_contiguous_balanced_partition(nblocks, world):
 
 @pytest.mark.parametrize("field,value", [("prn", 33), ("code_phase", 1023.0), ("code_phase", -0.5), ("carr_phase", 1.0),
                                          ("carr_phase", -0.1), ("iword", 60), ("ibit", 30), ("icode", 20),
-                                         ("f_carr", 2.0e6), ("f_code", 6.0e6), ("f_code", 0.0), ("f_carr", float("nan"))])
+                                         ("f_carr", 2.0e6), ("f_code", 6.0e6), ("f_code", 0.0), ("f_carr", float("nan")),
+                                         ("gain", float("nan")), ("gain", float("inf")), ("gain", -float("inf")),
+                                         ("gain", 1e300), ("gain", 4.0e6), ("gain", -4.0e6)])
 def test_quantiser_rejects_out_of_range(field, value):
     d = synth_blocks(1, 3, seed=2)[0]
     d[field][1] = value
     with pytest.raises(gpsiq.GpsiqError):
         gpsiq.quantize(d, 2.6e6, 1000)
+
+
+def test_quantiser_takes_gains_up_to_the_bound_and_every_entry_point_checks_it():
+    d = synth_blocks(2, 3, seed=2)
+    d["gain"][0, 1] = 3.9e6
+    d["gain"][1, 2] = -3.9e6
+    gpsiq.quantize(d[0], 2.6e6, 1000)
+    gpsiq.quantize_blocks(d, 2.6e6, 1000)
+    d["gain"][1, 0] = float("nan")
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.quantize_blocks(d, 2.6e6, 1000)
+    with pytest.raises(gpsiq.GpsiqError):
+        gpsiq.reference_blocks(d, 2.6e6, 1000)
+
+
+def test_seeding_a_shard_in_place_refuses_a_view_it_would_have_to_copy():
+    from gpsiq.shard import seed_own_shard
+    q, _ = gpsiq.quantize_blocks(synth_blocks(6, 4, seed=5), 2.6e6, 1000)
+    with pytest.raises(ValueError):
+        seed_own_shard(q[:, ::2], 1000, 0, 1, lambda b: [b])          # a strided view: not seeded in place
+    own = q[2:5]                                                      # a contiguous slice of a larger timeline is fine
+    before = own.copy()
+    assert seed_own_shard(own, 1000, 0, 1, lambda b: [b]) is own and np.array_equal(own, before)
 
 
 def test_quantiser_rejects_running_off_the_word_buffer():

@@ -111,3 +111,41 @@ def test_carrier_wrap_that_rounds_to_one(oracle):
     _, want = oracle.block_float(d[0], ns, fs, SC08)
     _, _, got = gpsiq.reference_blocks(d, fs, ns)
     assert got.tobytes() == want.tobytes()
+
+
+def test_a_block_that_starts_on_one(oracle):
+    """The wrap that rounds to exactly 1.0 as the LAST addition of a block: the reference simply goes on from 1.0 in
+    the next block (its sample 0 indexes the table at 512, where the library takes entry 511).  The chain accepts the
+    value -- handed back by the caller or met inside a batch -- quantises the block as phase 0 and patches sample 0."""
+    fs = 2.6e6
+    d = synth_blocks(1, 16, seed=9)
+    i = np.arange(16)
+    c = -(2.0 ** -(8.0 + i % 5))
+    d["f_carr"][0] = c * fs
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    d["carr_phase"][0] = np.nextafter(-c, 0.0)
+    assert ((d["carr_phase"][0] + c) + 1.0 == 1.0).all()
+    _, _, one = gpsiq.reference_blocks(d, fs, 1)                      # a block of one sample ends on the wrap
+    assert (one == 1.0).all()
+    # (a) the caller hands 1.0 back, as the drop-in binding does with chan[i].carr_phase
+    ns = 5000
+    d2 = synth_blocks(2, 16, seed=9)
+    d2["f_carr"][:] = d["f_carr"][0]
+    d2["f_code"] = 1.023e6 + d2["f_carr"] / 1540.0
+    d2["carr_phase"][0] = one
+    want, carr_want = float_chain(oracle, d2, fs, ns, SC16)
+    got, carr, patches = product_chain(oracle, d2, fs, ns, SC16)
+    first = patches[(patches["block"] == 0) & (patches["sample"] == 0)]
+    assert len(first) == 16 and (first["lut"] == 511).all()
+    # sample 0 of block 0 is the reference's out-of-table read: compare everything after it
+    assert np.array_equal(got[0, 2:], want[0, 2:]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(carr, carr_want)
+    # (b) the same value met inside a batch: blocks of one sample, the second one starts on 1.0
+    d3 = synth_blocks(3, 16, seed=9)
+    d3["f_carr"][:] = d["f_carr"][0]
+    d3["f_code"] = 1.023e6 + d3["f_carr"] / 1540.0
+    d3["carr_phase"][0] = d["carr_phase"][0]
+    q, patches, carr = gpsiq.reference_blocks(d3, fs, 1)
+    _, carr_want = float_chain(oracle, d3, fs, 1, SC16)
+    assert np.array_equal(carr, carr_want)
+    assert (q[1]["carr_phase"] == 0).all() and len(patches[(patches["block"] == 1) & (patches["lut"] == 511)]) == 16
