@@ -307,63 +307,125 @@ static void block_patches(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double
 // result -- so it has its own form of Nco::advance for the common case (a normal addend below 2^-5 cycle per sample,
 // no exact-tie binade): between two wraps the phase climbs (or, with a negative addend, descends) through the binades
 // from the addend's own to [0.5, 1).  The lowest five of them hold 1, 2, 4, 8, 16 steps: plain additions there cost
-// less than a table piece each (measured: 20 against 32 us per channel and block at 2.6 Msps, +-0.5..5 kHz); above
-// them one piece per binade as in Nco::advance, with the run length from the per-binade table.
-static double carrier_after(double x0, double c, long ns)
-{
+// less than a table piece each; above them one piece per binade as in Nco::advance, with the run length from the
+// per-binade table.  That is one carrier CYCLE, ~70 ns of dependent operations.
+//
+// On top of it, a map from wrap to wrap.  Right after a wrap the phase is a multiple of U = 2^-52 (positive addend:
+// y - 1.0 with y in [1, 2)) or 2^-53 (negative addend: y + 1.0 in [0.5, 1)).  Start the same cycle from x0 + d*U
+// instead of x0: as long as every RESULT of the cycle's additions stays inside the binade it had, every rounding
+// drops the same bits (d*U is an even multiple of every ulp involved -- all of them are <= 2^-53 -- so ties to even
+// fall the same way as well) and the whole cycle is the first one translated: same number of samples, final state
+// moved by d*U.  The cycle walk therefore also returns the range of d for which that holds (the distance of every
+// result to the edges of its binade, two units short on either side because a sum that crosses an edge is rounded on
+// the other grid), and the cycle becomes an entry {first state, last state, state increment, samples} of a small sorted
+// table.  As the start state sweeps the addend's width, every binade edge on the way is crossed one step earlier
+// exactly once, so the table has about as many entries as a cycle has binades (a dozen or two); a block of 260 000
+// samples at 2.6 kHz Doppler is 260 cycles, of which the first ~20 are walked and the rest are table look-ups on
+// integers.  The one rounding that is not translation invariant is the wrap itself when it is an exact tie (the kept
+// bit's parity moves with d): such a cycle is never entered into the table.  The addend changes with every block
+// (gps.c:2042), so the table lives for one call.
+namespace {
+
+struct CarrierWalk {
     struct Piece { int64_t dm, k, rem, kdm, span; };
-    const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
-    const int64_t ec = (int64_t) (bc >> 52), mc = (int64_t) ((bc & kMant) | (kMant + 1));
-    const bool neg = c < 0.0;
-    constexpr int kLow = 4;                               // binades ec .. ec + kLow: plain additions
-    bool general = ec > 1023 - 6 || ec < 1023 - 40 || !(x0 >= 0.0 && x0 < 1.0);
-    Piece T[64];
-    const int top = (int) (1022 - ec);                    // exponent difference of the binade [0.5, 1)
-    for (int s = kLow + 1; s <= top && !general; ++s) {
-        int64_t dm = mc >> s;                             // rnd(c / ulp) in ulps of the binade, see Nco::build_piece
-        const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
-        if (rem > half) ++dm;
-        else if (rem == half) general = true;             // ties to even depend on x's parity: the probing walk
-        Piece &p = T[s];
-        p.dm = dm;
-        p.span = neg ? ((int64_t) 1 << 52) - 2 : ((int64_t) 1 << 52) - 1;
-        p.k = p.span / dm; p.kdm = p.k * dm; p.rem = p.span - p.kdm;
-    }
-    if (general) {
-        Nco carr = {x0, c, 0, 0, 1};
-        carr.advance(ns);
-        return carr.x;
-    }
-    const double thr = from_bits((uint64_t) (ec + kLow + 1) << 52);   // first value the table handles; thr <= 0.5, |c| < thr / 16
-    const int64_t one52 = (int64_t) 1 << 52;
-    double x = x0;
-    long n = 0;
-    if (!neg) {
-        while (n < ns) {
-            while (x < thr) { x += c; if (++n == ns) return x; }      // cannot wrap: x + c < 0.5 + 2^-5
-            for (;;) {                                                // x in [thr, 1)
-                const uint64_t bx = bits_of(x);
-                const Piece &p = T[(int64_t) (bx >> 52) - ec];
-                const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1)), off = mx - one52;
-                int64_t run, moved;
-                if (off <= p.rem) { run = p.k; moved = p.kdm; }
-                else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
-                else { run = (p.span - off) / p.dm; moved = run * p.dm; }
-                if (run >= ns - n) return from_bits((bx & ~kMant) | ((uint64_t) (mx + (ns - n) * p.dm) & kMant));
-                x = from_bits((bx & ~kMant) | ((uint64_t) (mx + moved) & kMant));
-                n += run;
-                const double y = x + c;                               // leaves the binade, or wraps
-                ++n;
-                if (y >= 1.0) { x = y - 1.0; break; }
-                x = y;
-                if (n == ns) return x;
-            }
+    static constexpr int kLow = 4;                        // binades ec .. ec + kLow: plain additions
+    double  c = 0.0, thr = 0.0;
+    int64_t ec = 0;
+    bool    neg = false, general = true;
+    Piece   T[64];
+
+    // distance of the cycle's results to their binade edges, in units of the state grid U = 2^-unit_exp
+    struct Slack {
+        int64_t lo, hi;        // the cycle holds for start states x0 + d*U, lo <= d <= hi
+        int     top_exp;       // biased exponent of the binade whose ulp is U (1023 for U = 2^-52, 1022 for 2^-53)
+        bool    ok;
+        inline void note(double v)
+        {
+            const uint64_t b = bits_of(v);
+            const int e = (int) (b >> 52);                                        // sign bit set -> e >= 2048 -> sh < 0
+            const int sh = top_exp - e;                                           // U / ulp(v) = 2^sh
+            if (sh < 0 || sh > 62 || e == 0) { ok = false; return; }
+            const int64_t mx = (int64_t) ((b & kMant) | (kMant + 1));
+            const int64_t l = 2 - ((mx - ((int64_t) 1 << 52)) >> sh), h = ((((int64_t) 1 << 53) - mx) >> sh) - 2;
+            if (l > lo) lo = l;
+            if (h < hi) hi = h;
         }
-        return x;
+    };
+
+    void setup(double addend)
+    {
+        c = addend;
+        const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
+        ec = (int64_t) (bc >> 52);
+        const int64_t mc = (int64_t) ((bc & kMant) | (kMant + 1));
+        neg = c < 0.0;
+        general = ec > 1023 - 6 || ec < 1023 - 40;
+        const int top = (int) (1022 - ec);                // exponent difference of the binade [0.5, 1)
+        for (int s = kLow + 1; s <= top && !general; ++s) {
+            int64_t dm = mc >> s;                         // rnd(c / ulp) in ulps of the binade, see Nco::build_piece
+            const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
+            if (rem > half) ++dm;
+            else if (rem == half) general = true;         // ties to even depend on x's parity: the probing walk
+            Piece &p = T[s];
+            p.dm = dm;
+            p.span = neg ? ((int64_t) 1 << 52) - 2 : ((int64_t) 1 << 52) - 1;
+            p.k = p.span / dm; p.kdm = p.k * dm; p.rem = p.span - p.kdm;
+        }
+        if (!general) thr = from_bits((uint64_t) (ec + kLow + 1) << 52);   // first value the table handles; thr <= 0.5, |c| < thr / 16
     }
-    while (n < ns) {
+
+    // Positive addend: from x (sample n) up to the next wrap.  true: wrapped, x is the state after the wrap (sample n);
+    // false: sample ns was reached first, x is its state.
+    template <bool kNote>
+    inline bool climb(double &x, long &n, long ns, Slack *sl) const
+    {
+        constexpr int64_t one52 = (int64_t) 1 << 52;
+        while (x < thr) {                                             // cannot wrap: x + c < 0.5 + 2^-5
+            x += c;
+            if (kNote) sl->note(x);
+            if (++n == ns) return false;
+        }
+        for (;;) {                                                    // x in [thr, 1)
+            const uint64_t bx = bits_of(x);
+            const Piece &p = T[(int64_t) (bx >> 52) - ec];
+            const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1)), off = mx - one52;
+            int64_t run, moved;
+            if (off <= p.rem) { run = p.k; moved = p.kdm; }
+            else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
+            else { run = (p.span - off) / p.dm; moved = run * p.dm; }
+            if (run >= ns - n) { x = from_bits((bx & ~kMant) | ((uint64_t) (mx + (ns - n) * p.dm) & kMant)); n = ns; return false; }
+            x = from_bits((bx & ~kMant) | ((uint64_t) (mx + moved) & kMant));
+            n += run;
+            if (kNote && run) sl->note(x);
+            const double y = x + c;                                   // leaves the binade, or wraps
+            ++n;
+            if (y >= 1.0) {
+                if (kNote) {
+                    sl->note(y);
+                    const double bb = y - x, err = (x - (y - bb)) + (c - bb);     // the rounding error of x + c, exactly
+                    if (std::fabs(err) == 0x1p-53) sl->ok = false;                // a tie on the grid of [1, 2): see above
+                }
+                x = y - 1.0;
+                return true;
+            }
+            x = y;
+            if (kNote) sl->note(x);
+            if (n == ns) return false;
+        }
+    }
+
+    // Negative addend, the same downwards.
+    template <bool kNote>
+    inline bool descend(double &x, long &n, long ns, Slack *sl) const
+    {
+        constexpr int64_t one52 = (int64_t) 1 << 52;
         while (x >= thr) {
-            if (x >= 1.0) { x += c; if (++n == ns) return x; continue; }   // a wrap that rounded to exactly 1.0 (see block_patches)
+            if (x >= 1.0) {                                           // a wrap that rounded to exactly 1.0 (see block_patches)
+                if (kNote) sl->ok = false;
+                x += c;
+                if (++n == ns) return false;
+                continue;
+            }
             const uint64_t bx = bits_of(x);
             const Piece &p = T[(int64_t) (bx >> 52) - ec];
             const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1)), off = (2 * one52 - 1) - mx;
@@ -372,21 +434,128 @@ static double carrier_after(double x0, double c, long ns)
             else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
             else if (off > p.span) { run = 0; moved = 0; }            // on the binade's first value: the next sum is rounded underneath
             else { run = (p.span - off) / p.dm; moved = run * p.dm; }
-            if (run >= ns - n) return from_bits((bx & ~kMant) | ((uint64_t) (mx - (ns - n) * p.dm) & kMant));
+            if (run >= ns - n) { x = from_bits((bx & ~kMant) | ((uint64_t) (mx - (ns - n) * p.dm) & kMant)); n = ns; return false; }
             x = from_bits((bx & ~kMant) | ((uint64_t) (mx - moved) & kMant));
             n += run;
+            if (kNote && run) sl->note(x);
             x += c;                                                   // into the binade underneath; x >= thr > 16 |c|: still positive
-            if (++n == ns) return x;
+            if (kNote) sl->note(x);
+            if (++n == ns) return false;
         }
         for (;;) {                                                    // x < thr: plain additions until the sum turns negative
             const double y = x + c;
             ++n;
-            if (y < 0.0) { x = y + 1.0; break; }
+            if (y < 0.0) {
+                const double r = y + 1.0;
+                if (kNote) {
+                    sl->note(-y);                                     // y's own rounding depends on its binade
+                    const double bb = r - y, err = (y - (r - bb)) + (1.0 - bb);
+                    if (r >= 1.0 || std::fabs(err) == 0x1p-54) sl->ok = false;   // rounded up to 1.0, or a tie on the grid of [0.5, 1)
+                    else sl->note(r);
+                }
+                x = r;
+                return true;
+            }
             x = y;
-            if (n == ns) return x;
+            if (kNote) sl->note(x);
+            if (n == ns) return false;
         }
     }
-    return x;
+
+    // wrap-to-wrap table.  Entries are valid each on its own (overlaps are harmless) and are found through 1024 buckets
+    // over the range of post-wrap states: a bucket wholly inside an entry names it (one shift and two loads per cycle,
+    // no search: the states are as good as random, a binary search would mispredict at every level); the few buckets that
+    // straddle an edge fall back to a scan.
+    struct Entry { int64_t first, last, inc; long steps; };
+    static constexpr int kMaxEntries = 64, kBuckets = 1024;
+
+    double run(double x0, long ns) const
+    {
+        if (general || !(x0 >= 0.0 && x0 < 1.0) || ns <= 0) {
+            if (ns <= 0) return x0;
+            Nco carr = {x0, c, 0, 0, 1};
+            carr.advance(ns);
+            return carr.x;
+        }
+        double x = x0;
+        long n = 0;
+        // few cycles in the block: the table would never be read
+        static const bool no_map = std::getenv("GPSIQ_WALK_NOMAP") != nullptr;      // A/B knob: every cycle walked
+        const bool use_map = !no_map && std::fabs(c) * (double) ns > 24.0;
+        if (!use_map) {
+            while (n < ns && (neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr))) {}
+            return x;
+        }
+        if (!(neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr)) || n == ns) return x;      // to the first wrap
+        const double scale = neg ? 0x1p53 : 0x1p52, unit = neg ? 0x1p-53 : 0x1p-52;
+        const int64_t m_max = neg ? ((int64_t) 1 << 53) - 1 : ((int64_t) 1 << 52) - 1;
+        // post-wrap states: [0, c] (positive addend) or [1 + c, 1) (negative), W units wide
+        const int64_t W = (int64_t) (std::fabs(c) * scale) + 4;
+        const int64_t base = neg ? ((int64_t) 1 << 53) - W : 0;
+        int bshift = 0;
+        while ((W >> bshift) >= kBuckets) ++bshift;
+        Entry tab[kMaxEntries];
+        uint8_t bucket[kBuckets] = {};                                     // 0: no entry covers the whole bucket; else entry index + 1
+        int ntab = 0;
+        long min_steps = ns;                                          // shortest cycle seen
+        int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
+        for (;;) {
+            if (n >= ns) return (double) m * unit;
+            const int64_t rel = m - base;
+            const Entry *e = nullptr;
+            if (rel >= 0 && rel < W) {
+                const int id = bucket[rel >> bshift];
+                if (id) e = &tab[id - 1];
+                else
+                    for (int i = 0; i < ntab; ++i)
+                        if (tab[i].first <= m && m <= tab[i].last) { e = &tab[i]; break; }
+            }
+            if (e) {
+                if (e->steps > ns - n) break;                         // the block ends inside this cycle
+                m += e->inc; n += e->steps;
+                continue;
+            }
+            // not in the table (or 1.0, outside its domain): walk the cycle, noting how far the start state may move
+            x = (double) m * unit;
+            const bool memo = rel >= 0 && rel < W && ntab < kMaxEntries && (ntab == 0 || ns - n >= 2 * min_steps);
+            if (!memo) {
+                if (!(neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr))) return x;
+                m = (int64_t) (x * scale);
+                continue;
+            }
+            Slack sl = {-m, m_max - m, neg ? 1022 : 1023, true};     // the start state itself stays in [0, 1)
+            long ne = 0;
+            const bool wrapped = neg ? descend<true>(x, ne, ns - n, &sl) : climb<true>(x, ne, ns - n, &sl);
+            n += ne;
+            if (!wrapped) return x;                                   // the block ended inside this cycle
+            const int64_t m2 = (int64_t) (x * scale);
+            if (sl.ok && sl.lo <= 0 && sl.hi >= 0 && x < 1.0) {
+                Entry &t = tab[ntab++];
+                t.first = m + sl.lo; t.last = m + sl.hi; t.inc = m2 - m; t.steps = ne;
+                if (ne < min_steps) min_steps = ne;
+                // buckets wholly inside [first, last]
+                const int64_t f = t.first - base, l = t.last - base;
+                int64_t k0 = f <= 0 ? 0 : ((f - 1) >> bshift) + 1;    // first bucket starting at or after `first`
+                int64_t k1 = l >= W ? kBuckets - 1 : ((l + 1) >> bshift) - 1;  // last bucket ending at or before `last`
+                if (k1 > kBuckets - 1) k1 = kBuckets - 1;
+                for (int64_t k = k0; k <= k1; ++k) bucket[k] = (uint8_t) ntab;
+            }
+            m = m2;
+        }
+        // the last, partial cycle
+        x = (double) m * unit;
+        while (n < ns && (neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr))) {}
+        return x;
+    }
+};
+
+}  // namespace
+
+static double carrier_after(double x0, double c, long ns)
+{
+    CarrierWalk w;
+    w.setup(c);
+    return w.run(x0, ns);
 }
 
 int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,

@@ -190,6 +190,10 @@ int main(int argc, char **argv)
 
     gpsiq_ctx_t *gq = NULL;
     if (gpsiq_create(&gq, 0) != GPSIQ_OK) return die("create");
+    {   /* GPSIQ_NCO=reference: the reference's double accumulators, as in the binding of INTEGRATION.md section 2 */
+        const char *m = getenv("GPSIQ_NCO");
+        if (m && strcmp(m, "reference") == 0 && gpsiq_set_nco_mode(gq, GPSIQ_NCO_REFERENCE) != GPSIQ_OK) return die("nco mode");
+    }
     const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) ss;
     void *buf = gpsiq_host_alloc(blk_bytes * BLOCKS_PER_CALL);
     gpsiq_chan_t *desc = malloc(sizeof *desc * BLOCKS_PER_CALL * (size_t) nchan);

@@ -167,6 +167,17 @@ out:
     return rc;
 }
 
+/* The carrier accumulator alone: gps.c:2821-2826, nsamp times.  (For the tests of the product's wrap-to-wrap table.) */
+double oracle_carrier_chain(double carr_phase, double carr_inc, long nsamp)
+{
+    for (long n = 0; n < nsamp; n++) {
+        carr_phase += carr_inc;                                       /* gps.c:2821 */
+        if (carr_phase >= 1.0) carr_phase -= 1.0;                     /* gps.c:2823-2826 */
+        else if (carr_phase < 0.0) carr_phase += 1.0;
+    }
+    return carr_phase;
+}
+
 /* ------------------------------------------------------------------------- */
 /* include/gpsiq.h quantisation rules. */
 #define CARR_F GPSIQ_CARR_FRAC_BITS

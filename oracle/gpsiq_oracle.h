@@ -37,6 +37,8 @@ int  oracle_block_float(const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
  * exact integers (one piece per binade the phase passes through), built by real double additions
  * at the piece edges and integer jumps in between; every sample is then evaluated by piece
  * lookup.  Must equal oracle_block_float / the reference bit for bit, carr_phase_out included. */
+/* the carrier accumulator alone, gps.c:2821-2826 nsamp times */
+double oracle_carrier_chain(double carr_phase, double carr_inc, long nsamp);
 int  oracle_block_float_closed(const gpsiq_chan_t *ch, int nchan, int nsamp, double fs,
                                int sample_size, void *dst, double *carr_phase_out);
 

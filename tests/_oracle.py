@@ -39,6 +39,8 @@ class Oracle:
         L.oracle_block_fixed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_block_fixed_seq.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.oracle_block_fixed_range.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_int, C.c_void_p]
+        L.oracle_carrier_chain.argtypes = [C.c_double, C.c_double, C.c_long]
+        L.oracle_carrier_chain.restype = C.c_double
         L.oracle_chunk_plan.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
 
     def tables(self):
@@ -71,6 +73,10 @@ class Oracle:
         if rc:
             raise ValueError(rc)
         return out, carr
+
+    def carrier_chain(self, x0, inc, nsamp):
+        """carr_phase after nsamp passes of gps.c:2821-2826."""
+        return self.lib.oracle_carrier_chain(float(x0), float(inc), int(nsamp))
 
     def quantize(self, ch, fs, nsamp, carry_in=None):
         ch = np.ascontiguousarray(ch, dtype=CHAN_DTYPE)

@@ -75,3 +75,116 @@ def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout
     data = open(out, "rb").read()
     assert len(data) == expect, (len(data), expect)
     return data
+
+
+# ---- BASELINE config 4: the reference's own circle.csv -------------------------------------------------------
+CONFIG4 = os.path.join(ROOT, "tests", "golden", "config4_circle.npz")
+
+
+def write_motion_csv(path, xyz_mm):
+    """A user-motion file in the very format of the reference's circle.csv ('%5.1f,%.3f, %.3f, %.3f' per 0.1 s) from
+    positions in whole millimetres (the file holds three decimals): rows 0..2999 of the fixture written this way are
+    byte-identical to /root/reference/circle.csv (checked where the reference is present), so readUserMotion()
+    (gps.c:2253-2277) parses the same doubles."""
+    def dec(mm):
+        mm = int(mm)
+        return "%s%d.%03d" % ("-" if mm < 0 else "", abs(mm) // 1000, abs(mm) % 1000)
+    with open(path, "w") as f:
+        for k, (x, y, z) in enumerate(xyz_mm):
+            f.write("%5.1f,%s, %s, %s\n" % (k / 10.0, dec(x), dec(y), dec(z)))
+    return path
+
+
+def stream_blocks(args, workdir, out_name, blk_bytes, nblocks, env_extra=None, timeout=900, idles=False, on_block=None):
+    """Run a program that writes nblocks blocks of blk_bytes to `out_name` in workdir and hand every block to
+    on_block(index, bytes) as it arrives.  out_name is a named pipe: a 600 s run at 2.6 Msps int16 is 6.2 GB, which
+    never has to exist on a disk.  idles: the program does not exit by itself (the reference program sits in its key
+    loop after the run and keeps the last few KB in its stdio buffer): it gets SIGTERM once everything but that tail
+    has arrived, which makes it close the file (gps-sim.c:216-247).  Returns the number of blocks seen."""
+    import select
+    fifo = os.path.join(workdir, out_name)
+    if os.path.exists(fifo):
+        os.remove(fifo)
+    os.mkfifo(fifo)
+    fd = os.open(fifo, os.O_RDONLY | os.O_NONBLOCK)               # the reader first: the program's fopen() then never blocks
+    env = dict(os.environ, LINES="50", COLUMNS="160", TERM="xterm")
+    env.update(env_extra or {})
+    p = subprocess.Popen(args, cwd=workdir, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    expect = blk_bytes * nblocks
+    st = {"got": 0, "seen": 0}
+    pend = bytearray()
+
+    def take(chunk):
+        st["got"] += len(chunk)
+        pend.extend(chunk)
+        while len(pend) >= blk_bytes:
+            if on_block:
+                on_block(st["seen"], bytes(pend[:blk_bytes]))
+            st["seen"] += 1
+            del pend[:blk_bytes]
+
+    def read_some():
+        """bytes, b"" (no writer has the pipe open) or None (a writer has, nothing to read yet)"""
+        try:
+            return os.read(fd, 1 << 22)
+        except BlockingIOError:
+            return None
+
+    t0 = last_data = time.time()
+    termed = False
+    try:
+        while True:
+            if time.time() - t0 > timeout:
+                raise RuntimeError(f"{args[0]}: {st['got']} of {expect} bytes after {timeout} s")
+            select.select([fd], [], [], 0.25)
+            chunk = read_some()
+            if chunk:
+                take(chunk)
+                last_data = time.time()
+                continue
+            if p.poll() is not None:                                # the program is gone: whatever is left is in the pipe
+                while True:
+                    chunk = read_some()
+                    if not chunk:
+                        break
+                    take(chunk)
+                if st["got"] == 0:
+                    raise RuntimeError(f"{args[0]} exited with {p.returncode} without writing")
+                break
+            if chunk == b"":
+                time.sleep(0.02)                                    # not opened yet, or closed and about to exit
+            if idles and not termed and st["got"] >= expect - (1 << 16) and time.time() - last_data > 0.75:
+                p.send_signal(signal.SIGTERM)                       # main loop: signal_handler -> cleanup_and_exit
+                termed = True
+    finally:
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        os.close(fd)
+        os.remove(fifo)
+    got, seen = st["got"], st["seen"]
+    assert got == expect and not pend, (got, expect, len(pend))
+    return seen
+
+
+def program_block_digests(binary, workdir, motion, seconds, nblocks, iq16=True, fs=2600000, rinex=RINEX16, env_extra=None,
+                          keep=(), timeout=900):
+    """The reference program (patched or not) on a user-motion file: SHA-256 of every block of its iqdata.bin, and the
+    first 4096 elements of the blocks listed in `keep`."""
+    import hashlib
+    import numpy as np
+    sha, heads = [], {}
+    ss = 2 if iq16 else 1
+
+    def on_block(i, b):
+        sha.append(hashlib.sha256(b).hexdigest())
+        if i in keep:
+            heads[i] = np.frombuffer(b[:4096 * ss], dtype=np.int16 if iq16 else np.int8).copy()
+    args = [binary, "-e", rinex, "-m", motion, "-r", "iqfile", "-d", str(seconds), "--disable-almanac"] + (["--iq16"] if iq16 else [])
+    n = stream_blocks(args, workdir, "iqdata.bin", (fs // 10) * 2 * ss, nblocks, env_extra, timeout, idles=True, on_block=on_block)
+    assert n == nblocks
+    return sha, heads

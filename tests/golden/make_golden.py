@@ -281,8 +281,51 @@ def make_program_golden():
     np.savez_compressed(os.path.join(HERE, "program_static_30s.npz"), fs=FS, seconds=30, **sha)
 
 
+def make_config4_golden():
+    """BASELINE config 4 as written: the reference's own circle.csv (/root/reference/circle.csv, 3 000 rows; reader
+    gps.c:2253-2277), --iq16, 2.6 Msps, -d 600 -- which the reference clamps to the file (gps.c:2502-2504): 2 999
+    blocks -- and the same circle continued on its own period (24 pi s, fitted centre and axes) to 6 000 rows for a
+    real 600 s: 5 999 blocks.  Rendered by the reference program rebuilt at the BASELINE constants
+    (oracle/_ref/gps-sim-ref-2M6) on tests/golden/synth_static16.21n.  The fixture is data only: the positions in
+    whole millimetres, SHA-256 of every block, the first 4096 elements of a few blocks."""
+    import tempfile
+    from _program import program, program_block_digests, write_motion_csv
+    src = "/root/reference/circle.csv"
+    a = np.loadtxt(src, delimiter=",")
+    t, pos = a[:, 0], a[:, 1:]
+    mm = np.rint(pos * 1000.0).astype(np.int64)
+    # the circle's own parametrisation: centre + A cos(wt) + B sin(wt), w = -1/12 rad/s (period 24 pi s); linear fit
+    w = -1.0 / 12.0
+    G = np.stack([np.ones_like(t), np.cos(w * t), np.sin(w * t)], axis=1)
+    coef, *_ = np.linalg.lstsq(G, pos, rcond=None)
+    resid = np.abs(G @ coef - pos).max()
+    assert resid < 0.0007, resid                       # the file's three decimals
+    t2 = np.arange(3000, 6000) / 10.0
+    ext = np.stack([np.ones_like(t2), np.cos(w * t2), np.sin(w * t2)], axis=1) @ coef
+    mm_all = np.concatenate([mm, np.rint(ext * 1000.0).astype(np.int64)])
+    step = np.abs(np.diff(mm_all, axis=0)).max(axis=1)
+    assert step[2999] <= step[:2999].max() + 2, (step[2999], step[:2999].max())     # no jump at the seam
+    ref26 = program("gps-sim-ref-2M6")
+    assert ref26, "oracle/_ref/gps-sim-ref-2M6 missing (make -C oracle progs)"
+    keep = (0, 299, 300, 301, 2998, 2999, 3000, 5998)
+    with tempfile.TemporaryDirectory() as td:
+        csv = write_motion_csv(os.path.join(td, "circle.csv"), mm)
+        assert open(csv, "rb").read() == open(src, "rb").read()       # byte-identical to the reference's file
+        sha300, heads300 = program_block_digests(ref26, td, csv, 600, 2999, keep=keep)
+        csv6 = write_motion_csv(os.path.join(td, "circle6000.csv"), mm_all)
+        sha600, heads600 = program_block_digests(ref26, td, csv6, 600, 5999, keep=keep)
+    assert sha600[:2999] == sha300                     # the clamped run is the first half of the long one
+    assert all(np.array_equal(heads300[k], heads600[k]) for k in heads300)
+    np.savez_compressed(os.path.join(HERE, "config4_circle.npz"), fs=2600000, rows_reference=3000, xyz_mm=mm_all,
+                        sha16=np.array(sha600), head_blocks=np.array(sorted(heads600)),
+                        heads=np.stack([heads600[k] for k in sorted(heads600)]), fit_residual_m=resid)
+    print("config4_circle: 2999 / 5999 blocks, fit residual %.5f m" % resid, hashlib.sha256("".join(sha600).encode()).hexdigest())
+
+
 if __name__ == "__main__":
-    if "--program-only" in sys.argv:
+    if "--config4-only" in sys.argv:
+        make_config4_golden()
+    elif "--program-only" in sys.argv:
         make_program_golden()
     elif "--alloc-only" in sys.argv:
         make_alloc_golden()
@@ -303,3 +346,4 @@ if __name__ == "__main__":
         make_epochs_golden()
         make_alloc_golden()
         make_program_golden()
+        make_config4_golden()

@@ -149,3 +149,56 @@ def test_a_block_that_starts_on_one(oracle):
     _, carr_want = float_chain(oracle, d3, fs, 1, SC16)
     assert np.array_equal(carr, carr_want)
     assert (q[1]["carr_phase"] == 0).all() and len(patches[(patches["block"] == 1) & (patches["lut"] == 511)]) == 16
+
+
+def chain_case(oracle, fs, ns, f_carr, x0):
+    """gpsiq_reference_batch's carried phase for 16 channels at once against the plain loop of gps.c:2821-2826."""
+    d = synth_blocks(1, 16, seed=1)
+    d["f_carr"][0] = f_carr
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    d["carr_phase"][0] = x0
+    _, _, got = gpsiq.reference_blocks(d, fs, ns)
+    want = np.array([oracle.carrier_chain(x0[i], f_carr[i] * (1.0 / fs), ns) for i in range(16)])
+    assert got.tobytes() == want.tobytes(), (fs, ns, f_carr[got != want], x0[got != want])
+
+
+def test_wrap_to_wrap_table_against_the_plain_loop(oracle):
+    """The carrier chain's table of whole cycles (csrc/gpsiq_exact.cpp, CarrierWalk): blocks of hundreds of carrier
+    cycles, where all but the first dozen or two cycles are look-ups -- Doppler-sized addends of both signs, addends
+    that are short binary fractions (every rounding a tie or exact), start phases on and next to binade edges and on
+    the post-wrap grid, whole-run lengths at all four sample rates."""
+    rng = np.random.default_rng(2024)
+    cases = [(2.6e6, 260000), (3e6, 300000), (10e6, 1000000), (25e6, 2500000), (2.6e6, 259999), (2.6e6, 70001)]
+    for it in range(36):
+        fs, ns = cases[it % len(cases)]
+        mag = rng.uniform(300.0, 6500.0, 16)
+        if it % 6 == 4:
+            mag = rng.uniform(8000.0, 39000.0, 16)                    # up to 2^-6 cycle per sample at 2.6 Msps: the table's limit
+        f = mag * rng.choice([-1.0, 1.0], 16)
+        if it % 4 == 1:                                               # dyadic addends: c = k * 2^-j exactly
+            f[:8] = fs * rng.integers(1, 16, 8) * 2.0 ** -rng.integers(12, 26, 8) * rng.choice([-1.0, 1.0], 8)
+        if it % 4 == 3:                                               # addends one ulp either side of a dyadic one
+            c = rng.integers(1, 8, 8) * 2.0 ** -rng.integers(11, 20, 8) * rng.choice([-1.0, 1.0], 8)
+            f[8:] = np.nextafter(c, rng.choice([-1.0, 1.0], 8)) * fs
+        x0 = rng.uniform(0.0, 1.0, 16)
+        k = rng.integers(1, 30, 16)
+        x0 = np.where(rng.random(16) < 0.25, 2.0 ** -k.astype(np.float64) * (1.0 + rng.integers(-2, 3, 16) * 2.0 ** -52), x0)
+        x0 = np.where(rng.random(16) < 0.2, rng.integers(0, 2 ** 40, 16) * 2.0 ** -52, x0)          # the post-wrap grid itself
+        x0 = np.where(rng.random(16) < 0.1, 1.0 - rng.integers(1, 2 ** 40, 16) * 2.0 ** -53, x0)
+        chain_case(oracle, fs, ns, f, np.clip(x0, 0.0, np.nextafter(1.0, 0.0)))
+
+
+def test_wrap_to_wrap_table_chained_over_blocks(oracle):
+    """A run of blocks with the Doppler drifting from block to block, as a moving receiver has it: the phase handed from
+    block to block is the plain loop's, for every block."""
+    fs, ns, nb = 2.6e6, 260000, 12
+    rng = np.random.default_rng(5)
+    d = synth_blocks(nb, 16, seed=3)
+    f0 = rng.uniform(-5000.0, 5000.0, 16)
+    d["f_carr"] = f0[None, :] + np.cumsum(rng.uniform(-0.8, 0.8, (nb, 16)), axis=0)
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    _, _, got = gpsiq.reference_blocks(d, fs, ns)
+    x = d["carr_phase"][0].copy()
+    for b in range(nb):
+        x = np.array([oracle.carrier_chain(x[i], d["f_carr"][b, i] * (1.0 / fs), ns) for i in range(16)])
+    assert got.tobytes() == x.tobytes()
