@@ -184,6 +184,31 @@ def roofline_obj(alg_bytes, launch_ms, traffic=None):
             "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes)}
 
 
+def counters_obj(key, launch_ms):
+    """Counter-based fractions of the dominant kernel: rocprofv3 --pmc passes of this very command, committed under
+    profiles/ (scripts/gpu_prof.sh -> scripts/prof_summary.py -> profiles/pmc_counters.json), per launch, against the
+    launch duration measured live in this run.  Independent of the kernel's own instruction mix (unlike issue_roofline)."""
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    try:
+        c = json.load(open(path)).get(key)
+    except Exception:
+        c = None
+    if not c:
+        return None
+    valu_peak = 256 * 4 * 2.4e9 / 2.0                     # wave64 VALU instructions/s: 1024 SIMD-32s, 2 cycles each, 2.4 GHz
+    cu_cycles = c["GRBM_GUI_ACTIVE"] / 8.0                 # cycles the launch was resident, per XCD = per CU
+    out = {"source": c.get("source"), "collected_with": "rocprofv3 --pmc (SQ passes alone, no tracing), averages per launch of the dominant kernel",
+           "valu_wave_insts_per_launch": int(c["SQ_INSTS_VALU"]),
+           "valu_issue_frac": round(c["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / valu_peak, 4),
+           "valu_issue_peak": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 /s",
+           "lds_busy": round(c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cu_cycles), 4),
+           "lds_conflict_ratio": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4),
+           "lds_wave_insts_per_launch": int(c["SQ_INSTS_LDS"]),
+           "clock_ghz_under_load": round(cu_cycles / c["_avg_duration_ns_pmc_sq1"], 3),
+           "profiled_launch_ms": round(c["_avg_duration_ns_pmc_sq1"] * 1e-6, 4)}
+    return out
+
+
 class Scenario:
     """BASELINE config 1/2 geometry for the end-to-end leg: static receiver, synthetic RINEX v2 file with
     nchan satellites in view -> ephemeris -> the host chain of gpsiq/pipeline.py."""
@@ -431,8 +456,17 @@ def main():
             gc.enable()
             passes_s.append(round(tot_s, 5))
             if best_s is None or tot_s < best_s[0]:
-                best_s = (tot_s, max_over_ranks(host_busy, dist, device=xdev))
+                best_s = (tot_s, max_over_ranks(host_busy, dist, device=xdev), host_busy)
+        # which side every rank is bound by: its own host time per round (refresh + quantise + seed exchange, with the
+        # threads it was given) against its kernel time per round
+        mine = {"rank": rank, "host_ms_per_round": round(best_s[2] / R * 1e3, 3),
+                "kernel_ms_per_round": None if dry else round(launch_ms * nb_e / nblocks, 3),
+                "threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus()}
+        mine["bound"] = None if dry else ("host" if mine["host_ms_per_round"] > mine["kernel_ms_per_round"] else "kernel")
+        per_rank = [json.loads(b.decode()) for b in gather(json.dumps(mine).ljust(200).encode())]
         e2e["streamed"] = {"value": None if dry else round(R * nb_e * world * nsamp / best_s[0] / 1e6, 1), "unit": "Msamples/s",
+                           "per_rank": per_rank,
+                           "bound": None if dry else ("host" if any(r["bound"] == "host" for r in per_rank) else "kernel"),
                            "rounds": R, "blocks_per_gpu_per_round": nb_e, "seconds": round(best_s[0], 5), "seconds_each_pass": passes_s,
                            "x_realtime": None if dry else round(R * nb_e * world * 0.1 / best_s[0], 1),
                            "host_refresh_and_quantise_ms_per_round": round(best_s[1] / R * 1e3, 2), "seed_exchange": exchange,
@@ -472,6 +506,9 @@ def main():
                                    f"({B * 0.1:.0f} s of signal per GPU and step, {nblocks * stride / 2**30:.2f} GiB ring), time-sharded x{world}",
                        "fs_hz": fs, "channels": nchan, "sample_bytes": ss, "blocks_per_launch": nblocks, "launches_per_step": L,
                        "blocks_per_gpu_per_step": B, "samples_per_block": nsamp, "variant": args.variant,
+                       "nco_mode": "fixed (GPSIQ_NCO_FIXED: 59/56-bit closed form, bit-exact vs the oracle; the reference-identical "
+                                   "model is measured in `reference_nco`)",
+                       "host_threads_per_rank": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus(),
                        "preheat_launches": PREHEAT_LAUNCHES, "x_realtime": None if dry else round(value * 1e6 / fs, 1),
                        "host_quantise_own_shard_ms": round(t_q * 1e3, 1)},
             "end_to_end": e2e,
@@ -487,13 +524,21 @@ def main():
             #   plain-add kernels (all sums inside int16): 3 x 4.3 + 4.3 / 2 + 2 x 4.4 = 23.85 cycles
             #   packed kernels (larger gains):             3 x 4.3 + 2 x 2.5 + 2 x 4.4 = 26.7 cycles
             # peak = every SIMD of 256 CUs issuing only that core at the 2.4 GHz maximum clock.
-            out["issue_roofline"] = {"bound": "valu-issue", "unit": "Gchannel-samples/s", "core_cycles": core_cycles,
+            cnt = counters_obj(f"{int(fs)}_{nchan}_{ss}_{nblocks}", launch_ms)
+            if cnt:
+                out["counters"] = cnt
+            out["issue_roofline"] = {"bound": "valu-issue", "note": "vs the kernel's OWN instruction stream (how close it runs to the cost of its "
+                                     "seven-instruction core), not a statement that the stream is minimal: see `counters` for the "
+                                     "instruction-mix-independent fractions",
+                                     "unit": "Gchannel-samples/s", "core_cycles": core_cycles,
                                      "achieved": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / 1e9, 1),
                                      "peak": round(256 * 4 * 64 * 2.4e9 / core_cycles / 1e9, 1),
                                      "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / core_cycles), 4)}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if extra:
+            if "reference_nco" in extra:
+                out["reference_nco"] = extra.pop("reference_nco")
             out["extra"] = extra
         print(json.dumps(out), flush=True)
     if ctx is not None:
@@ -586,18 +631,61 @@ def extra_legs(ctx, ring, stream, args, first):
         dt = time.perf_counter() - t1
     ex["block_call_async"] = {"what": "gpsiq_generate_block_async, 50 blocks queued back to back into page-locked buffers + gpsiq_wait",
                               "us_per_block": round(dt / 50 * 1e6, 1), "x_realtime": round(0.1 * 50 / dt, 1)}
-    # GPSIQ_NCO_REFERENCE over a batch: bound by the serial carrier walk on the host
     ctx.set_nco_mode(NCO_REFERENCE)
-    nb_r = 1000
-    d_r = pat[np.arange(nb_r) % 64]
-    stride = (blk + 15) & ~15
-    ctx.generate_batch(d_r[:64], nsamp, fs, ss, device_ptr=ring.data_ptr())
-    t1 = time.perf_counter()
-    ctx.generate_batch(d_r, nsamp, fs, ss, device_ptr=ring.data_ptr())
-    dt = time.perf_counter() - t1
-    ex["reference_nco_batch"] = {"what": f"gpsiq_generate_batch, GPSIQ_NCO_REFERENCE, {nb_r} blocks -> device memory (host carrier walk + patches + kernel)",
-                                 "value": round(nb_r * nsamp / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / dt, 1),
-                                 "host_cpus": effective_cpus()}
+    carr = None
+    for rep in range(2):
+        t1 = time.perf_counter()
+        for k in range(50):
+            ch1 = d_h[k].copy()
+            if carr is not None:
+                ch1["carr_phase"] = carr
+            carr = ctx.generate_block_async(ch1, nsamp, fs, ss, many[k % 8].data_ptr())
+        ctx.wait()
+        dt = time.perf_counter() - t1
+    ex["block_call_async_reference_nco"] = {"what": "the same in GPSIQ_NCO_REFERENCE (the host walks block k+1's carrier while block k is rendered and copied)",
+                                            "us_per_block": round(dt / 50 * 1e6, 1), "x_realtime": round(0.1 * 50 / dt, 1)}
+    ctx.set_nco_mode(NCO_FIXED)
+    # GPSIQ_NCO_REFERENCE, the model whose output IS the reference's (T2 = 0): the batch call into device memory at the
+    # headline workload and at 25 Msps, each with the whole call (host carrier walk + candidates in pieces, the device
+    # rendering piece k under the walk of piece k+1), the host side alone (gpsiq_reference_batch) and the kernel alone
+    ctx.set_nco_mode(NCO_REFERENCE)
+    ref = {"nco_mode": "reference (GPSIQ_NCO_REFERENCE: the reference's double accumulators reproduced exactly; whole runs equal "
+                       "the reference program's file, tests/test_reference_program.py, tests/test_config4.py)",
+           "host_cpus": effective_cpus(), "legs": {}}
+    for label, fs_r, ss_r, nb_r in (("2M6_int8_16ch", args.fs, args.sample_size, 2000), ("25M_int16_16ch", 25e6, 2, 200)):
+        ns_r = int(round(fs_r / 10))
+        blk_r = 2 * ns_r * ss_r
+        nb_r = min(nb_r, ring_bytes // blk_r)
+        d_r = pat[np.arange(nb_r) % 64]
+        ctx.generate_batch(d_r[:64], ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
+        dt = float("inf")
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
+            dt = min(dt, time.perf_counter() - t1)
+        th = float("inf")
+        for _ in range(2):
+            t1 = time.perf_counter()
+            q_r, patches, _ = gpsiq.reference_blocks(d_r, fs_r, ns_r)
+            th = min(th, time.perf_counter() - t1)
+        ctx.set_descriptors(q_r)
+        ctx.set_patches(patches)
+        ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 3, stream=stream)
+        km = min(ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 5, stream=stream) for _ in range(2))
+        ref["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks, gpsiq_generate_batch -> device memory",
+                              "value": round(nb_r * ns_r / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / dt, 1),
+                              "call_ms": round(dt * 1e3, 3), "host_walk_and_candidates_ms": round(th * 1e3, 3),
+                              "kernel_and_patches_ms": round(km, 3), "patched_samples": int(len(patches)),
+                              "bound": "host carrier walk" if th * 1e3 > km else "kernel",
+                              "roofline": roofline_obj(nb_r * blk_r, dt * 1e3),
+                              "roofline_kernel_only": roofline_obj(nb_r * blk_r, km)}
+    ref["value"] = ref["legs"]["2M6_int8_16ch"]["value"]
+    ref["unit"] = "Msamples/s"
+    ref["roofline"] = ref["legs"]["2M6_int8_16ch"]["roofline"]
+    ref["what"] = ("whole gpsiq_generate_batch call (walk + candidates + upload + kernel + patches) at the headline workload; the walk is "
+                   "serial in time per channel (one host thread per channel), so this leg is host-bound at 2.6 Msps and approaches "
+                   "the kernel at 25 Msps, where a block is ten times the device work for the same walk")
+    ex["reference_nco"] = ref
     ctx.set_nco_mode(NCO_FIXED)
     # the batch call with a device destination from double-precision descriptors: host quantiser + upload + kernel
     nb_d = min(ring_bytes // stride, 4130)

@@ -116,9 +116,11 @@ typedef struct gpsiq_ctx gpsiq_ctx_t;
  * an independent function of its descriptor, so the time axis shards freely.  GPSIQ_NCO_REFERENCE: the
  * reference's own double accumulators (gps.c:2789-2792, 2821-2826), reproduced exactly: a whole run
  * equals the reference element for element and carr_phase is handed out as the reference's accumulator
- * leaves it.  Costs a serial walk of the carrier per channel on the host (a dozen integer steps per
- * carrier cycle, see csrc/gpsiq_exact.cpp); the device runs the same kernels plus a fix-up of the few
- * samples per 10^7 where the two models differ. */
+ * leaves it.  Costs a serial walk of the carrier per channel on the host (a table look-up per carrier cycle
+ * once the cycles of a block have been seen, a dozen integer steps for those that have not, see
+ * csrc/gpsiq_exact.cpp); the device runs the same kernels plus a fix-up of the few samples per 10^7 where
+ * the two models differ.  A batch is walked and rendered in pieces (GPSIQ_REF_CHUNK_BLOCKS, default 256 blocks):
+ * the device renders piece k under the walk of piece k+1. */
 #define GPSIQ_NCO_FIXED      0
 #define GPSIQ_NCO_REFERENCE  1
 
@@ -219,7 +221,8 @@ int gpsiq_generate_block(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, double *carr_phase_out);
 
-/* The same call without waiting for the device (GPSIQ_NCO_FIXED only): it returns once the descriptor upload, the
+/* The same call without waiting for the device (both NCO models; in GPSIQ_NCO_REFERENCE the host walks the block's
+ * carrier first, so the block's patches are queued with it): it returns once the descriptor upload, the
  * kernel and the copy into dst are queued; carr_phase_out is final on return (the host computes it), dst -- which
  * must be page-locked (gpsiq_host_alloc) -- is complete after gpsiq_wait().  Calls queue in order on the context's
  * stream, so a generator thread can prepare block k+1 (host model, fifo hand-off of block k-1) while block k is

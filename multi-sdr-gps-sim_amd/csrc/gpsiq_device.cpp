@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <ctime>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <vector>
 
@@ -44,17 +45,19 @@ struct gpsiq_ctx {
         Use            use[kUses];
         bool           in_use = false;
         std::vector<uint8_t> active_per_block;            // active channels of every resident block (patch validation)
+        // patches that go with this set (GPSIQ_NCO_REFERENCE): per buffer, so that the next set's list can be uploaded
+        // while launches of this one are still applying theirs
+        gpsiq_patch_t *d_patch = nullptr;
+        size_t         patch_cap = 0;
+        int            npatch = 0;
     } buf[2];
+    hipStream_t    up_stream = nullptr;  // descriptor / patch uploads: never behind a running kernel
     int            cur = 0;             // buf[cur] holds the resident set
     gpsiq_qchan_t *d_desc = nullptr;    // == buf[cur].d
     int            nblocks = 0, nchan = 0;
     uint64_t       max_code_step = 0;
     int            max_active = 0;      // most active channels in any resident block
     long           max_amplitude = 0;   // largest sum over a block's channels of (int)(250*|gain|): bound on |I|, |Q|
-    // patches that go with the resident descriptors (GPSIQ_NCO_REFERENCE)
-    gpsiq_patch_t *d_patch = nullptr;
-    size_t         patch_cap = 0;
-    int            npatch = 0;
     int            nco_mode = GPSIQ_NCO_FIXED;
     // scratch of the kernel variants that need some (segm: the sign masks of one launch)
     void          *d_scratch = nullptr;
@@ -67,6 +70,8 @@ struct gpsiq_ctx {
     // says its block has landed
     struct AsyncSlot {
         gpsiq_qchan_t *d = nullptr, *h = nullptr;
+        gpsiq_patch_t *d_patch = nullptr, *h_patch = nullptr;   // GPSIQ_NCO_REFERENCE: the block's patches, staged page-locked
+        size_t         patch_cap = 0;
         void          *out = nullptr;
         size_t         out_cap = 0;
         hipEvent_t     done = nullptr;
@@ -182,6 +187,7 @@ int gpsiq_create(gpsiq_ctx_t **out, int device)
     if (!h) { delete c; return fail(GPSIQ_E_NOMEM, "out of memory"); }
     build_device_tables(h);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->chunk_done[i], hipEventDisableTiming);
@@ -204,23 +210,26 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     (void) hipDeviceSynchronize();
     if (c->d_tab) (void) hipFree(c->d_tab);
     if (c->d_out) (void) hipFree(c->d_out);
-    if (c->d_patch) (void) hipFree(c->d_patch);
     if (c->d_scratch) (void) hipFree(c->d_scratch);
     for (auto &a : c->aslot) {
         if (a.d) (void) hipFree(a.d);
         if (a.h) (void) hipHostFree(a.h);
+        if (a.d_patch) (void) hipFree(a.d_patch);
+        if (a.h_patch) (void) hipHostFree(a.h_patch);
         if (a.out) (void) hipFree(a.out);
         if (a.done) (void) hipEventDestroy(a.done);
     }
     for (int i = 0; i < 2; ++i) {
         if (c->buf[i].d) (void) hipFree(c->buf[i].d);
         if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
+        if (c->buf[i].d_patch) (void) hipFree(c->buf[i].d_patch);
         for (auto &u : c->buf[i].use)
             if (u.ev) (void) hipEventDestroy(u.ev);
         if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
         if (c->copy_stream[i]) (void) hipStreamDestroy(c->copy_stream[i]);
     }
     if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->up_stream) (void) hipStreamDestroy(c->up_stream);
     delete c;
 }
 
@@ -304,9 +313,10 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     }
     if (n) {
         const double t1 = trace ? wall_ms() : 0.0;
-        // on the context's own (non-blocking) stream: overlaps whatever the caller's streams are doing
-        hipError_t e = hipMemcpyAsync(nb.d, nb.h, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        // on the context's upload stream (non-blocking, nothing else ever queued on it): overlaps whatever the caller's
+        // streams and the context's own kernels are doing
+        hipError_t e = hipMemcpyAsync(nb.d, nb.h, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->up_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->up_stream);
         if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "descriptor upload: %s", hipGetErrorString(e));
         if (trace)
             std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %.2f ms\n",
@@ -315,7 +325,7 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
     c->cur ^= 1;
     c->d_desc = nb.d;
     c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = pj.mx; c->max_active = pj.max_active; c->max_amplitude = pj.max_amp;
-    c->npatch = 0;
+    nb.npatch = 0;
     return GPSIQ_OK;
 }
 
@@ -323,27 +333,30 @@ int gpsiq_set_patches(gpsiq_ctx_t *c, const gpsiq_patch_t *patches, int n)
 {
     if (!c || (n > 0 && !patches) || n < 0) return fail(GPSIQ_E_ARG, "bad patch list");
     HIP_TRY(hipSetDevice(c->device));
-    c->npatch = 0;
-    if (n == 0) return GPSIQ_OK;
+    gpsiq_ctx::DescBuf &cb = c->buf[c->cur];
     for (int i = 0; i < n; ++i) {
         const gpsiq_patch_t &p = patches[i];
         // slot counts the block's ACTIVE channels (device order), not the caller's channel index
-        if ((int64_t) p.block >= c->nblocks || p.slot >= c->buf[c->cur].active_per_block[p.block] || p.lut > 511 || p.neg > 1)
+        if ((int64_t) p.block >= c->nblocks || p.slot >= cb.active_per_block[p.block] || p.lut > 511 || p.neg > 1)
             return fail(GPSIQ_E_RANGE, "patch %d (block %u, slot %u, lut %u) outside the resident descriptors", i, p.block, p.slot, p.lut);
         if (i && (patches[i - 1].block > p.block || (patches[i - 1].block == p.block && patches[i - 1].sample > p.sample)))
             return fail(GPSIQ_E_ARG, "patches not sorted by (block, sample) at %d", i);
     }
-    // the launches that may still read the previous list were issued on caller streams this context
-    // does not track beyond the descriptor events: wait for those
-    for (int i = 0; i < 2; ++i) { int wrc = wait_idle(c->buf[i]); if (wrc) return wrc; }
-    if ((size_t) n > c->patch_cap) {
-        if (c->d_patch) HIP_TRY(hipFree(c->d_patch));
-        c->d_patch = nullptr; c->patch_cap = 0;
-        HIP_TRY(hipMalloc((void **) &c->d_patch, (size_t) n * sizeof(gpsiq_patch_t)));
-        c->patch_cap = (size_t) n;
+    cb.npatch = 0;
+    if (n == 0) return GPSIQ_OK;                      // launches in flight took their count with them
+    // launches of THIS set may still be applying the list that is replaced (the other buffer's launches have their own)
+    { int wrc = wait_idle(cb); if (wrc) return wrc; }
+    if ((size_t) n > cb.patch_cap) {
+        if (cb.d_patch) HIP_TRY(hipFree(cb.d_patch));
+        cb.d_patch = nullptr; cb.patch_cap = 0;
+        const size_t cap = (size_t) n < 256 ? 256 : (size_t) n;
+        HIP_TRY(hipMalloc((void **) &cb.d_patch, cap * sizeof(gpsiq_patch_t)));
+        cb.patch_cap = cap;
     }
-    HIP_TRY(hipMemcpy(c->d_patch, patches, (size_t) n * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice));
-    c->npatch = n;
+    hipError_t e = hipMemcpyAsync(cb.d_patch, patches, (size_t) n * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice, c->up_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->up_stream);
+    if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "patch upload: %s", hipGetErrorString(e));
+    cb.npatch = n;
     return GPSIQ_OK;
 }
 
@@ -370,8 +383,9 @@ static int launch_on(gpsiq_ctx *c, int v, int block0, int nblocks, int nsamp, in
     }
     hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, s,
                                   c->max_active, c->max_amplitude, need ? c->d_scratch : nullptr);
-    if (e == hipSuccess && c->npatch)
-        e = launch_patches(c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, c->d_patch, c->npatch, s);
+    if (e == hipSuccess && c->buf[c->cur].npatch)
+        e = launch_patches(c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, c->buf[c->cur].d_patch,
+                           c->buf[c->cur].npatch, s);
     if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "launch: %s", hipGetErrorString(e));
     if (nblocks > 0 && nsamp > 0) return mark_use(c->buf[c->cur], s);
     return GPSIQ_OK;
@@ -454,17 +468,12 @@ static int d2h_chunk_blocks(size_t stride)
 }
 
 static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nblocks, int nchan,
-                                 int nsamp, int sample_size, void *dst, int dst_is_device,
-                                 const std::vector<gpsiq_patch_t> *patches = nullptr)
+                                 int nsamp, int sample_size, void *dst, int dst_is_device)
 {
     const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
     const size_t stride = (blk_bytes + 15) & ~(size_t) 15;
     int rc = gpsiq_set_descriptors(c, q, nblocks, nchan);
     if (rc) return rc;
-    if (patches && !patches->empty()) {
-        rc = gpsiq_set_patches(c, patches->data(), (int) patches->size());
-        if (rc) return rc;
-    }
     if (!nblocks || !nsamp) return GPSIQ_OK;
     if (dst_is_device && stride == blk_bytes && !((uintptr_t) dst & 3)) {
         rc = gpsiq_launch(c, 0, nblocks, nsamp, sample_size, dst, stride, c->stream, kAuto);
@@ -527,27 +536,113 @@ static int check_gen_args(const gpsiq_ctx *c, const void *ch, const void *dst, i
     return GPSIQ_OK;
 }
 
+// ---- GPSIQ_NCO_REFERENCE: walk and render in pieces ------------------------------------------
+// The carrier walk is serial in time on the host, the render is not: the timeline is cut into pieces of a few hundred
+// blocks, and while the device renders (and copies out) piece k the host walks piece k+1.  RefRender is the device side of
+// one context: begin() sizes the staging once, piece() queues descriptors + patches + kernel (+ the copy to the
+// destination) without waiting, finish() drains.  generate_reference drives one of them from the walking thread;
+// gpsiq_generate_batch_multi gives every device one, fed through a queue by the thread that walks the whole timeline.
+static int ref_chunk_blocks(int nblocks)
+{
+    int n = 256;                                              // ~1-4 ms of walking, 60-180 us of kernel at 2.6 Msps
+    if (const char *e = std::getenv("GPSIQ_REF_CHUNK_BLOCKS")) n = std::atoi(e);       // read per call: A/B in one process; <= 0: one piece
+    return n > 0 && n < nblocks ? n : nblocks;
+}
+
+struct RefRender {
+    gpsiq_ctx *c = nullptr;
+    int nchan = 0, nsamp = 0, ss = 0;
+    uint8_t *dst = nullptr;          // destination of the range's first block
+    bool dst_is_device = false, direct = false;
+    size_t blk_bytes = 0, stride = 0;
+    int k = 0;
+
+    int begin(gpsiq_ctx *ctx, int range_blocks, int nchan_, int nsamp_, int ss_, void *dst_, int dst_is_device_)
+    {
+        c = ctx; nchan = nchan_; nsamp = nsamp_; ss = ss_; dst = static_cast<uint8_t *>(dst_); dst_is_device = dst_is_device_ != 0; k = 0;
+        blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) ss;
+        stride = (blk_bytes + 15) & ~(size_t) 15;
+        direct = dst_is_device && stride == blk_bytes && !((uintptr_t) dst & 3);
+        HIP_TRY(hipSetDevice(c->device));
+        if (!direct && range_blocks && nsamp) return ensure_out(c, stride * (size_t) range_blocks);      // before anything is queued
+        return GPSIQ_OK;
+    }
+
+    // blocks [b0, b0 + nb) of the range: q and patches (block indices relative to b0) belong to this piece
+    int piece(const gpsiq_qchan_t *q, int b0, int nb, const std::vector<gpsiq_patch_t> &patches)
+    {
+        int rc = gpsiq_set_descriptors(c, q, nb, nchan);
+        if (rc) return rc;
+        if (!patches.empty()) {
+            rc = gpsiq_set_patches(c, patches.data(), (int) patches.size());
+            if (rc) return rc;
+        }
+        if (!nb || !nsamp) return GPSIQ_OK;
+        uint8_t *dev = direct ? dst + (size_t) b0 * blk_bytes : static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
+        rc = gpsiq_launch(c, 0, nb, nsamp, ss, dev, stride, c->stream, kAuto);
+        if (rc || direct) return rc;
+        hipStream_t cs = c->copy_stream[k & 1];
+        HIP_TRY(hipEventRecord(c->chunk_done[k & 1], c->stream));
+        HIP_TRY(hipStreamWaitEvent(cs, c->chunk_done[k & 1], 0));
+        const hipMemcpyKind kind = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (stride == blk_bytes)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t) b0 * blk_bytes, dev, blk_bytes * (size_t) nb, kind, cs));
+        else
+            HIP_TRY(hipMemcpy2DAsync(dst + (size_t) b0 * blk_bytes, blk_bytes, dev, stride, blk_bytes, (size_t) nb, kind, cs));
+        ++k;
+        return GPSIQ_OK;
+    }
+
+    // on every path, also after an error: nothing may still be writing the caller's buffer when the call returns
+    int finish()
+    {
+        if (!c) return GPSIQ_OK;
+        (void) hipSetDevice(c->device);
+        const hipError_t s0 = hipStreamSynchronize(c->copy_stream[0]);
+        const hipError_t s1 = hipStreamSynchronize(c->copy_stream[1]);
+        const hipError_t s2 = hipStreamSynchronize(c->stream);
+        if (s0 != hipSuccess || s1 != hipSuccess || s2 != hipSuccess)
+            return fail(GPSIQ_E_DEVICE, "reference NCO pieces: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1 != hipSuccess ? s1 : s2));
+        return GPSIQ_OK;
+    }
+};
+
 // GPSIQ_NCO_REFERENCE form of both drop-in calls: the carrier is the caller's double, walked exactly
 static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
                               int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
 {
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
+    double t_walk = 0.0;
+    size_t npatch = 0;
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     std::vector<gpsiq_patch_t> patches;
-    double carr_end[GPSIQ_MAX_CHAN];
-    int last_prn[GPSIQ_MAX_CHAN];
-    int rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), &patches, carr_end, last_prn);
-    if (rc) return rc;
-    const double t1 = trace ? wall_ms() : 0.0;
-    rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device, &patches);
-    if (rc) return rc;
+    double carr[GPSIQ_MAX_CHAN] = {};
+    int prn[GPSIQ_MAX_CHAN] = {};
+    RefRender r;
+    int rc = r.begin(c, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+    const int chunk = ref_chunk_blocks(nblocks);
+    for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK; b0 += chunk) {
+        const int nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+        const double tw = trace ? wall_ms() : 0.0;
+        patches.clear();
+        rc = reference_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, q.data() + (size_t) b0 * nchan, &patches, carr, prn,
+                                b0 ? carr : nullptr, b0 ? prn : nullptr);
+        if (trace) t_walk += wall_ms() - tw;
+        npatch += patches.size();
+        if (rc == GPSIQ_OK) rc = r.piece(q.data() + (size_t) b0 * nchan, b0, nb, patches);
+    }
+    char err[400] = "";
+    if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
+    const int frc = r.finish();
+    if (rc != GPSIQ_OK) return fail(rc, "%s", err);
+    if (frc != GPSIQ_OK) return frc;
     if (trace)
-        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks: carrier walk + candidates %.2f ms (%zu patches), device %.2f ms\n",
-                     nblocks, t1 - t0, patches.size(), wall_ms() - t1);
+        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in pieces of %d: carrier walk + candidates %.2f ms (%zu patches), whole call %.2f ms\n",
+                     nblocks, chunk, t_walk, npatch, wall_ms() - t0);
     if (carr_phase_out)
         for (int i = 0; i < nchan; ++i)
-            carr_phase_out[i] = last_prn[i] ? carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+            carr_phase_out[i] = prn[i] ? carr[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
     return GPSIQ_OK;
 }
 
@@ -585,15 +680,25 @@ int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan
     if (!dst) return fail(GPSIQ_E_ARG, "null argument");
     int rc = check_gen_args(c, ch, dst, 1, nchan, nsamp, fs, sample_size);
     if (rc) return rc;
-    if (c->nco_mode != GPSIQ_NCO_FIXED) return fail(GPSIQ_E_STATE, "the asynchronous block call serves the fixed-point NCO model only");
     HIP_TRY(hipSetDevice(c->device));
+    const bool reference = c->nco_mode == GPSIQ_NCO_REFERENCE;
     gpsiq_qchan_t q[GPSIQ_MAX_CHAN];
     uint64_t next[GPSIQ_MAX_CHAN] = {};
+    std::vector<gpsiq_patch_t> patches;
+    double carr_end[GPSIQ_MAX_CHAN] = {};
+    int last_prn[GPSIQ_MAX_CHAN] = {};
     const double delt = 1.0 / fs;
-    for (int i = 0; i < nchan; ++i) {
-        const bool cont = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
-        rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[i], &next[i]);
+    if (reference) {
+        // the carrier is the caller's double, walked exactly on the host: everything the device needs (start phases,
+        // patches) and the phase to hand out are known before anything is queued
+        rc = reference_timeline(ch, 1, nchan, delt, nsamp, q, &patches, carr_end, last_prn);
         if (rc) return rc;
+    } else {
+        for (int i = 0; i < nchan; ++i) {
+            const bool cont = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
+            rc = quantize_one(ch[i], delt, nsamp, cont ? &c->carry[i] : nullptr, &q[i], &next[i]);
+            if (rc) return rc;
+        }
     }
     gpsiq_ctx::AsyncSlot &a = c->aslot[c->anext];
     if (a.busy) { HIP_TRY(hipEventSynchronize(a.done)); a.busy = false; }     // the ring is full: wait for its oldest block
@@ -621,16 +726,34 @@ int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan
         HIP_TRY(hipMalloc(&a.out, stride ? stride : 16));
         a.out_cap = stride ? stride : 16;
     }
+    if (!patches.empty() && patches.size() > a.patch_cap) {      // the slot is idle here (its event was waited for above)
+        if (a.d_patch) HIP_TRY(hipFree(a.d_patch));
+        if (a.h_patch) HIP_TRY(hipHostFree(a.h_patch));
+        a.d_patch = a.h_patch = nullptr; a.patch_cap = 0;
+        const size_t cap = patches.size() < 256 ? 256 : patches.size();
+        HIP_TRY(hipMalloc((void **) &a.d_patch, cap * sizeof(gpsiq_patch_t)));
+        HIP_TRY(hipHostMalloc((void **) &a.h_patch, cap * sizeof(gpsiq_patch_t), hipHostMallocDefault));
+        a.patch_cap = cap;
+    }
     if (nsamp > 0) {
         const int v = max_step <= kRowsMaxCodeStep ? kSeg : max_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
         HIP_TRY(hipMemcpyAsync(a.d, a.h, (size_t) nchan * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(launch_variant(v, a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, c->stream, na, amp, nullptr));
+        if (!patches.empty()) {
+            std::memcpy(a.h_patch, patches.data(), patches.size() * sizeof(gpsiq_patch_t));
+            HIP_TRY(hipMemcpyAsync(a.d_patch, a.h_patch, patches.size() * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(launch_patches(a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, a.d_patch, (int) patches.size(), c->stream));
+        }
         HIP_TRY(hipMemcpyAsync(dst, a.out, blk_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(a.done, c->stream));
         a.busy = true;
         c->anext = (c->anext + 1) & 3;
     }
     for (int i = 0; i < nchan; ++i) {
+        if (reference) {
+            if (carr_phase_out) carr_phase_out[i] = last_prn[i] ? carr_end[i] : ch[i].carr_phase;
+            continue;
+        }
         c->carry_prn[i] = ch[i].prn > 0 ? ch[i].prn : 0;
         c->carry[i] = next[i];
         c->handed[i] = ch[i].prn > 0 ? carr_phase_to_double(next[i]) : 0.0;
@@ -706,16 +829,104 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
     if (rc) return rc;
     if (nblocks == 0) return GPSIQ_OK;
     gpsiq_ctx *c0 = ctx[0];
-    // the host side once, for the whole timeline
-    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
-    std::vector<gpsiq_patch_t> patches;
-    uint64_t carry[GPSIQ_MAX_CHAN] = {};
-    double carr_end[GPSIQ_MAX_CHAN] = {};
-    int prev_prn[GPSIQ_MAX_CHAN] = {};
     const bool reference = c0->nco_mode == GPSIQ_NCO_REFERENCE;
+    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
+    for (int i = 0; i < ndev; ++i) {
+        int b0 = 0, b1 = 0;
+        (void) gpsiq_shard_range(nblocks, i, ndev, &b0, &b1);
+        if (b1 > b0 && !host_dst && !dev_dst[i]) return fail(GPSIQ_E_ARG, "null destination for range %d", i);
+    }
+    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     if (reference) {
-        rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), &patches, carr_end, prev_prn);
-    } else {
+        // The walk is serial in time, the devices are not: the calling thread walks the timeline piece by piece and hands
+        // every piece to the device that owns it; device i starts as soon as the walk reaches its range, and renders
+        // under the walk of what follows.
+        struct Item { const gpsiq_qchan_t *q; int b0, nb; std::vector<gpsiq_patch_t> patches; };
+        struct Dev {
+            gpsiq_ctx *c; int range_blocks, nchan, nsamp, ss; void *dst; int dst_is_device;
+            pthread_mutex_t mu; pthread_cond_t cv; std::deque<Item> items; bool closed;
+            int rc; char err[256]; pthread_t th; bool started;
+        };
+        std::vector<Dev> devs((size_t) ndev);
+        auto body = [](void *arg) -> void * {
+            Dev &d = *static_cast<Dev *>(arg);
+            RefRender r;
+            d.rc = r.begin(d.c, d.range_blocks, d.nchan, d.nsamp, d.ss, d.dst, d.dst_is_device);
+            if (d.rc != GPSIQ_OK) std::snprintf(d.err, sizeof d.err, "%s", gpsiq_last_error());
+            for (;;) {
+                pthread_mutex_lock(&d.mu);
+                while (d.items.empty() && !d.closed) pthread_cond_wait(&d.cv, &d.mu);
+                if (d.items.empty()) { pthread_mutex_unlock(&d.mu); break; }
+                Item it = std::move(d.items.front());
+                d.items.pop_front();
+                pthread_mutex_unlock(&d.mu);
+                if (d.rc != GPSIQ_OK) continue;                       // after an error: take the rest off the queue, render nothing
+                d.rc = r.piece(it.q, it.b0, it.nb, it.patches);
+                if (d.rc != GPSIQ_OK) std::snprintf(d.err, sizeof d.err, "%s", gpsiq_last_error());
+            }
+            const int frc = r.finish();
+            if (d.rc == GPSIQ_OK && frc != GPSIQ_OK) { d.rc = frc; std::snprintf(d.err, sizeof d.err, "%s", gpsiq_last_error()); }
+            return nullptr;
+        };
+        for (int i = 0; i < ndev; ++i) {
+            int b0 = 0, b1 = 0;
+            (void) gpsiq_shard_range(nblocks, i, ndev, &b0, &b1);
+            Dev &d = devs[(size_t) i];
+            d.c = ctx[i]; d.range_blocks = b1 - b0; d.nchan = nchan; d.nsamp = nsamp; d.ss = sample_size;
+            d.dst = host_dst ? (void *) (static_cast<uint8_t *>(host_dst) + (size_t) b0 * blk_bytes) : dev_dst[i];
+            d.dst_is_device = host_dst ? 0 : 1;
+            pthread_mutex_init(&d.mu, nullptr); pthread_cond_init(&d.cv, nullptr);
+            d.closed = false; d.rc = GPSIQ_OK; d.err[0] = 0;
+            d.started = d.range_blocks > 0 && pthread_create(&d.th, nullptr, body, &d) == 0;
+        }
+        double carr[GPSIQ_MAX_CHAN] = {};
+        int prn[GPSIQ_MAX_CHAN] = {};
+        int wrc = GPSIQ_OK;
+        char werr[400] = "";
+        for (int i = 0; i < ndev; ++i) {
+            int r0 = 0, r1 = 0;
+            (void) gpsiq_shard_range(nblocks, i, ndev, &r0, &r1);
+            Dev &d = devs[(size_t) i];
+            const int chunk = ref_chunk_blocks(r1 - r0);
+            for (int b0 = r0; b0 < r1 && wrc == GPSIQ_OK; b0 += chunk) {
+                Item it;
+                it.nb = r1 - b0 < chunk ? r1 - b0 : chunk;
+                it.b0 = b0 - r0;
+                it.q = q.data() + (size_t) b0 * nchan;
+                wrc = reference_timeline(ch + (size_t) b0 * nchan, it.nb, nchan, 1.0 / fs, nsamp, q.data() + (size_t) b0 * nchan, &it.patches,
+                                         carr, prn, b0 ? carr : nullptr, b0 ? prn : nullptr);
+                if (wrc != GPSIQ_OK) { std::snprintf(werr, sizeof werr, "%s", gpsiq_last_error()); break; }
+                if (d.started) {
+                    pthread_mutex_lock(&d.mu);
+                    d.items.push_back(std::move(it));
+                    pthread_cond_signal(&d.cv);
+                    pthread_mutex_unlock(&d.mu);
+                } else {
+                    d.items.push_back(std::move(it));                 // no thread for this device: rendered below, after the walk
+                }
+            }
+            pthread_mutex_lock(&d.mu);
+            d.closed = true;
+            pthread_cond_signal(&d.cv);
+            pthread_mutex_unlock(&d.mu);
+        }
+        for (int i = 0; i < ndev; ++i) {
+            Dev &d = devs[(size_t) i];
+            if (d.started) pthread_join(d.th, nullptr);
+            else if (d.range_blocks > 0) body(&d);
+            pthread_mutex_destroy(&d.mu); pthread_cond_destroy(&d.cv);
+        }
+        if (wrc != GPSIQ_OK) return fail(wrc, "%s", werr);
+        for (int i = 0; i < ndev; ++i)
+            if (devs[(size_t) i].rc != GPSIQ_OK) return fail(devs[(size_t) i].rc, "device range %d: %s", i, devs[(size_t) i].err);
+        if (carr_phase_out)
+            for (int i = 0; i < nchan; ++i) carr_phase_out[i] = prn[i] ? carr[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+        return GPSIQ_OK;
+    }
+    // the fixed-point model: the host side once, for the whole timeline (threaded), then every device its range
+    uint64_t carry[GPSIQ_MAX_CHAN] = {};
+    int prev_prn[GPSIQ_MAX_CHAN] = {};
+    {
         bool cont0[GPSIQ_MAX_CHAN];
         for (int i = 0; i < nchan; ++i)
             cont0[i] = ch[i].prn > 0 && c0->carry_prn[i] == ch[i].prn && c0->handed[i] == ch[i].carr_phase;
@@ -723,10 +934,9 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
     }
     if (rc) return rc;
     // one host thread per context; each renders its own contiguous range
-    struct Part { gpsiq_ctx *c; const gpsiq_qchan_t *q; std::vector<gpsiq_patch_t> patches; int nb, nchan, nsamp, ss; void *dst; int dst_is_device;
+    struct Part { gpsiq_ctx *c; const gpsiq_qchan_t *q; int nb, nchan, nsamp, ss; void *dst; int dst_is_device;
                   int rc; char err[256]; pthread_t th; bool started; };
     std::vector<Part> parts((size_t) ndev);
-    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
     for (int i = 0; i < ndev; ++i) {
         int b0 = 0, b1 = 0;
         (void) gpsiq_shard_range(nblocks, i, ndev, &b0, &b1);
@@ -735,14 +945,11 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
         p.dst = host_dst ? (void *) (static_cast<uint8_t *>(host_dst) + (size_t) b0 * blk_bytes) : dev_dst[i];
         p.dst_is_device = host_dst ? 0 : 1;
         p.rc = GPSIQ_OK; p.err[0] = 0; p.started = false;
-        for (const gpsiq_patch_t &pt : patches)
-            if ((int) pt.block >= b0 && (int) pt.block < b1) { gpsiq_patch_t r = pt; r.block -= (uint32_t) b0; p.patches.push_back(r); }
-        if (p.nb > 0 && !p.dst) return fail(GPSIQ_E_ARG, "null destination for range %d", i);
     }
     auto body = [](void *arg) -> void * {
         Part &p = *static_cast<Part *>(arg);
         if (p.nb > 0) {
-            p.rc = run_to_host_or_device(p.c, p.q, p.nb, p.nchan, p.nsamp, p.ss, p.dst, p.dst_is_device, &p.patches);
+            p.rc = run_to_host_or_device(p.c, p.q, p.nb, p.nchan, p.nsamp, p.ss, p.dst, p.dst_is_device);
             if (p.rc != GPSIQ_OK) std::snprintf(p.err, sizeof p.err, "%s", gpsiq_last_error());
         }
         return nullptr;
@@ -757,14 +964,10 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
     for (int i = 0; i < ndev; ++i)
         if (parts[(size_t) i].rc != GPSIQ_OK) return fail(parts[(size_t) i].rc, "device range %d: %s", i, parts[(size_t) i].err);
     for (int i = 0; i < nchan; ++i) {
-        if (reference) {
-            if (carr_phase_out) carr_phase_out[i] = prev_prn[i] ? carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
-        } else {
-            c0->carry_prn[i] = prev_prn[i];
-            c0->carry[i] = carry[i];
-            c0->handed[i] = prev_prn[i] ? carr_phase_to_double(carry[i]) : 0.0;
-            if (carr_phase_out) carr_phase_out[i] = c0->handed[i];
-        }
+        c0->carry_prn[i] = prev_prn[i];
+        c0->carry[i] = carry[i];
+        c0->handed[i] = prev_prn[i] ? carr_phase_to_double(carry[i]) : 0.0;
+        if (carr_phase_out) carr_phase_out[i] = c0->handed[i];
     }
     return GPSIQ_OK;
 }

@@ -559,24 +559,27 @@ static double carrier_after(double x0, double c, long ns)
 }
 
 int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
-                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn)
+                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
+                       const double *carr_in, const int *prn_in)
 {
     // pass 1: the carrier chain, serial per channel (gps.c:2821 carries chan[i].carr_phase from block to
     // block; allocateChannel re-initialises it when the slot gets another satellite, gps.c:2208-2214)
     std::vector<double> start((size_t) nblocks * (size_t) nchan, 0.0);
-    struct CJob { const gpsiq_chan_t *ch; int nblocks, nchan, nsamp; double delt; double *start, *end; int *last; };
+    struct CJob { const gpsiq_chan_t *ch; int nblocks, nchan, nsamp; double delt; double *start, *end; int *last; const double *carr_in; const int *prn_in; };
     std::vector<double> end((size_t) nchan, 0.0);
     std::vector<int> last((size_t) nchan, 0);
-    CJob cj = {ch, nblocks, nchan, nsamp, delt, start.data(), end.data(), last.data()};
+    CJob cj = {ch, nblocks, nchan, nsamp, delt, start.data(), end.data(), last.data(), carr_in, prn_in};
     parallel_for(nchan, nchan, 1, [](void *p, int i0, int i1) {
         CJob &j = *static_cast<CJob *>(p);
         for (int i = i0; i < i1; ++i) {
-            double carr = 0.0;
-            int prev = 0;
+            // carr_in / prn_in: this timeline goes on where another call stopped (the pieces of one batch): the slot's
+            // accumulator and satellite after that call's last block
+            double carr = j.carr_in ? j.carr_in[i] : 0.0;
+            int prev = j.prn_in ? j.prn_in[i] : 0;
             for (int b = 0; b < j.nblocks; ++b) {
                 const gpsiq_chan_t &d = j.ch[(size_t) b * j.nchan + i];
                 if (d.prn <= 0) { prev = 0; carr = 0.0; continue; }
-                if (b == 0 || prev != d.prn) carr = d.carr_phase;
+                if ((b == 0 && !j.prn_in) || prev != d.prn) carr = d.carr_phase;
                 j.start[(size_t) b * j.nchan + i] = carr;
                 // carr == 1.0: a wrap of the block before rounded up to one (see block_patches); the reference goes on from it
                 if (carr >= 0.0 && carr <= 1.0 && std::fabs(d.f_carr * j.delt) < 0.5)    // else quantize_one reports it below
@@ -657,7 +660,7 @@ extern "C" int gpsiq_reference_batch(const gpsiq_chan_t *ch, int nblocks, int nc
     if (nsamp < 0 || !(fs > 0.0) || max_patches < 0 || !npatches || (max_patches && !patches))
         return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g / patch buffer", nsamp, fs);
     std::vector<gpsiq_patch_t> v;
-    int rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q, &v, carr_phase_out, nullptr);
+    int rc = reference_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, q, &v, carr_phase_out, nullptr, nullptr, nullptr);
     if (rc) return rc;
     *npatches = (int) v.size();
     if (v.size() > (size_t) max_patches)

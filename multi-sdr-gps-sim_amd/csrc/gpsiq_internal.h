@@ -34,8 +34,11 @@ int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double del
 // GPSIQ_NCO_REFERENCE (gpsiq_exact.cpp): quantise a timeline with every block seeded from the carrier
 // phase the reference's double accumulator holds at its start, and list the samples where the double
 // path differs from the closed form.  carr_end / last_prn (may be null): state after the last block.
+// carr_in / prn_in (both or neither; may be null): the accumulator and satellite of every slot after the block before
+// block 0, when this timeline continues one that an earlier call walked (block 0 then only re-seeds a slot whose PRN changed).
 int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
-                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn);
+                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
+                       const double *carr_in = nullptr, const int *prn_in = nullptr);
 
 // Run fn(ctx, begin, end) over [0, n) on up to nthreads host threads (<= 0: one per online
 // CPU, but at least `grain` items per thread).  Returns after all parts are done.

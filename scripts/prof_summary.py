@@ -72,3 +72,21 @@ if w is not None and f is not None:
     d[key + "_detail"] = {"WRITE_SIZE_KiB": w, "FETCH_SIZE_KiB_raw": f, "fetch_correction": "x2 (gfx950)", "source": f"profiles/{tag}_pmc_counters.txt"}
     json.dump(d, open(path, "w"), indent=1)
     print("traffic bytes/launch:", d[key])
+
+# SQ counters per launch of the dominant kernel for bench.py's `counters` object (valu_issue_frac, lds_busy,
+# lds_conflict_ratio): averages over the dispatches of the synth kernel, from the two SQ passes.
+sq = {}
+for sub in ("pmc_sq1", "pmc_sq2"):
+    for db in sorted(glob.glob(os.path.join(src, sub, "*.db"))):
+        for name, val, dur in q(db, "select counter_name, avg(value), avg(duration) from counters_collection "
+                                    "where kernel_name like '%synth_%' group by counter_name"):
+            sq[name] = val
+            sq.setdefault("_avg_duration_ns_" + sub, dur)
+if sq:
+    key = os.environ.get("PMC_KEY", "2600000_16_1_4130")
+    path = "profiles/pmc_counters.json"
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    sq["source"] = f"profiles/{tag}_pmc_counters.txt"
+    d[key] = sq
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    print("SQ counters per launch:", {k: v for k, v in sq.items() if not k.startswith("_")})

@@ -78,7 +78,7 @@ def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout
 
 
 # ---- BASELINE config 4: the reference's own circle.csv -------------------------------------------------------
-CONFIG4 = os.path.join(ROOT, "tests", "golden", "config4_circle.npz")
+CONFIG4 = os.path.join(ROOT, "tests", "golden", "program_config4_circle.npz")
 
 
 def write_motion_csv(path, xyz_mm):

@@ -316,7 +316,7 @@ def make_config4_golden():
         sha600, heads600 = program_block_digests(ref26, td, csv6, 600, 5999, keep=keep)
     assert sha600[:2999] == sha300                     # the clamped run is the first half of the long one
     assert all(np.array_equal(heads300[k], heads600[k]) for k in heads300)
-    np.savez_compressed(os.path.join(HERE, "config4_circle.npz"), fs=2600000, rows_reference=3000, xyz_mm=mm_all,
+    np.savez_compressed(os.path.join(HERE, "program_config4_circle.npz"), fs=2600000, rows_reference=3000, xyz_mm=mm_all,
                         sha16=np.array(sha600), head_blocks=np.array(sorted(heads600)),
                         heads=np.stack([heads600[k] for k in sorted(heads600)]), fit_residual_m=resid)
     print("config4_circle: 2999 / 5999 blocks, fit residual %.5f m" % resid, hashlib.sha256("".join(sha600).encode()).hexdigest())

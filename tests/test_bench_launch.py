@@ -43,3 +43,19 @@ def test_more_ranks_than_gpus_is_an_error():
     r = run(["--gpus", str(have + 7), "--steps", "1", "--no-cpu-baseline"])
     assert r.returncode == 3 and "visible" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_gpus_8_dry_run_is_one_line_from_eight_ranks():
+    """The pre-flight for the driver's 8-GPU run: 8 gloo ranks on this host's cores, one JSON line, n_gpus 8, every rank's
+    share of the host threads and its own host time per round reported."""
+    r = run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--blocks", "24", "--launches", "2", "--rounds", "3"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["scaling"] == "weak"
+    assert out["config"]["nco_mode"].startswith("fixed") and out["config"]["host_threads_per_rank"] >= 1
+    st = out["end_to_end"]["streamed"]
+    assert [p["rank"] for p in st["per_rank"]] == list(range(8))
+    assert all(p["host_ms_per_round"] > 0.0 and p["threads"] == out["config"]["host_threads_per_rank"] for p in st["per_rank"])
+    assert st["bound"] is None and all(p["kernel_ms_per_round"] is None for p in st["per_rank"])       # no device in a dry run

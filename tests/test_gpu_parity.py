@@ -515,10 +515,6 @@ def test_asynchronous_block_calls(ctx, oracle):
         for b in range(nb):
             got = bufs[b].numpy().view(np.int8 if ss == SC08 else np.int16)
             assert np.array_equal(got, want[b]), (ss, b)
-    ctx.set_nco_mode(1)
-    with pytest.raises(gpsiq.GpsiqError):
-        ctx.generate_block_async(d[0], ns, fs, SC08, bufs[0].data_ptr())
-    ctx.set_nco_mode(0)
 
 
 def test_descriptor_sets_swap_under_running_launches(ctx, oracle):

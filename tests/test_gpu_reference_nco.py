@@ -221,3 +221,84 @@ def float_run_ns(oracle, d, fs, ns, ss):
         out.append(o)
         prev = db["prn"].copy()
     return np.stack(out), carr
+
+
+def test_asynchronous_block_calls_reference_nco(rctx, oracle):
+    """gpsiq_generate_block_async in GPSIQ_NCO_REFERENCE: the host walks the block's carrier before anything
+    is queued, so the phase handed out is final at once and the block's patches ride along on the stream.  Blocks queued
+    back to back, more than the ring of four holds, a synchronous call in between: every buffer == the float loop, the
+    phase after every call == the loop's.  25 Msps: this scenario has patched samples."""
+    import torch
+    fs, nb, nc = 25e6, 7, 16
+    ns = int(fs) // 10
+    d = synth_blocks(nb, nc, seed=3032)
+    d["prn"][3:, 5] = 0
+    for ss in (SC16, SC08):
+        want, carr_want = float_run(oracle, d, fs, ss)
+        bufs = [torch.zeros(2 * ns * ss, dtype=torch.uint8).pin_memory() for _ in range(nb)]
+        carr, prev = None, None
+        for b in range(nb):
+            db = d[b].copy()
+            if b:
+                db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+            if b == 4:
+                out, carr = rctx.generate_block(db, ns, fs, ss)
+                bufs[b].numpy().view(out.dtype)[:] = out
+            else:
+                carr = rctx.generate_block_async(db, ns, fs, ss, bufs[b].data_ptr())
+            prev = db["prn"].copy()
+        rctx.wait()
+        for b in range(nb):
+            got = bufs[b].numpy().view(np.int8 if ss == SC08 else np.int16)
+            assert np.array_equal(got, want[b]), (ss, b)
+        act = d[-1]["prn"] > 0
+        assert np.array_equal(carr[act], carr_want[act])
+
+
+@pytest.mark.parametrize("pieces", ["1", "3", "0"])
+def test_batch_walked_and_rendered_in_pieces(rctx, oracle, monkeypatch, pieces):
+    """gpsiq_generate_batch in GPSIQ_NCO_REFERENCE walks the timeline in pieces and renders piece k under the walk of
+    piece k+1: whatever the piece length (1 block, 3 blocks, the whole batch), host or device destination, the result is
+    the float loop, every element, and the phase handed out is the loop's."""
+    import torch
+    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", pieces)
+    fs, nb, nc = 10e6, 8, 16
+    ns = int(fs) // 10
+    d = synth_blocks(nb, nc, seed=77)
+    d["prn"][3:, 1] = 0
+    d["prn"][5:, 1] = 21
+    d["carr_phase"][5:, 1] = 0.3125
+    for ss in (SC16, SC08):
+        want, carr_want = float_run(oracle, d, fs, ss)
+        carr = np.zeros(nc)
+        got = rctx.generate_batch(d, ns, fs, ss, carr_out=carr)
+        assert np.array_equal(got, want)
+        act = d[-1]["prn"] > 0
+        assert np.array_equal(carr[act], carr_want[act])
+        buf = torch.zeros(nb * 2 * ns * ss, dtype=torch.uint8, device="cuda")
+        rctx.generate_batch(d, ns, fs, ss, device_ptr=buf.data_ptr())
+        torch.cuda.synchronize()
+        dev = buf.cpu().numpy().view(np.int8 if ss == SC08 else np.int16).reshape(nb, 2 * ns)
+        assert np.array_equal(dev, got)
+
+
+def test_multi_device_reference_nco_in_pieces(oracle, monkeypatch):
+    """gpsiq_generate_batch_multi in GPSIQ_NCO_REFERENCE: one thread walks, every device renders its range piece by piece
+    as the walk reaches it (three contexts on the one GPU here) == the single-context batch == the float loop."""
+    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "2")
+    fs, nb, nc = 2.6e6, 13, 12
+    ns = int(fs) // 10
+    d = synth_blocks(nb, nc, seed=12)
+    d["prn"][6:, 3] = 0
+    ctxs = [gpsiq.Context(0) for _ in range(3)]
+    try:
+        ctxs[0].set_nco_mode(NCO_REFERENCE)
+        want, carr_want = float_run(oracle, d, fs, SC16)
+        carr = np.zeros(nc)
+        got = gpsiq.generate_batch_multi(ctxs, d, ns, fs, SC16, carr_out=carr)
+        assert np.array_equal(got, want)
+        act = d[-1]["prn"] > 0
+        assert np.array_equal(carr[act], carr_want[act])
+    finally:
+        for c in ctxs:
+            c.close()
