@@ -688,6 +688,7 @@ def extra_legs(ctx, ring, stream, args, first):
     ex["reference_nco"] = ref
     ctx.set_nco_mode(NCO_FIXED)
     # the batch call with a device destination from double-precision descriptors: host quantiser + upload + kernel
+    stride = (blk + 15) & ~15
     nb_d = min(ring_bytes // stride, 4130)
     d_d = pat[np.arange(nb_d) % 64]
     ctx.generate_batch(d_d, nsamp, fs, ss, device_ptr=ring.data_ptr())
@@ -720,14 +721,24 @@ def sweep_legs(ctx, ring, stream, args, q, nblocks, nsamp, ss, stride):
     pos = llh_to_ecef(*TOKYO_LLH)
     eph = synth_constellation(args.nchan, pos, SEC0, seed=3)
     xyz = circle_track(pos, 200000)
-    for nt in (1, 0):
-        trk = synth_tracks(args.nchan, WEEK, SEC0)
-        gpsiq.track_init(eph, synth_iono(), WEEK, SEC0, xyz[0], trk)
-        t1 = time.perf_counter()
-        gpsiq.refresh_batch(eph, synth_iono(), WEEK, SEC0, xyz[1:], trk, nthreads=nt)
-        dt = time.perf_counter() - t1
-        print(f"[refresh] gpsiq_refresh_batch {args.nchan} ch, {len(xyz) - 1} blocks, threads={'all' if nt == 0 else nt}: "
-              f"{(len(xyz) - 1) / dt / 1e3:.1f} kblocks/s = {(len(xyz) - 1) * 0.1 / dt:.0f}x real time", file=sys.stderr)
+    for nt, scalar in ((1, True), (1, False), (0, False)):
+        # scalar: one channel at a time (the round-2 form, GPSIQ_REFRESH_SCALAR); else the stages of the orbit / range /
+        # ionosphere chain looped over the block's channels, so that the libm calls of neighbouring channels overlap
+        if scalar:
+            os.environ["GPSIQ_REFRESH_SCALAR"] = "1"
+        else:
+            os.environ.pop("GPSIQ_REFRESH_SCALAR", None)
+        dt = float("inf")
+        for _ in range(2):
+            trk = synth_tracks(args.nchan, WEEK, SEC0)
+            gpsiq.track_init(eph, synth_iono(), WEEK, SEC0, xyz[0], trk)
+            t1 = time.perf_counter()
+            gpsiq.refresh_batch(eph, synth_iono(), WEEK, SEC0, xyz[1:], trk, nthreads=nt)
+            dt = min(dt, time.perf_counter() - t1)
+        print(f"[refresh] gpsiq_refresh_batch {args.nchan} ch, {len(xyz) - 1} blocks, threads={'all' if nt == 0 else nt}, "
+              f"{'one channel at a time' if scalar else 'channels staged together'}: "
+              f"{(len(xyz) - 1) / dt / 1e3:.1f} kblocks/s = {(len(xyz) - 1) * 0.1 / dt:.0f}x real time, "
+              f"{dt / (len(xyz) - 1) / args.nchan * 1e6:.3f} us per channel-block", file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 #include "gpsiq_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -229,6 +230,156 @@ Range range_to(const gpsiq_ephem_t &e, const gpsiq_iono_t &io, double sec, const
     return r;
 }
 
+// The same for all channels of one block at once, stage by stage.  Per channel the operations and their order are exactly
+// those of sv_state / range_to / iono_delay above (this file is built with -ffp-contract=off; nothing is reassociated), so
+// every double is bit-identical to the one-channel functions -- tests/test_refresh.py holds both against the reference's
+// lines.  The point is the dependency chain: one channel is ~25 libm calls of which each needs the one before (Kepler
+// iteration -> true anomaly -> argument of latitude -> ...), ~0.5 us of latency with the core mostly idle; with the
+// stages looped over up to 16 independent channels the out-of-order core overlaps the calls of neighbouring channels.
+constexpr int kLanes = GPSIQ_MAX_CHAN;
+
+void ranges_for_block(const gpsiq_ephem_t *eph, const int *ch, int n, const gpsiq_iono_t &io, double sec, const double *xyz,
+                      const Site &site, Range *out /* indexed by channel */)
+{
+    double tk[kLanes], mk[kLanes], ek[kLanes], ekold[kLanes], one_m_ecos[kLanes], so[kLanes], co[kLanes];
+    bool act[kLanes];
+    for (int k = 0; k < n; ++k) {
+        const gpsiq_ephem_t &e = eph[ch[k]];
+        double t = sec - e.toe_sec;
+        if (t > kSecHalfWeek) t -= kSecWeek;
+        else if (t < -kSecHalfWeek) t += kSecWeek;
+        tk[k] = t;
+        mk[k] = e.m0 + e.n * t;
+        ek[k] = mk[k]; ekold[k] = ek[k] + 1.0; one_m_ecos[k] = 0;
+        act[k] = true;
+    }
+    for (;;) {                                                       // Kepler: every channel stops on its own criterion
+        int live = 0;
+        for (int k = 0; k < n; ++k) {
+            act[k] = act[k] && std::fabs(ek[k] - ekold[k]) > 1.0E-14;
+            live += act[k];
+        }
+        if (!live) break;
+        for (int k = 0; k < n; ++k) if (act[k]) { ekold[k] = ek[k]; so[k] = sin_only(ekold[k]); }
+        for (int k = 0; k < n; ++k) if (act[k]) co[k] = cos_only(ekold[k]);
+        for (int k = 0; k < n; ++k)
+            if (act[k]) {
+                const gpsiq_ephem_t &e = eph[ch[k]];
+                one_m_ecos[k] = 1.0 - e.ecc * co[k];
+                ek[k] = ek[k] + (mk[k] - ekold[k] + e.ecc * so[k]) / one_m_ecos[k];
+            }
+    }
+    double sek[kLanes], cek[kLanes], pk[kLanes], s2pk[kLanes], c2pk[kLanes], uk[kLanes], suk[kLanes], cuk[kLanes];
+    double ik[kLanes], sik[kLanes], cik[kLanes], ok[kLanes], sok[kLanes], cok[kLanes];
+    // the last Newton step usually leaves ek where it was: sin and cos of the same argument are the loop's own
+    for (int k = 0; k < n; ++k) sek[k] = ek[k] == ekold[k] ? so[k] : sin_only(ek[k]);
+    for (int k = 0; k < n; ++k) cek[k] = ek[k] == ekold[k] ? co[k] : cos_only(ek[k]);
+    for (int k = 0; k < n; ++k) { const gpsiq_ephem_t &e = eph[ch[k]]; pk[k] = std::atan2(e.sq1e2 * sek[k], cek[k] - e.ecc) + e.aop; }
+    for (int k = 0; k < n; ++k) s2pk[k] = sin_only(2.0 * pk[k]);
+    for (int k = 0; k < n; ++k) c2pk[k] = cos_only(2.0 * pk[k]);
+    for (int k = 0; k < n; ++k) { const gpsiq_ephem_t &e = eph[ch[k]]; uk[k] = pk[k] + e.cus * s2pk[k] + e.cuc * c2pk[k]; }
+    for (int k = 0; k < n; ++k) suk[k] = sin_only(uk[k]);
+    for (int k = 0; k < n; ++k) cuk[k] = cos_only(uk[k]);
+    for (int k = 0; k < n; ++k) { const gpsiq_ephem_t &e = eph[ch[k]]; ik[k] = e.inc0 + e.idot * tk[k] + e.cic * c2pk[k] + e.cis * s2pk[k]; }
+    for (int k = 0; k < n; ++k) sik[k] = sin_only(ik[k]);
+    for (int k = 0; k < n; ++k) cik[k] = cos_only(ik[k]);
+    for (int k = 0; k < n; ++k) { const gpsiq_ephem_t &e = eph[ch[k]]; ok[k] = e.omg0 + tk[k] * e.omgkdot - kOmegaEarth * e.toe_sec; }
+    for (int k = 0; k < n; ++k) sok[k] = sin_only(ok[k]);
+    for (int k = 0; k < n; ++k) cok[k] = cos_only(ok[k]);
+
+    double los[kLanes][3], d[kLanes], prange[kLanes], az[kLanes], el[kLanes], neu2[kLanes], rho[kLanes];
+    for (int k = 0; k < n; ++k) {
+        const gpsiq_ephem_t &e = eph[ch[k]];
+        const double ekdot = e.n / one_m_ecos[k];
+        const double relativistic = -4.442807633E-10 * e.ecc * e.sqrta * sek[k];
+        const double pkdot = e.sq1e2 * ekdot / one_m_ecos[k];
+        const double ukdot = pkdot * (1.0 + 2.0 * (e.cus * c2pk[k] - e.cuc * s2pk[k]));
+        const double rk = e.A * one_m_ecos[k] + e.crc * c2pk[k] + e.crs * s2pk[k];
+        const double rkdot = e.A * e.ecc * sek[k] * ekdot + 2.0 * pkdot * (e.crs * c2pk[k] - e.crc * s2pk[k]);
+        const double ikdot = e.idot + 2.0 * pkdot * (e.cis * c2pk[k] - e.cic * s2pk[k]);
+        const double xpk = rk * cuk[k], ypk = rk * suk[k];
+        const double xpkdot = rkdot * cuk[k] - ypk * ukdot;
+        const double ypkdot = rkdot * suk[k] + xpk * ukdot;
+        double pos[3], vel[3];
+        pos[0] = xpk * cok[k] - ypk * cik[k] * sok[k];
+        pos[1] = xpk * sok[k] + ypk * cik[k] * cok[k];
+        pos[2] = ypk * sik[k];
+        const double tmp = ypkdot * cik[k] - ypk * sik[k] * ikdot;
+        vel[0] = -e.omgkdot * pos[1] + xpkdot * cok[k] - tmp * sok[k];
+        vel[1] = e.omgkdot * pos[0] + xpkdot * sok[k] + tmp * cok[k];
+        vel[2] = ypk * cik[k] * ikdot + ypkdot * sik[k];
+        double tc = sec - e.toc_sec;
+        if (tc > kSecHalfWeek) tc -= kSecWeek;
+        else if (tc < -kSecHalfWeek) tc += kSecWeek;
+        const double clk0 = e.af0 + tc * (e.af1 + tc * e.af2) + relativistic - e.tgd;
+        // range_to
+        double l0[3] = {pos[0] - xyz[0], pos[1] - xyz[1], pos[2] - xyz[2]};
+        const double tau = norm3(l0) / kC;
+        pos[0] -= vel[0] * tau;
+        pos[1] -= vel[1] * tau;
+        pos[2] -= vel[2] * tau;
+        const double xrot = pos[0] + pos[1] * kOmegaEarth * tau;
+        const double yrot = pos[1] - pos[0] * kOmegaEarth * tau;
+        pos[0] = xrot;
+        pos[1] = yrot;
+        los[k][0] = pos[0] - xyz[0]; los[k][1] = pos[1] - xyz[1]; los[k][2] = pos[2] - xyz[2];
+        d[k] = norm3(los[k]);
+        prange[k] = d[k] - kC * clk0;
+        double neu[3];
+        for (int m = 0; m < 3; ++m)
+            neu[m] = site.t[m][0] * los[k][0] + site.t[m][1] * los[k][1] + site.t[m][2] * los[k][2];
+        los[k][0] = neu[0]; los[k][1] = neu[1];                     // kept for the two atan2 stages
+        neu2[k] = neu[2];
+        rho[k] = std::sqrt(neu[0] * neu[0] + neu[1] * neu[1]);
+    }
+    for (int k = 0; k < n; ++k) { az[k] = std::atan2(los[k][1], los[k][0]); if (az[k] < 0.0) az[k] += (2.0 * kPi); }
+    for (int k = 0; k < n; ++k) el[k] = std::atan2(neu2[k], rho[k]);
+    // iono_delay
+    if (io.enable) {
+        const double phi_u = site.llh[0] / kPi, lam_u = site.llh[1] / kPi;
+        double F[kLanes];
+        for (int k = 0; k < n; ++k) F[k] = 1.0 + 16.0 * std::pow((0.53 - el[k] / kPi), 3.0);
+        if (!io.vflg) {
+            for (int k = 0; k < n; ++k) prange[k] += F[k] * 5.0e-9 * kC;
+        } else {
+            double saz[kLanes], caz[kLanes], phi_i[kLanes], psi[kLanes], cphi[kLanes], lam_i[kLanes], cl[kLanes];
+            for (int k = 0; k < n; ++k) saz[k] = sin_only(az[k]);
+            for (int k = 0; k < n; ++k) caz[k] = cos_only(az[k]);
+            for (int k = 0; k < n; ++k) {
+                psi[k] = 0.0137 / (el[k] / kPi + 0.11) - 0.022;
+                double p = phi_u + psi[k] * caz[k];
+                if (p > 0.416) p = 0.416;
+                else if (p < -0.416) p = -0.416;
+                phi_i[k] = p;
+            }
+            for (int k = 0; k < n; ++k) cphi[k] = cos_only(phi_i[k] * kPi);
+            for (int k = 0; k < n; ++k) lam_i[k] = lam_u + psi[k] * saz[k] / cphi[k];
+            for (int k = 0; k < n; ++k) cl[k] = cos_only((lam_i[k] - 1.617) * kPi);
+            for (int k = 0; k < n; ++k) {
+                const double phi_m = phi_i[k] + 0.064 * cl[k];
+                const double phi_m2 = phi_m * phi_m, phi_m3 = phi_m2 * phi_m;
+                double amp = io.alpha[0] + io.alpha[1] * phi_m + io.alpha[2] * phi_m2 + io.alpha[3] * phi_m3;
+                if (amp < 0.0) amp = 0.0;
+                double per = io.beta[0] + io.beta[1] * phi_m + io.beta[2] * phi_m2 + io.beta[3] * phi_m3;
+                if (per < 72000.0) per = 72000.0;
+                double t = kSecDay / 2.0 * lam_i[k] + sec;
+                while (t >= kSecDay) t -= kSecDay;
+                while (t < 0) t += kSecDay;
+                const double X = 2.0 * kPi * (t - 50400.0) / per;
+                if (std::fabs(X) < 1.57) {
+                    const double X2 = X * X, X4 = X2 * X2;
+                    prange[k] += F[k] * (5.0e-9 + amp * (1.0 - X2 / 2.0 + X4 / 24.0)) * kC;
+                } else {
+                    prange[k] += F[k] * 5.0e-9 * kC;
+                }
+            }
+        }
+    } else {
+        for (int k = 0; k < n; ++k) prange[k] += 0.0;
+    }
+    for (int k = 0; k < n; ++k) { Range &r = out[ch[k]]; r.prange = prange[k]; r.d = d[k]; r.az = az[k]; r.el = el[k]; }
+}
+
 struct Job {
     const gpsiq_ephem_t *eph; const gpsiq_iono_t *iono; const double *xyz; const GpsTime *t;
     int nchan, gain_x2; const gpsiq_track_t *trk; const double *ant_pat;
@@ -247,12 +398,24 @@ struct Job {
 void work(void *p, int b0, int b1)
 {
     const Job &j = *static_cast<const Job *>(p);
+    Site site = {};
+    int active[kLanes], nact = 0;
+    for (int c = 0; c < j.nchan; ++c)
+        if (j.trk[c].prn > 0) active[nact++] = c;
+    const bool scalar = std::getenv("GPSIQ_REFRESH_SCALAR") != nullptr;      // A/B knob (read per call): one channel at a time
     for (int b = b0; b < b1; ++b) {
         if (j.pass == 0) {                                   // ranges: independent per block
-            const Site site = site_from_ecef(j.xyz + 3 * (size_t) b);
-            for (int c = 0; c < j.nchan; ++c)
-                if (j.trk[c].prn > 0)
-                    j.rng[(size_t) (b + 1) * j.nchan + c] = range_to(j.eph[c], *j.iono, j.t[b + 1].sec, j.xyz + 3 * (size_t) b, site);
+            // a receiver that has not moved since the block before (every static scenario) keeps its geodetic position
+            // and rotation: same input, same output
+            const double *pos = j.xyz + 3 * (size_t) b;
+            if (b == b0 || pos[0] != pos[-3] || pos[1] != pos[-2] || pos[2] != pos[-1]) site = site_from_ecef(pos);
+            if (scalar) {
+                for (int c = 0; c < j.nchan; ++c)
+                    if (j.trk[c].prn > 0)
+                        j.rng[(size_t) (b + 1) * j.nchan + c] = range_to(j.eph[c], *j.iono, j.t[b + 1].sec, pos, site);
+            } else if (nact) {
+                ranges_for_block(j.eph, active, nact, *j.iono, j.t[b + 1].sec, pos, site, &j.rng[(size_t) (b + 1) * j.nchan]);
+            }
         } else {                                             // code phase, Doppler, gain
             int ep = 0;
             if (j.nepochs > 1) { while (ep + 1 < j.nepochs && j.first[ep + 1] <= b) ++ep; }
