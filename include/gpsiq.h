@@ -26,6 +26,22 @@
  *   almanac.c:73-184 almanac_read_file (SEM)             -> gpsiq_almanac_read_sem()
  *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
  *
+ * WHAT A MAINTAINER OF THE REFERENCE HAS TO READ.  The drop-in boundary is fifteen functions:
+ *   gpsiq_create / gpsiq_destroy / gpsiq_set_nco_mode / gpsiq_last_error            the context
+ *   gpsiq_generate_block (+ _async / gpsiq_wait)                                    gps.c:2767-2846, one call per 0.1 s block
+ *   gpsiq_generate_batch / gpsiq_generate_batch_multi                               the same loop run ahead, one or several GPUs
+ *   gpsiq_chunker_init / _push / _reserve / _commit                                 gps.c:2847-2865, the fifo hand-off
+ *   gpsiq_host_alloc / gpsiq_host_free                                              page-locked fifo buffers
+ * with gpsiq_chan_t as the only input type.  Sections below marked [boundary] are those.  Everything else is one of
+ *   [sharding]     the resident-descriptor path and the time-axis sharding recipe: multi-GPU hosts, bench.py;
+ *   [next rows]    SURVEY.md 8f rows 1-4 (batched host refresh, navigation words, RINEX readers), each bit-identical to the
+ *                  reference lines it restates -- for run-ahead hosts that do not keep the reference's C host model;
+ *   [convenience]  restatements of reference host/CLI pieces OUTSIDE section 8 (SEM almanac reader, -T time overwrite, date
+ *                  conversion, receiver-position inputs, tangent-frame move).  They exist so that host/gpsiq_runahead.c can
+ *                  take the reference's own inputs; they are NOT part of the drop-in boundary, a port of the reference does
+ *                  not need them (its own C host code stays), and the set is frozen: nothing further of the reference's
+ *                  host model or command line will be added here.
+ *
  * NCO definition ("identical fixed-point NCO word widths", BASELINE.json north_star).
  * The reference advances both NCOs with sequential double additions (gps.h:17
  * FLOAT_CARR_PHASE; gps.c:2789, 2821).  libgpsiq and its CPU oracle evaluate the
@@ -134,7 +150,7 @@ typedef struct gpsiq_patch {
     uint16_t lut;     /* iTable, gps.c:2775 */
 } gpsiq_patch_t;
 
-/* ---- library / tables (no device needed) -------------------------------- */
+/* ---- [boundary] library / tables (no device needed) ----------------------- */
 const char *gpsiq_version(void);
 /* last error text of the calling thread ("" if none) */
 const char *gpsiq_last_error(void);
@@ -143,7 +159,8 @@ int gpsiq_prn_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN]);
 /* carrier LUTs; replace cosTable512 / sinTable512 gps.c:145-213 */
 void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512[512]);
 
-/* Quantise nchan descriptors for a block of nsamp samples at fs Hz.
+/* ---- [sharding] the quantiser on its own -------------------------------------
+ * Quantise nchan descriptors for a block of nsamp samples at fs Hz.
  * delt = 1.0/fs as in gps.c:2298; steps are rint(f*delt*2^F).
  * carry_in: if non-NULL, carry_in[i] replaces the phase derived from ch[i].carr_phase.
  * carry_out: if non-NULL, receives the exact carrier phase after nsamp samples
@@ -199,7 +216,7 @@ int gpsiq_shard_carry(const gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp,
 int gpsiq_shard_seed(gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp,
                      const gpsiq_shard_carry_t *all /* [world][nchan], rank-major */, int rank);
 
-/* ---- device context ------------------------------------------------------ */
+/* ---- [boundary] device context and the drop-in calls ------------------------ */
 /* device = HIP device ordinal.  Fails (GPSIQ_E_DEVICE) when no GPU is present:
  * there is no CPU fallback in this library. */
 int  gpsiq_create(gpsiq_ctx_t **ctx, int device);
@@ -269,7 +286,7 @@ int gpsiq_generate_quantized(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nbloc
 void *gpsiq_host_alloc(size_t bytes);
 void  gpsiq_host_free(void *p);
 
-/* ---- resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
+/* ---- [sharding] resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
 /* Copy nblocks*nchan quantised descriptors ([nblocks][nchan]) to the device. */
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
 /* Patches that go with the resident descriptors (gpsiq_reference_batch); every later gpsiq_launch
@@ -297,7 +314,7 @@ int gpsiq_time_launches(gpsiq_ctx_t *ctx, int block0, int nblocks, int nsamp, in
 int         gpsiq_num_variants(void);
 const char *gpsiq_variant_name(int variant);
 
-/* ---- per-block host refresh, batched ----------- */
+/* ---- [next rows] per-block host refresh, batched ----------- */
 /* What the reference does on the host just before every pass of the sample loop
  * (gps.c:2731-2765: computeRange -> computeCodePhase -> gain), for many 0.1 s blocks at
  * once.  Plain double-precision C on the host, same operation order as the reference, so
@@ -338,7 +355,7 @@ int gpsiq_track_init(const gpsiq_ephem_t *eph, const gpsiq_iono_t *iono, int wee
 int gpsiq_sat_visibility(const gpsiq_ephem_t *eph, int week, double sec, const double xyz[3],
                          double elv_mask_deg, double azel[2]);
 
-/* Where the receiver is: the two inputs gps_thread_ep() turns into its xyz[] array before the block loop.
+/* [convenience] Where the receiver is: the two inputs gps_thread_ep() turns into its xyz[] array before the block loop.
  * gpsiq_llh_to_ecef = llh2xyz() (gps.c:412-447) for the static position `-l lat,lon,h` (gps.c:2480-2490 converts the
  * degrees to radians first): llh = latitude and longitude in RADIANS, height in metres.  gpsiq_ecef_to_llh = xyz2llh()
  * (gps.c:361-410).  gpsiq_motion_read_csv = readUserMotion() (gps.c:2253-2277): a text file with one line
@@ -382,7 +399,7 @@ int gpsiq_refresh_epochs_quantized(const gpsiq_ephem_t *eph, const gpsiq_iono_t 
                                    gpsiq_track_t *trk_epochs /* [nepochs][nchan] */, const int *first_block /* [nepochs] */,
                                    int nepochs, double fs, int nsamp, gpsiq_qchan_t *out, int nthreads);
 
-/* ---- navigation message words ------------------- */
+/* ---- [next rows] navigation message words ------------------- */
 /* The 60-word rolling buffer dwrd[] the sample loop reads its data bits from
  * (gps.c:2811) is built by the reference from the broadcast ephemeris: eph2sbf()
  * (gps.c:617-884) packs 3 + 2*25 subframe pages, generateNavMsg() (gps.c:2066-2140) inserts
@@ -422,7 +439,7 @@ uint32_t gpsiq_nav_parity(uint32_t source, int nib);
 int gpsiq_nav_subframes(const gpsiq_nav_eph_t *eph, const gpsiq_nav_utc_t *utc,
                         const gpsiq_nav_alm_sv_t *alm,
                         uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF]);
-/* almanac_read_file() (almanac.c:73-184): a SEM almanac file -> the 32 entries gpsiq_nav_subframes() takes, indexed by
+/* [convenience] almanac_read_file() (almanac.c:73-184): a SEM almanac file -> the 32 entries gpsiq_nav_subframes() takes, indexed by
  * PRN - 1.  The reference's rules are kept: ids 0 / > 32 are clamped to 1 / 32, at most 32 records are read whatever the
  * header announces, the week gets + 2048 (the reference's roll-over constant), a file that ends early keeps the records
  * read so far (the last one possibly half filled and not valid), any other damage drops them all.
@@ -437,7 +454,7 @@ int gpsiq_nav_message(const uint32_t sbf[GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], in
  * channels): sbf is [nchan][GPSIQ_N_SBF_PAGE][GPSIQ_N_DWRD_SBF], st[nchan]. */
 int gpsiq_nav_roll(const uint32_t *sbf, int nchan, int week, double sec, gpsiq_nav_state_t *st);
 
-/* ---- RINEX navigation files ---------------------- */
+/* ---- [next rows] RINEX navigation files ---------------------- */
 /* readRinex2() (gps.c:1131-1505) / readRinex3() (gps.c:1512-1891): fixed-column parse of a
  * GPS broadcast-ephemeris file (plain or gzip), records grouped into sets whenever the time
  * of clock advances by more than an hour, at most GPSIQ_EPHEM_SETS sets of 32 satellites. */
@@ -462,18 +479,18 @@ int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsi
 /* The set gps_thread_ep() would use for a start time (gps.c:2588-2608): first set with a
  * satellite whose toc is within one hour of (week, sec); -1 if none. */
 int gpsiq_rinex_select(const gpsiq_rinex_eph_t *eph, int nsets, int week, double sec);
-/* The reference's -T option (gps.c:2534-2561): move the times of clock and of ephemeris of every valid record, and its
+/* [convenience] The reference's -T option (gps.c:2534-2561): move the times of clock and of ephemeris of every valid record, and its
  * calendar time, by the distance from the first set's first time of clock (gps.c:2507-2513) to the start time cut to
  * whole two hours, and set the UTC reference (wnt, tot) to that cut time: an old broadcast file then serves any start
  * time.  eph is [nsets][GPSIQ_MAX_SAT] as gpsiq_rinex_read() filled it. */
 int gpsiq_rinex_overwrite_time(gpsiq_rinex_eph_t *eph, int nsets, gpsiq_nav_utc_t *utc, int week, double sec);
-/* date2gps() / gps2date() (gps.c:315-355): a calendar date and time of day <-> GPS week and seconds of the week, as the
+/* [convenience] date2gps() / gps2date() (gps.c:315-355): a calendar date and time of day <-> GPS week and seconds of the week, as the
  * reference converts its -t start time and RINEX epochs (no leap seconds either way; months outside 1..12 count as
  * January where the reference indexes past its table). */
 void gpsiq_date_to_gps(int year, int month, int day, int hour, int minute, double second, int *week, double *sec);
 void gpsiq_gps_to_date(int week, double sec, int *year, int *month, int *day, int *hour, int *minute, double *second);
 
-/* ---- hand-off to fifo.h buffers (gps.c:2847-2865) -------------------------- */
+/* ---- [boundary] hand-off to fifo.h buffers (gps.c:2847-2865) -------------------------- */
 /* Element-exact restatement of the chunking rules, independent of the FIFO
  * implementation: the caller supplies acquire/enqueue callbacks with the fifo.h
  * semantics (fifo.h:45-55).  struct layout of the buffers is fifo.h:19-25. */

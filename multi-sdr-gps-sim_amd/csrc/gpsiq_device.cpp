@@ -542,11 +542,16 @@ static int check_gen_args(const gpsiq_ctx *c, const void *ch, const void *dst, i
 // one context: begin() sizes the staging once, piece() queues descriptors + patches + kernel (+ the copy to the
 // destination) without waiting, finish() drains.  generate_reference drives one of them from the walking thread;
 // gpsiq_generate_batch_multi gives every device one, fed through a queue by the thread that walks the whole timeline.
-static int ref_chunk_blocks(int nblocks)
+static int ref_chunk_blocks(int nblocks, int nsamp)
 {
-    int n = 256;                                              // ~1-4 ms of walking, 60-180 us of kernel at 2.6 Msps
+    // A piece should be a few milliseconds of walking (the walk costs the same per 0.1 s block whatever the sample rate,
+    // ~5-15 us) and enough samples for a launch that fills the chip: 512 blocks at 2.6 Msps, fewer at higher rates where
+    // a block is more device work (25 Msps: 53 blocks = 133 M samples, ~0.4 ms of kernel under ~0.7 ms of walk).
+    long n = nsamp > 0 ? ((long) 512 * 260000) / nsamp : 512;
+    if (n > 512) n = 512;
+    if (n < 16) n = 16;
     if (const char *e = std::getenv("GPSIQ_REF_CHUNK_BLOCKS")) n = std::atoi(e);       // read per call: A/B in one process; <= 0: one piece
-    return n > 0 && n < nblocks ? n : nblocks;
+    return n > 0 && n < nblocks ? (int) n : nblocks;
 }
 
 struct RefRender {
@@ -613,7 +618,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
 {
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
-    double t_walk = 0.0;
+    double t_walk = 0.0, t_queue = 0.0;
     size_t npatch = 0;
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     std::vector<gpsiq_patch_t> patches;
@@ -621,7 +626,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     int prn[GPSIQ_MAX_CHAN] = {};
     RefRender r;
     int rc = r.begin(c, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
-    const int chunk = ref_chunk_blocks(nblocks);
+    const int chunk = ref_chunk_blocks(nblocks, nsamp);
     for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK; b0 += chunk) {
         const int nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
         const double tw = trace ? wall_ms() : 0.0;
@@ -630,16 +635,20 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
                                 b0 ? carr : nullptr, b0 ? prn : nullptr);
         if (trace) t_walk += wall_ms() - tw;
         npatch += patches.size();
+        const double tp = trace ? wall_ms() : 0.0;
         if (rc == GPSIQ_OK) rc = r.piece(q.data() + (size_t) b0 * nchan, b0, nb, patches);
+        if (trace) t_queue += wall_ms() - tp;
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
+    const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();
     if (rc != GPSIQ_OK) return fail(rc, "%s", err);
     if (frc != GPSIQ_OK) return frc;
     if (trace)
-        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in pieces of %d: carrier walk + candidates %.2f ms (%zu patches), whole call %.2f ms\n",
-                     nblocks, chunk, t_walk, npatch, wall_ms() - t0);
+        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in pieces of %d: carrier walk + candidates %.2f ms (%zu patches), "
+                             "validate + upload + launch %.2f ms, final wait %.2f ms, whole call %.2f ms\n",
+                     nblocks, chunk, t_walk, npatch, t_queue, wall_ms() - tf, wall_ms() - t0);
     if (carr_phase_out)
         for (int i = 0; i < nchan; ++i)
             carr_phase_out[i] = prn[i] ? carr[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
@@ -887,7 +896,7 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
             int r0 = 0, r1 = 0;
             (void) gpsiq_shard_range(nblocks, i, ndev, &r0, &r1);
             Dev &d = devs[(size_t) i];
-            const int chunk = ref_chunk_blocks(r1 - r0);
+            const int chunk = ref_chunk_blocks(r1 - r0, nsamp);
             for (int b0 = r0; b0 < r1 && wrc == GPSIQ_OK; b0 += chunk) {
                 Item it;
                 it.nb = r1 - b0 < chunk ? r1 - b0 : chunk;

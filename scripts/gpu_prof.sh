@@ -16,4 +16,4 @@ du -sh $OUT
 # summarise on the box too (the .db files can be large; only the text summaries are needed)
 ( cd $REPO && python scripts/prof_summary.py gpurun_out/prof ${PROF_TAG:-r02} > $OUT/summary.log 2>&1; tail -3 $OUT/summary.log )
 find $OUT -name "*.db" -size +8M -delete
-mkdir -p $REPO/gpurun_out/profiles_out; cp $REPO/profiles/${PROF_TAG:-r02}_* $REPO/profiles/pmc_traffic.json $REPO/gpurun_out/profiles_out/
+mkdir -p $REPO/gpurun_out/profiles_out; cp $REPO/profiles/${PROF_TAG:-r02}_* $REPO/profiles/pmc_traffic.json $REPO/profiles/pmc_counters.json $REPO/gpurun_out/profiles_out/

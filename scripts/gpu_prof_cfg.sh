@@ -13,8 +13,8 @@ for cfg in "cfg3 10000000" "cfg5 25000000"; do
   rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
   rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
   nb=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['config']['blocks_per_launch'])")
-  ( cd $REPO && PMC_KEY=${fs}_16_2_${nb} python scripts/prof_summary.py gpurun_out/prof_$name r02_$name > $OUT/summary.log 2>&1; tail -2 $OUT/summary.log )
+  ( cd $REPO && PMC_KEY=${fs}_16_2_${nb} python scripts/prof_summary.py gpurun_out/prof_$name ${PROF_TAG:-r02}_$name > $OUT/summary.log 2>&1; tail -2 $OUT/summary.log )
   find $OUT -name "*.db" -size +20M -delete
 done
-cd $REPO; mkdir -p gpurun_out/profiles_out; cp profiles/r02_cfg* profiles/pmc_traffic.json gpurun_out/profiles_out/
+cd $REPO; mkdir -p gpurun_out/profiles_out; cp profiles/${PROF_TAG:-r02}_cfg* profiles/pmc_traffic.json profiles/pmc_counters.json gpurun_out/profiles_out/
 du -sh gpurun_out

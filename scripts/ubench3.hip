@@ -80,6 +80,29 @@ __global__ __launch_bounds__(256) void ub(uint32_t *out, int iters, uint64_t s0,
             : [p] "+v"(Pn), [q] "+v"(Qn), [a] "+v"(a), [k] "+v"(k), [acc] "+v"(acc) \
             : [ph] "v"((uint32_t) (Pn >> 32)), [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [mask] "s"(mask), [sp] "v"(v0), [sq] "v"(v1), [base] "v"(base));
             LC(P0, Q0) LC(P1, Q1) LC(P2, Q2) LC(P3, Q3) LC(P0, Q0) LC(P1, Q1) LC(P2, Q2) LC(P3, Q3)
+        } else if (MODE == 6) {    // round-3 experiment, the row loop: the chip sign of channel c is bit c of a per-lane 16-bit word S
+            // (one ds_read_u16 per row, not counted here): constant shift (plain VOP2), sign into the phase, address, carrier
+            // NCO, add3 per two channels -- no code NCO, no SDWA shift
+#define SW(Pn, T, C) asm volatile( \
+            "v_lshrrev_b32 " T ", " C ", %[w]\n" \
+            "v_lshl_add_u32 " T ", " T ", 26, %[ph]\n" \
+            "v_and_b32_sdwa " T ", " T ", %[mask] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n" \
+            "v_lshl_add_u64 %[p], %[p], 0, %[sp]\n" \
+            : [p] "+v"(Pn), [a] "+v"(a), [k] "+v"(k) \
+            : [ph] "v"((uint32_t) (Pn >> 32)), [w] "v"(w), [mask] "s"(mask), [sp] "s"(s0));
+#define SW2(Pa, Pb, Ca, Cb) SW(Pa, "%[a]", Ca) SW(Pb, "%[k]", Cb) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(k));
+            SW2(P0, P1, "0", "1") SW2(P2, P3, "2", "3") SW2(Q0, Q1, "4", "5") SW2(Q2, Q3, "6", "7")
+        } else if (MODE == 7) {    // ... and what building those words costs per channel-sample, lane = sample: the code NCO, the
+            // window shifted by the chip byte (as today), and the bit shifted into the word (v_alignbit takes bit 0 of the
+            // shifted window whatever its upper bits are)
+#define SB(Qn) asm volatile( \
+            "v_lshrrev_b32_sdwa %[k], %[qh], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n" \
+            "v_alignbit_b32 %[a], %[k], %[a], 1\n" \
+            "v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" \
+            : [q] "+v"(Qn), [a] "+v"(a), [k] "+v"(k) \
+            : [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [sq] "s"(s1));
+            SB(Q0) SB(Q1) SB(Q2) SB(Q3) SB(P0) SB(P1) SB(P2) SB(P3)
+            acc += a;
         } else if (MODE == 3) {    // NCO adds with VGPR steps instead of SGPR pairs
             uint64_t v0 = s0 + threadIdx.x, v1 = s1 + threadIdx.x;
 #define TWOV(Pn, Qn) asm volatile("v_lshl_add_u64 %[p], %[p], 0, %[sp]\n v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" : [p] "+v"(Pn), [q] "+v"(Qn) : [sp] "v"(v0), [sq] "v"(v1));
@@ -123,6 +146,8 @@ int main()
         run<2>("sdwa,lshr,bfe,or,pk_mad", w, 5);
         run<4>("plain-add core: sdwa lshr,lshl_add,sdwa and,1/2 add3,2x lshl_add_u64", w, 5);
         run<5>("lane = channel: the same core + LUT base + 4 DPP row adds per 4 samples", w, 11);
+        run<6>("sign-word row loop: lshr const,lshl_add,sdwa and,1/2 add3,1x lshl_add_u64", w, 4);
+        run<7>("sign-word builder: lshl_add_u64, sdwa lshr, alignbit", w, 3);
     }
     return 0;
 }
