@@ -537,18 +537,18 @@ static int check_gen_args(const gpsiq_ctx *c, const void *ch, const void *dst, i
 }
 
 // ---- GPSIQ_NCO_REFERENCE: walk and render in pieces ------------------------------------------
-// The carrier walk is serial in time on the host, the render is not: the timeline is cut into pieces of a few hundred
-// blocks, and while the device renders (and copies out) piece k the host walks piece k+1.  RefRender is the device side of
-// one context: begin() sizes the staging once, piece() queues descriptors + patches + kernel (+ the copy to the
-// destination) without waiting, finish() drains.  generate_reference drives one of them from the walking thread;
-// gpsiq_generate_batch_multi gives every device one, fed through a queue by the thread that walks the whole timeline.
+// The carrier walk is serial in time on the host, the render is not: the timeline is cut into pieces, and while the device
+// renders (and copies out) piece k the walkers (RefWalk, gpsiq_exact.cpp: one host thread per channel, one pass) are in
+// the pieces behind it.  RefRender is the device side of one context: begin() sizes the staging once, piece() queues
+// descriptors + patches + kernel (+ the copy to the destination) without waiting, finish() drains.  generate_reference
+// drives one from the calling thread; gpsiq_generate_batch_multi gives every device one, fed through a queue.
 static int ref_chunk_blocks(int nblocks, int nsamp)
 {
-    // A piece should be a few milliseconds of walking (the walk costs the same per 0.1 s block whatever the sample rate,
-    // ~5-15 us) and enough samples for a launch that fills the chip: 512 blocks at 2.6 Msps, fewer at higher rates where
-    // a block is more device work (25 Msps: 53 blocks = 133 M samples, ~0.4 ms of kernel under ~0.7 ms of walk).
-    long n = nsamp > 0 ? ((long) 512 * 260000) / nsamp : 512;
-    if (n > 512) n = 512;
+    // A piece costs the renderer ~0.1-0.2 ms (validate + compact + upload + launch) whatever its size and nothing on the
+    // walkers' side, and should be enough samples for a launch that fills the chip: 256 blocks at 2.6 Msps (1.6 ms of
+    // walking, 0.2 ms of kernel), fewer at higher rates where a block is more device work (25 Msps: 26 blocks = 66 M samples).
+    long n = nsamp > 0 ? ((long) 256 * 260000) / nsamp : 256;
+    if (n > 256) n = 256;
     if (n < 16) n = 16;
     if (const char *e = std::getenv("GPSIQ_REF_CHUNK_BLOCKS")) n = std::atoi(e);       // read per call: A/B in one process; <= 0: one piece
     return n > 0 && n < nblocks ? (int) n : nblocks;
@@ -612,46 +612,63 @@ struct RefRender {
     }
 };
 
+// piece boundaries of a range of `n` blocks starting at block `first` of the walk, `chunk` blocks each
+static void piece_ends(int first, int n, int chunk, std::vector<int> *ends)
+{
+    for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
+    ends->push_back(first + n);
+}
+
+static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
+
 // GPSIQ_NCO_REFERENCE form of both drop-in calls: the carrier is the caller's double, walked exactly
 static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
                               int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
 {
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
-    double t_walk = 0.0, t_queue = 0.0;
+    double t_wait = 0.0, t_queue = 0.0;
     size_t npatch = 0;
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     std::vector<gpsiq_patch_t> patches;
-    double carr[GPSIQ_MAX_CHAN] = {};
-    int prn[GPSIQ_MAX_CHAN] = {};
     RefRender r;
     int rc = r.begin(c, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+    if (rc) return rc;
     const int chunk = ref_chunk_blocks(nblocks, nsamp);
-    for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK; b0 += chunk) {
-        const int nb = nblocks - b0 < chunk ? nblocks - b0 : chunk;
+    std::vector<int> ends;
+    piece_ends(0, nblocks, chunk, &ends);
+    RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
+    // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
+    // thread, and this thread renders every piece as soon as all channels are through it
+    pthread_t th;
+    const bool threaded = w.npieces() > 1 && pthread_create(&th, nullptr, run_walk, &w) == 0;
+    if (!threaded) w.run();
+    for (size_t k = 0; k < w.npieces() && rc == GPSIQ_OK; ++k) {
         const double tw = trace ? wall_ms() : 0.0;
-        patches.clear();
-        rc = reference_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, q.data() + (size_t) b0 * nchan, &patches, carr, prn,
-                                b0 ? carr : nullptr, b0 ? prn : nullptr);
-        if (trace) t_walk += wall_ms() - tw;
-        npatch += patches.size();
+        rc = w.wait_piece(k);
+        if (rc != GPSIQ_OK) { (void) fail(rc, "%s", w.err); break; }
         const double tp = trace ? wall_ms() : 0.0;
-        if (rc == GPSIQ_OK) rc = r.piece(q.data() + (size_t) b0 * nchan, b0, nb, patches);
-        if (trace) t_queue += wall_ms() - tp;
+        w.take_patches(k, &patches, true);
+        npatch += patches.size();
+        const int b0 = k ? w.ends[k - 1] : 0;
+        rc = r.piece(q.data() + (size_t) b0 * nchan, b0, w.ends[k] - b0, patches);
+        if (trace) { t_wait += tp - tw; t_queue += wall_ms() - tp; }
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
+    if (threaded) pthread_join(th, nullptr);                 // the walkers read ch and write q: never leave them running
     const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();
     if (rc != GPSIQ_OK) return fail(rc, "%s", err);
+    if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
     if (frc != GPSIQ_OK) return frc;
     if (trace)
-        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in pieces of %d: carrier walk + candidates %.2f ms (%zu patches), "
+        std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in %zu pieces of %d: waited for the walkers %.2f ms (%zu patches), "
                              "validate + upload + launch %.2f ms, final wait %.2f ms, whole call %.2f ms\n",
-                     nblocks, chunk, t_walk, npatch, t_queue, wall_ms() - tf, wall_ms() - t0);
+                     nblocks, w.npieces(), chunk, t_wait, npatch, t_queue, wall_ms() - tf, wall_ms() - t0);
     if (carr_phase_out)
         for (int i = 0; i < nchan; ++i)
-            carr_phase_out[i] = prn[i] ? carr[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+            carr_phase_out[i] = w.last_prn[i] ? w.carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
     return GPSIQ_OK;
 }
 
@@ -847,9 +864,9 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
     }
     std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     if (reference) {
-        // The walk is serial in time, the devices are not: the calling thread walks the timeline piece by piece and hands
-        // every piece to the device that owns it; device i starts as soon as the walk reaches its range, and renders
-        // under the walk of what follows.
+        // The walk is serial in time, the devices are not: the walkers (one host thread per channel, RefWalk) go through the
+        // whole timeline once, and this thread hands every piece, as soon as all channels are through it, to the device that
+        // owns it; device i starts as soon as the walk reaches its range, and renders under the walk of what follows.
         struct Item { const gpsiq_qchan_t *q; int b0, nb; std::vector<gpsiq_patch_t> patches; };
         struct Dev {
             gpsiq_ctx *c; int range_blocks, nchan, nsamp, ss; void *dst; int dst_is_device;
@@ -888,37 +905,56 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
             d.closed = false; d.rc = GPSIQ_OK; d.err[0] = 0;
             d.started = d.range_blocks > 0 && pthread_create(&d.th, nullptr, body, &d) == 0;
         }
-        double carr[GPSIQ_MAX_CHAN] = {};
-        int prn[GPSIQ_MAX_CHAN] = {};
-        int wrc = GPSIQ_OK;
-        char werr[400] = "";
+        // pieces never straddle two devices' ranges
+        std::vector<int> ends, owner;
         for (int i = 0; i < ndev; ++i) {
             int r0 = 0, r1 = 0;
             (void) gpsiq_shard_range(nblocks, i, ndev, &r0, &r1);
-            Dev &d = devs[(size_t) i];
-            const int chunk = ref_chunk_blocks(r1 - r0, nsamp);
-            for (int b0 = r0; b0 < r1 && wrc == GPSIQ_OK; b0 += chunk) {
-                Item it;
-                it.nb = r1 - b0 < chunk ? r1 - b0 : chunk;
-                it.b0 = b0 - r0;
-                it.q = q.data() + (size_t) b0 * nchan;
-                wrc = reference_timeline(ch + (size_t) b0 * nchan, it.nb, nchan, 1.0 / fs, nsamp, q.data() + (size_t) b0 * nchan, &it.patches,
-                                         carr, prn, b0 ? carr : nullptr, b0 ? prn : nullptr);
-                if (wrc != GPSIQ_OK) { std::snprintf(werr, sizeof werr, "%s", gpsiq_last_error()); break; }
-                if (d.started) {
-                    pthread_mutex_lock(&d.mu);
-                    d.items.push_back(std::move(it));
-                    pthread_cond_signal(&d.cv);
-                    pthread_mutex_unlock(&d.mu);
-                } else {
-                    d.items.push_back(std::move(it));                 // no thread for this device: rendered below, after the walk
-                }
+            if (r1 == r0) continue;
+            const size_t before = ends.size();
+            piece_ends(r0, r1 - r0, ref_chunk_blocks(r1 - r0, nsamp), &ends);
+            owner.insert(owner.end(), ends.size() - before, i);
+        }
+        RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
+        pthread_t wth;
+        const bool threaded = pthread_create(&wth, nullptr, run_walk, &w) == 0;
+        if (!threaded) w.run();
+        int wrc = GPSIQ_OK;
+        char werr[400] = "";
+        int open_dev = 0;                                             // devices before this one have all their pieces
+        for (size_t k = 0; k < w.npieces(); ++k) {
+            if (wrc == GPSIQ_OK) {
+                wrc = w.wait_piece(k);
+                if (wrc != GPSIQ_OK) std::snprintf(werr, sizeof werr, "%s", w.err);
             }
+            const int i = owner[k];
+            for (; open_dev < i; ++open_dev) {                        // the walk has left device open_dev's range: no more pieces for it
+                Dev &p = devs[(size_t) open_dev];
+                pthread_mutex_lock(&p.mu); p.closed = true; pthread_cond_signal(&p.cv); pthread_mutex_unlock(&p.mu);
+            }
+            if (wrc != GPSIQ_OK) continue;
+            Dev &d = devs[(size_t) i];
+            int r0 = 0, r1 = 0;
+            (void) gpsiq_shard_range(nblocks, i, ndev, &r0, &r1);
+            Item it;
+            const int b0 = k ? w.ends[k - 1] : 0;
+            it.nb = w.ends[k] - b0;
+            it.b0 = b0 - r0;
+            it.q = q.data() + (size_t) b0 * nchan;
+            w.take_patches(k, &it.patches, true);
             pthread_mutex_lock(&d.mu);
-            d.closed = true;
+            d.items.push_back(std::move(it));
             pthread_cond_signal(&d.cv);
             pthread_mutex_unlock(&d.mu);
         }
+        for (; open_dev < ndev; ++open_dev) {
+            Dev &p = devs[(size_t) open_dev];
+            pthread_mutex_lock(&p.mu); p.closed = true; pthread_cond_signal(&p.cv); pthread_mutex_unlock(&p.mu);
+        }
+        if (threaded) pthread_join(wth, nullptr);
+        double carr[GPSIQ_MAX_CHAN];
+        int prn[GPSIQ_MAX_CHAN];
+        for (int i = 0; i < nchan; ++i) { carr[i] = w.carr_end[i]; prn[i] = w.last_prn[i]; }
         for (int i = 0; i < ndev; ++i) {
             Dev &d = devs[(size_t) i];
             if (d.started) pthread_join(d.th, nullptr);

@@ -29,6 +29,7 @@
 #include "gpsiq_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -558,91 +559,147 @@ static double carrier_after(double x0, double c, long ns)
     return w.run(x0, ns);
 }
 
-int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
-                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
-                       const double *carr_in, const int *prn_in)
+// ---- the host side of GPSIQ_NCO_REFERENCE as ONE pass per channel -------------------------------------------------
+// Everything a channel needs for block b -- the accumulator the reference holds at its start, the quantised descriptor
+// seeded from it, the samples where the double path leaves the closed form -- depends on that channel's own history only
+// (the patch slot is the count of active channels before it in the block, read off the descriptors).  So one host thread
+// per channel walks the whole timeline once, block after block, and counts the pieces it has finished; whoever renders
+// (the calling thread of a batch, the device queues of a multi-device batch) waits for a piece to be complete in all
+// channels and takes its descriptors and patches while the walkers are already in the pieces behind it.  No barrier
+// between the carrier chain and the candidate search, no thread woken per piece, and the work per thread is the same for
+// every channel whatever the piece length.
+RefWalk::RefWalk(const gpsiq_chan_t *ch_, int nblocks_, int nchan_, double delt_, int nsamp_, gpsiq_qchan_t *q_,
+                 const double *carr_in_, const int *prn_in_, const std::vector<int> &piece_ends)
+    : ch(ch_), nblocks(nblocks_), nchan(nchan_), nsamp(nsamp_), delt(delt_), q(q_), ends(piece_ends), have_in(carr_in_ && prn_in_)
 {
-    // pass 1: the carrier chain, serial per channel (gps.c:2821 carries chan[i].carr_phase from block to
-    // block; allocateChannel re-initialises it when the slot gets another satellite, gps.c:2208-2214)
-    std::vector<double> start((size_t) nblocks * (size_t) nchan, 0.0);
-    struct CJob { const gpsiq_chan_t *ch; int nblocks, nchan, nsamp; double delt; double *start, *end; int *last; const double *carr_in; const int *prn_in; };
-    std::vector<double> end((size_t) nchan, 0.0);
-    std::vector<int> last((size_t) nchan, 0);
-    CJob cj = {ch, nblocks, nchan, nsamp, delt, start.data(), end.data(), last.data(), carr_in, prn_in};
-    parallel_for(nchan, nchan, 1, [](void *p, int i0, int i1) {
-        CJob &j = *static_cast<CJob *>(p);
-        for (int i = i0; i < i1; ++i) {
-            // carr_in / prn_in: this timeline goes on where another call stopped (the pieces of one batch): the slot's
-            // accumulator and satellite after that call's last block
-            double carr = j.carr_in ? j.carr_in[i] : 0.0;
-            int prev = j.prn_in ? j.prn_in[i] : 0;
-            for (int b = 0; b < j.nblocks; ++b) {
-                const gpsiq_chan_t &d = j.ch[(size_t) b * j.nchan + i];
-                if (d.prn <= 0) { prev = 0; carr = 0.0; continue; }
-                if ((b == 0 && !j.prn_in) || prev != d.prn) carr = d.carr_phase;
-                j.start[(size_t) b * j.nchan + i] = carr;
-                // carr == 1.0: a wrap of the block before rounded up to one (see block_patches); the reference goes on from it
-                if (carr >= 0.0 && carr <= 1.0 && std::fabs(d.f_carr * j.delt) < 0.5)    // else quantize_one reports it below
-                    carr = carrier_after(carr, d.f_carr * j.delt, j.nsamp);
-                prev = d.prn;
-            }
-            j.end[i] = carr; j.last[i] = prev;
-        }
-    }, &cj);
-    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
-    timespec ts1;
-    clock_gettime(CLOCK_MONOTONIC, &ts1);
-    // pass 2: quantise every block from its own start phase and look for the samples that differ
-    struct PJob { const gpsiq_chan_t *ch; gpsiq_qchan_t *q; const double *start; int nchan, nsamp; double delt;
-                  std::vector<gpsiq_patch_t> *out; pthread_mutex_t mu; int rc; char err[320]; };
-    PJob pj = {ch, q, start.data(), nchan, nsamp, delt, patches, PTHREAD_MUTEX_INITIALIZER, GPSIQ_OK, ""};
-    parallel_for(nblocks, 0, 4, [](void *p, int b0, int b1) {
-        PJob &j = *static_cast<PJob *>(p);
-        std::vector<gpsiq_patch_t> mine;
-        CodeCache codes;
-        for (int b = b0; b < b1; ++b) {
-            int slot = 0;                                   // device order: active channels first (gpsiq_set_descriptors)
-            for (int i = 0; i < j.nchan; ++i) {
-                gpsiq_chan_t d = j.ch[(size_t) b * j.nchan + i];
-                gpsiq_qchan_t &qq = j.q[(size_t) b * j.nchan + i];
-                const double start = j.start[(size_t) b * j.nchan + i];
-                // a start of exactly 1.0 is phase 0 of the closed form (mod 1); block_patches walks the double from 1.0 and
-                // patches sample 0, where the reference indexes its table at 512
-                d.carr_phase = start == 1.0 ? 0.0 : start;
-                const int rc = quantize_one(d, j.delt, j.nsamp, nullptr, &qq, nullptr);
-                d.carr_phase = start;
-                if (rc != GPSIQ_OK) {
-                    pthread_mutex_lock(&j.mu);
-                    if (j.rc == GPSIQ_OK) { j.rc = rc; std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error()); }
-                    pthread_mutex_unlock(&j.mu);
-                    continue;
-                }
-                if (d.prn <= 0) continue;
-                block_patches(d, qq, j.delt, j.nsamp, b, slot, &codes, &mine);
-                ++slot;
-            }
-        }
-        if (!mine.empty()) {
-            pthread_mutex_lock(&j.mu);
-            j.out->insert(j.out->end(), mine.begin(), mine.end());
-            pthread_mutex_unlock(&j.mu);
-        }
-    }, &pj);
-    if (pj.rc != GPSIQ_OK) return fail(pj.rc, "%s", pj.err);
-    if (trace) {
-        timespec ts2;
-        clock_gettime(CLOCK_MONOTONIC, &ts2);
-        std::fprintf(stderr, "[gpsiq trace] reference NCO %d blocks x %d ch: candidates + code walks + patches %.2f ms (after the carrier chain)\n",
-                     nblocks, nchan, (double) (ts2.tv_sec - ts1.tv_sec) * 1e3 + (double) (ts2.tv_nsec - ts1.tv_nsec) * 1e-6);
+    if (ends.empty() || ends.back() != nblocks) ends.push_back(nblocks);
+    for (int i = 0; i < GPSIQ_MAX_CHAN; ++i) {
+        carr_in[i] = have_in && i < nchan ? carr_in_[i] : 0.0;
+        prn_in[i] = have_in && i < nchan ? prn_in_[i] : 0;
+        carr_end[i] = 0.0; last_prn[i] = 0; taken[i] = 0;
+        pthread_mutex_init(&pmu[i], nullptr);
     }
-    std::sort(patches->begin(), patches->end(), [](const gpsiq_patch_t &a, const gpsiq_patch_t &b) {
+    done.reset(new std::atomic<int>[ends.size()]);
+    for (size_t k = 0; k < ends.size(); ++k) done[k].store(0, std::memory_order_relaxed);
+    pthread_mutex_init(&mu, nullptr);
+    pthread_cond_init(&cv, nullptr);
+}
+
+RefWalk::~RefWalk()
+{
+    for (int i = 0; i < GPSIQ_MAX_CHAN; ++i) pthread_mutex_destroy(&pmu[i]);
+    pthread_mutex_destroy(&mu);
+    pthread_cond_destroy(&cv);
+}
+
+void RefWalk::finish_piece(size_t k)
+{
+    if (done[k].fetch_add(1, std::memory_order_acq_rel) + 1 == nchan) {
+        pthread_mutex_lock(&mu);
+        pthread_cond_broadcast(&cv);
+        pthread_mutex_unlock(&mu);
+    }
+}
+
+void RefWalk::run_channel(int i)
+{
+    CodeCache codes;
+    std::vector<gpsiq_patch_t> mine;
+    // carr_in / prn_in: this timeline goes on where another call stopped: the slot's accumulator and satellite after that
+    // call's last block
+    double carr = carr_in[i];
+    int prev = prn_in[i];
+    size_t k = 0;
+    while (k < ends.size() && ends[k] == 0) finish_piece(k++);          // empty pieces in front
+    for (int b = 0; b < nblocks; ++b) {
+        gpsiq_chan_t d = ch[(size_t) b * nchan + i];
+        gpsiq_qchan_t &qq = q[(size_t) b * nchan + i];
+        if (d.prn <= 0) {
+            prev = 0; carr = 0.0;
+            (void) quantize_one(d, delt, nsamp, nullptr, &qq, nullptr);  // an unused slot: zeroes
+        } else {
+            // the carrier chain (gps.c:2821 carries chan[i].carr_phase from block to block; allocateChannel re-initialises
+            // it when the slot gets another satellite, gps.c:2208-2214)
+            if ((b == 0 && !have_in) || prev != d.prn) carr = d.carr_phase;
+            const double start = carr;
+            // carr == 1.0: a wrap of the block before rounded up to one (see block_patches); the reference goes on from it
+            if (carr >= 0.0 && carr <= 1.0 && std::fabs(d.f_carr * delt) < 0.5)     // else quantize_one reports it below
+                carr = carrier_after(carr, d.f_carr * delt, nsamp);
+            prev = d.prn;
+            // a start of exactly 1.0 is phase 0 of the closed form (mod 1); block_patches walks the double from 1.0 and
+            // patches sample 0, where the reference indexes its table at 512
+            d.carr_phase = start == 1.0 ? 0.0 : start;
+            const int qrc = quantize_one(d, delt, nsamp, nullptr, &qq, nullptr);
+            d.carr_phase = start;
+            if (qrc != GPSIQ_OK) {
+                pthread_mutex_lock(&mu);
+                if (rc == GPSIQ_OK) { rc = qrc; std::snprintf(err, sizeof err, "block %d: %.280s", b, gpsiq_last_error()); }
+                pthread_mutex_unlock(&mu);
+            } else {
+                int slot = 0;                                            // device order: active channels first (gpsiq_set_descriptors)
+                for (int j = 0; j < i; ++j) slot += ch[(size_t) b * nchan + j].prn > 0;
+                mine.clear();
+                block_patches(d, qq, delt, nsamp, b, slot, &codes, &mine);
+                if (!mine.empty()) {
+                    pthread_mutex_lock(&pmu[i]);
+                    patches[i].insert(patches[i].end(), mine.begin(), mine.end());
+                    pthread_mutex_unlock(&pmu[i]);
+                }
+            }
+        }
+        while (k < ends.size() && ends[k] == b + 1) finish_piece(k++);
+    }
+    carr_end[i] = carr; last_prn[i] = prev;
+}
+
+void RefWalk::run()
+{
+    parallel_for(nchan, nchan, 1, [](void *p, int i0, int i1) {
+        RefWalk &w = *static_cast<RefWalk *>(p);
+        for (int i = i0; i < i1; ++i) w.run_channel(i);
+    }, this);
+}
+
+int RefWalk::wait_piece(size_t k)
+{
+    pthread_mutex_lock(&mu);
+    while (done[k].load(std::memory_order_acquire) < nchan) pthread_cond_wait(&cv, &mu);
+    const int r = rc;
+    pthread_mutex_unlock(&mu);
+    return r;
+}
+
+void RefWalk::take_patches(size_t k, std::vector<gpsiq_patch_t> *out, bool relative)
+{
+    const uint32_t b0 = k ? (uint32_t) ends[k - 1] : 0u, b1 = (uint32_t) ends[k];
+    out->clear();
+    for (int i = 0; i < nchan; ++i) {
+        pthread_mutex_lock(&pmu[i]);
+        size_t t = taken[i];
+        while (t < patches[i].size() && patches[i][t].block < b1) out->push_back(patches[i][t++]);
+        taken[i] = t;
+        pthread_mutex_unlock(&pmu[i]);
+    }
+    std::sort(out->begin(), out->end(), [](const gpsiq_patch_t &a, const gpsiq_patch_t &b) {
         if (a.block != b.block) return a.block < b.block;
         if (a.sample != b.sample) return a.sample < b.sample;
         return a.slot < b.slot;
     });
+    if (relative)
+        for (gpsiq_patch_t &p : *out) p.block -= b0;
+}
+
+int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
+                       gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
+                       const double *carr_in, const int *prn_in)
+{
+    RefWalk w(ch, nblocks, nchan, delt, nsamp, q, carr_in, prn_in, std::vector<int>());
+    w.run();
+    if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
+    w.take_patches(0, patches, false);
     for (int i = 0; i < nchan; ++i) {
-        if (carr_end) carr_end[i] = end[(size_t) i];
-        if (last_prn) last_prn[i] = last[(size_t) i];
+        if (carr_end) carr_end[i] = w.carr_end[i];
+        if (last_prn) last_prn[i] = w.last_prn[i];
     }
     return GPSIQ_OK;
 }

@@ -6,7 +6,9 @@
 #include "gpsiq_tables.h"
 
 #include <pthread.h>
+#include <atomic>
 #include <cstdio>
+#include <memory>
 #include <vector>
 
 namespace gpsiq {
@@ -39,6 +41,37 @@ int quantize_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double del
 int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp,
                        gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
                        const double *carr_in = nullptr, const int *prn_in = nullptr);
+
+// The same as a walker that can be consumed piece by piece while it runs (gpsiq_exact.cpp): one host thread per channel goes
+// through the whole timeline once; piece k = blocks [ends[k-1], ends[k]) is complete when every channel has finished it.
+struct RefWalk {
+    RefWalk(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp, gpsiq_qchan_t *q,
+            const double *carr_in, const int *prn_in, const std::vector<int> &piece_ends);
+    ~RefWalk();
+    RefWalk(const RefWalk &) = delete;
+    RefWalk &operator=(const RefWalk &) = delete;
+    void run();                                   // returns when every channel has walked every block; call from any ONE thread
+    int  wait_piece(size_t k);                    // blocks until piece k is complete; the first error so far (GPSIQ_OK if none)
+    // the patches of piece k (pieces must be taken in ascending order), sorted by (block, sample, slot); relative: block
+    // indices counted from the piece's first block
+    void take_patches(size_t k, std::vector<gpsiq_patch_t> *out, bool relative);
+    size_t npieces() const { return ends.size(); }
+
+    const gpsiq_chan_t *ch; int nblocks, nchan, nsamp; double delt; gpsiq_qchan_t *q;
+    std::vector<int> ends;
+    bool have_in;
+    double carr_in[GPSIQ_MAX_CHAN]; int prn_in[GPSIQ_MAX_CHAN];
+    double carr_end[GPSIQ_MAX_CHAN]; int last_prn[GPSIQ_MAX_CHAN];       // valid after run()
+    int rc = GPSIQ_OK; char err[320] = "";
+private:
+    void run_channel(int i);
+    void finish_piece(size_t k);
+    std::vector<gpsiq_patch_t> patches[GPSIQ_MAX_CHAN];
+    size_t taken[GPSIQ_MAX_CHAN];
+    pthread_mutex_t pmu[GPSIQ_MAX_CHAN], mu;
+    pthread_cond_t cv;
+    std::unique_ptr<std::atomic<int>[]> done;
+};
 
 // Run fn(ctx, begin, end) over [0, n) on up to nthreads host threads (<= 0: one per online
 // CPU, but at least `grain` items per thread).  Returns after all parts are done.
