@@ -239,8 +239,6 @@ inline unsigned nav_bit(const gpsiq_chan_t &ch, long bit)     // the data bit `b
 
 }  // namespace
 
-// Patches of one channel of one block.  ch.carr_phase is the double the block starts from; q is its
-// quantised form (quantize_one without carry_in, i.e. seeded from that double).
 // One C/A code, generated when a block first has a candidate to look at (most have none).
 struct CodeCache {
     int     prn = 0;
@@ -248,120 +246,76 @@ struct CodeCache {
     const uint8_t *get(int p) { if (p != prn) { ca_code(p, ca); prn = p; } return ca; }
 };
 
-static void block_patches(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double delt, int nsamp, int block, int slot,
-                          CodeCache *codes, std::vector<gpsiq_patch_t> *out)
-{
-    const long ns = nsamp;
-    if (ns <= 0) return;
-    const double carr_inc = ch.f_carr * delt, code_inc = ch.f_code * delt;
-    // drift bounds at the end of the block, in units of the fixed-point formats (see the header)
-    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
-    const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
-    std::vector<long> t_carr, t_code, targets;
-    constexpr size_t kCap = 256;
-    bool every = false;
-    if (carr_inc != 0.0)          // a zero addend leaves both paths constant and equal
-        every |= !candidates(q.carr_phase, (uint64_t) q.carr_step, GPSIQ_CARR_FRAC_BITS - 9, w_carr, ns, kCap, &t_carr);
-    every |= !candidates(q.code_frac, q.code_step, GPSIQ_CODE_FRAC_BITS, w_code, ns, kCap, &t_code);
-    if (every) {
-        targets.resize((size_t) ns);
-        for (long n = 0; n < ns; ++n) targets[(size_t) n] = n;
-    } else {
-        targets.resize(t_carr.size() + t_code.size());
-        std::merge(t_carr.begin(), t_carr.end(), t_code.begin(), t_code.end(), targets.begin());
-        targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
-    }
-    if (targets.empty()) return;
-    const uint8_t *ca = codes->get(ch.prn);
-    Nco carr = {ch.carr_phase, carr_inc, 0, 0, 1}, code = {ch.code_phase, code_inc, 0, 0, 0};
-    const bool walk_code = every || !t_code.empty();
-    for (long n : targets) {
-        // fixed-point path (include/gpsiq.h)
-        const uint64_t P = (q.carr_phase + (uint64_t) q.carr_step * (uint64_t) n) & ((UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1);
-        const unsigned idx_f = (unsigned) (P >> (GPSIQ_CARR_FRAC_BITS - 9));
-        const u128 T = (u128) q.code_frac + (u128) q.code_step * (uint64_t) n;
-        const uint64_t A = (uint64_t) q.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
-        const unsigned chip_f = (unsigned) (A % GPSIQ_CA_SEQ_LEN);
-        const long per_f = (long) (A / GPSIQ_CA_SEQ_LEN);
-        const unsigned neg_f = ca[chip_f] ^ nav_bit(ch, ((long) ch.icode + per_f) / 20);
-        // double path
-        carr.advance(n);
-        unsigned idx_d = (unsigned) (int) std::floor(carr.x * 512.0);              // gps.c:2775
-        if (idx_d > 511u) idx_d = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
-        unsigned neg_d = neg_f;
-        if (walk_code) {
-            code.advance(n);
-            const unsigned chip_d = (unsigned) (int) code.x;                         // gps.c:2817
-            neg_d = ca[chip_d] ^ nav_bit(ch, ((long) ch.icode + code.wraps) / 20);   // gps.c:2791-2811
-        }
-        if (idx_d != idx_f || neg_d != neg_f) {
-            gpsiq_patch_t p;
-            p.block = (uint32_t) block; p.sample = (uint32_t) n;
-            p.slot = (uint8_t) slot; p.neg = (uint8_t) neg_d; p.lut = (uint16_t) idx_d;
-            out->push_back(p);
-        }
-    }
-}
-
-// The carrier phase the reference's accumulator holds after nsamp samples (gps.c:2821-2826 nsamp times).
-// This is the serial chain of the whole mode -- one call per channel and block, each starting from the last one's
-// result -- so it has its own form of Nco::advance for the common case (a normal addend below 2^-5 cycle per sample,
-// no exact-tie binade): between two wraps the phase climbs (or, with a negative addend, descends) through the binades
-// from the addend's own to [0.5, 1).  The lowest five of them hold 1, 2, 4, 8, 16 steps: plain additions there cost
-// less than a table piece each; above them one piece per binade as in Nco::advance, with the run length from the
-// per-binade table.  That is one carrier CYCLE, ~70 ns of dependent operations.
+// The accumulators walked from wrap to wrap.
 //
-// On top of it, a map from wrap to wrap.  Right after a wrap the phase is a multiple of U = 2^-52 (positive addend:
-// y - 1.0 with y in [1, 2)) or 2^-53 (negative addend: y + 1.0 in [0.5, 1)).  Start the same cycle from x0 + d*U
-// instead of x0: as long as every RESULT of the cycle's additions stays inside the binade it had, every rounding
-// drops the same bits (d*U is an even multiple of every ulp involved -- all of them are <= 2^-53 -- so ties to even
-// fall the same way as well) and the whole cycle is the first one translated: same number of samples, final state
-// moved by d*U.  The cycle walk therefore also returns the range of d for which that holds (the distance of every
-// result to the edges of its binade, two units short on either side because a sum that crosses an edge is rounded on
-// the other grid), and the cycle becomes an entry {first state, last state, state increment, samples} of a small sorted
-// table.  As the start state sweeps the addend's width, every binade edge on the way is crossed one step earlier
-// exactly once, so the table has about as many entries as a cycle has binades (a dozen or two); a block of 260 000
-// samples at 2.6 kHz Doppler is 260 cycles, of which the first ~20 are walked and the rest are table look-ups on
-// integers.  The one rounding that is not translation invariant is the wrap itself when it is an exact tie (the kept
-// bit's parity moves with d): such a cycle is never entered into the table.  The addend changes with every block
-// (gps.c:2042), so the table lives for one call.
-namespace {
-
-struct CarrierWalk {
+// Nco::advance costs a dozen dependent pieces per carrier cycle / code period, ~70 ns.  For the common case (a normal
+// addend well below the accumulator's range, no exact-tie binade) NcoWalk has the same walk in a leaner form -- between
+// two wraps the phase climbs (or, with a negative carrier addend, descends) through the binades from the addend's own to
+// the top one; the lowest five hold 1, 2, 4, 8, 16 steps: plain additions there cost less than a table piece each; above
+// them one piece per binade, with the run length from a per-binade table -- and, on top of it, a map from wrap to wrap.
+// Right after a wrap the state is a multiple of U = the ulp of the binade the wrap is taken in (carrier: 2^-52 for
+// y - 1.0 with y in [1, 2), 2^-53 for y + 1.0 in [0.5, 1); code: 2^-43 for y - 1023.0 with y in [512, 1024)).  Start the
+// same cycle from x0 + d*U instead of x0: as long as every RESULT of the cycle's additions stays inside the binade it had
+// (and on its side of the wrap limit), every rounding drops the same bits -- d*U is a multiple of every ulp involved, an
+// even one wherever a tie could occur, since addends with an exact-tie binade above the plain additions take the general
+// walker -- and the whole cycle is the first one translated: same number of samples, final state moved by d*U.  The cycle
+// walk therefore also returns the range of d for which that holds (the distance of every result to the edges of its
+// binade, two units short on either side because a sum that crosses an edge is rounded on the other grid), and the cycle
+// becomes an entry {first state, last state, state increment, samples} of a small table.  As the start state sweeps the
+// addend's width every binade edge on the way is crossed one step earlier exactly once, so the table has about as many
+// entries as a cycle has binades (a dozen or two); a block of 260 000 samples at 2.6 kHz Doppler is 260 carrier cycles, of
+// which the first ~17 are walked and the rest are look-ups on integers.  The one rounding that is not translation
+// invariant is the wrap itself when it is an exact tie (the kept bit's parity moves with d): such a cycle is never tabled.
+// The addends change with every block (gps.c:2042-2043), so a table lives for one block.
+struct NcoWalk {
     struct Piece { int64_t dm, k, rem, kdm, span; };
     static constexpr int kLow = 4;                        // binades ec .. ec + kLow: plain additions
-    double  c = 0.0, thr = 0.0;
+    int     kind = 1;                                     // 0: code phase (wrap at 1023 chips), 1: carrier phase (wrap into [0,1))
+    double  c = 0.0, thr = 0.0, wrap = 1.0;
     int64_t ec = 0;
+    int     top_exp = 1022;                               // biased exponent of the binade that holds the wrap limit
     bool    neg = false, general = true;
     Piece   T[64];
 
-    // distance of the cycle's results to their binade edges, in units of the state grid U = 2^-unit_exp
+    // distance of the cycle's results to their binade edges, in units of the state grid U
     struct Slack {
         int64_t lo, hi;        // the cycle holds for start states x0 + d*U, lo <= d <= hi
-        int     top_exp;       // biased exponent of the binade whose ulp is U (1023 for U = 2^-52, 1022 for 2^-53)
+        int     unit_exp;      // biased exponent of the binade whose ulp is U
         bool    ok;
         inline void note(double v)
         {
             const uint64_t b = bits_of(v);
             const int e = (int) (b >> 52);                                        // sign bit set -> e >= 2048 -> sh < 0
-            const int sh = top_exp - e;                                           // U / ulp(v) = 2^sh
+            const int sh = unit_exp - e;                                          // U / ulp(v) = 2^sh
             if (sh < 0 || sh > 62 || e == 0) { ok = false; return; }
             const int64_t mx = (int64_t) ((b & kMant) | (kMant + 1));
             const int64_t l = 2 - ((mx - ((int64_t) 1 << 52)) >> sh), h = ((((int64_t) 1 << 53) - mx) >> sh) - 2;
             if (l > lo) lo = l;
             if (h < hi) hi = h;
         }
+        // the code phase's wrap limit lies inside its top binade: last value before the wrap, first value after the addition
+        inline void note_limit(double below, double at_or_above, double limit, double scale)
+        {
+            const double a = (limit - at_or_above) * scale, t = (limit - below) * scale;      // a <= 0 < t, exact (same binade, times 2^k)
+            const int64_t l = 2 - (int64_t) (-a), h = (int64_t) t - 2;
+            if (l > lo) lo = l;
+            if (h < hi) hi = h;
+        }
     };
 
-    void setup(double addend)
+    void setup(double addend, int kind_)
     {
+        kind = kind_;
         c = addend;
+        wrap = kind == 0 ? (double) GPSIQ_CA_SEQ_LEN : 1.0;
+        top_exp = kind == 0 ? 1023 + 9 : 1022;
         const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
         ec = (int64_t) (bc >> 52);
         const int64_t mc = (int64_t) ((bc & kMant) | (kMant + 1));
         neg = c < 0.0;
-        general = ec > 1023 - 6 || ec < 1023 - 40;
-        const int top = (int) (1022 - ec);                // exponent difference of the binade [0.5, 1)
+        // the addend at least 2^6 below the top binade's start and not absurdly small; the code phase only ever climbs
+        general = ec > top_exp - 6 || ec < top_exp - 40 || (kind == 0 && neg);
+        const int top = (int) (top_exp - ec);             // exponent difference of the top binade
         for (int s = kLow + 1; s <= top && !general; ++s) {
             int64_t dm = mc >> s;                         // rnd(c / ulp) in ulps of the binade, see Nco::build_piece
             const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
@@ -369,10 +323,14 @@ struct CarrierWalk {
             else if (rem == half) general = true;         // ties to even depend on x's parity: the probing walk
             Piece &p = T[s];
             p.dm = dm;
-            p.span = neg ? ((int64_t) 1 << 52) - 2 : ((int64_t) 1 << 52) - 1;
+            // the run ends on the last mantissa of the binade -- or, in the code phase's top binade [512, 1024), short of
+            // 1023 = 1023 * 2^43 ulps; downwards it must stay strictly above the binade's first value (Nco::build_piece)
+            if (neg) p.span = ((int64_t) 1 << 52) - 2;
+            else if (kind == 0 && s == top) p.span = ((int64_t) GPSIQ_CA_SEQ_LEN << 43) - 1 - ((int64_t) 1 << 52);
+            else p.span = ((int64_t) 1 << 52) - 1;
             p.k = p.span / dm; p.kdm = p.k * dm; p.rem = p.span - p.kdm;
         }
-        if (!general) thr = from_bits((uint64_t) (ec + kLow + 1) << 52);   // first value the table handles; thr <= 0.5, |c| < thr / 16
+        if (!general) thr = from_bits((uint64_t) (ec + kLow + 1) << 52);   // first value the table handles; |c| < thr / 16
     }
 
     // Positive addend: from x (sample n) up to the next wrap.  true: wrapped, x is the state after the wrap (sample n);
@@ -381,18 +339,19 @@ struct CarrierWalk {
     inline bool climb(double &x, long &n, long ns, Slack *sl) const
     {
         constexpr int64_t one52 = (int64_t) 1 << 52;
-        while (x < thr) {                                             // cannot wrap: x + c < 0.5 + 2^-5
+        while (x < thr) {                                             // cannot wrap: x + c < thr + thr / 16
             x += c;
             if (kNote) sl->note(x);
             if (++n == ns) return false;
         }
-        for (;;) {                                                    // x in [thr, 1)
+        for (;;) {                                                    // x in [thr, wrap)
             const uint64_t bx = bits_of(x);
             const Piece &p = T[(int64_t) (bx >> 52) - ec];
             const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1)), off = mx - one52;
             int64_t run, moved;
             if (off <= p.rem) { run = p.k; moved = p.kdm; }
             else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
+            else if (off > p.span) { run = 0; moved = 0; }            // code phase within one step of 1023
             else { run = (p.span - off) / p.dm; moved = run * p.dm; }
             if (run >= ns - n) { x = from_bits((bx & ~kMant) | ((uint64_t) (mx + (ns - n) * p.dm) & kMant)); n = ns; return false; }
             x = from_bits((bx & ~kMant) | ((uint64_t) (mx + moved) & kMant));
@@ -400,13 +359,14 @@ struct CarrierWalk {
             if (kNote && run) sl->note(x);
             const double y = x + c;                                   // leaves the binade, or wraps
             ++n;
-            if (y >= 1.0) {
+            if (y >= wrap) {
                 if (kNote) {
                     sl->note(y);
+                    if (kind == 0) sl->note_limit(x, y, wrap, 0x1p43);
                     const double bb = y - x, err = (x - (y - bb)) + (c - bb);     // the rounding error of x + c, exactly
-                    if (std::fabs(err) == 0x1p-53) sl->ok = false;                // a tie on the grid of [1, 2): see above
+                    if (std::fabs(err) == (kind == 0 ? 0x1p-44 : 0x1p-53)) sl->ok = false;   // a tie on the grid the wrap is taken on
                 }
-                x = y - 1.0;
+                x = y - wrap;
                 return true;
             }
             x = y;
@@ -415,13 +375,13 @@ struct CarrierWalk {
         }
     }
 
-    // Negative addend, the same downwards.
+    // Negative addend (carrier only), the same downwards.
     template <bool kNote>
     inline bool descend(double &x, long &n, long ns, Slack *sl) const
     {
         constexpr int64_t one52 = (int64_t) 1 << 52;
         while (x >= thr) {
-            if (x >= 1.0) {                                           // a wrap that rounded to exactly 1.0 (see block_patches)
+            if (x >= 1.0) {                                           // a wrap that rounded to exactly 1.0 (see evaluate_block)
                 if (kNote) sl->ok = false;
                 x += c;
                 if (++n == ns) return false;
@@ -463,40 +423,72 @@ struct CarrierWalk {
         }
     }
 
+    inline bool cycle(double &x, long &n, long ns) const { return neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr); }
+
+    // the state at sample `target` (>= n) of a walk that is at sample n in state x; counts the wraps on the way
+    inline double state_at(double x, long n, long target, long *wraps) const
+    {
+        while (n < target && cycle(x, n, target)) ++*wraps;
+        return x;
+    }
+
     // wrap-to-wrap table.  Entries are valid each on its own (overlaps are harmless) and are found through 1024 buckets
-    // over the range of post-wrap states: a bucket wholly inside an entry names it (one shift and two loads per cycle,
-    // no search: the states are as good as random, a binary search would mispredict at every level); the few buckets that
+    // over the range of post-wrap states: a bucket wholly inside an entry names it (one shift and two loads per cycle, no
+    // search: the states are as good as random, a binary search would mispredict at every level); the few buckets that
     // straddle an edge fall back to a scan.
     struct Entry { int64_t first, last, inc; long steps; };
     static constexpr int kMaxEntries = 64, kBuckets = 1024;
 
-    double run(double x0, long ns) const
+    // The state after ns samples from x0.  targets[nt] (ascending, < ns): samples whose state is wanted as well -> xs[nt]
+    // and, if wraps_at is given, the number of wraps before each (code: code periods completed, gps.c:2791-2793).
+    double run(double x0, long ns, const long *targets = nullptr, int nt = 0, double *xs = nullptr, long *wraps_at = nullptr) const
     {
-        if (general || !(x0 >= 0.0 && x0 < 1.0) || ns <= 0) {
-            if (ns <= 0) return x0;
-            Nco carr = {x0, c, 0, 0, 1};
-            carr.advance(ns);
-            return carr.x;
+        int tk = 0;
+        if (ns <= 0) return x0;
+        if (general || !(x0 >= 0.0 && x0 < wrap)) {
+            Nco a = {x0, c, 0, 0, kind};
+            for (; tk < nt; ++tk) { a.advance(targets[tk]); xs[tk] = a.x; if (wraps_at) wraps_at[tk] = a.wraps; }
+            a.advance(ns);
+            return a.x;
         }
         double x = x0;
-        long n = 0;
+        long n = 0, wraps = 0;
+        // the targets that lie in [n, upto), from a walk that is at sample n in state x (not disturbed)
+        auto visit = [&](double xv, long nv, long upto) {
+            long w = wraps;
+            for (; tk < nt && targets[tk] < upto; ++tk) {      // each from the one before: a block whose every sample is a target stays linear
+                xv = state_at(xv, nv, targets[tk], &w);
+                nv = targets[tk];
+                xs[tk] = xv;
+                if (wraps_at) wraps_at[tk] = w;
+            }
+        };
         // few cycles in the block: the table would never be read
         static const bool no_map = std::getenv("GPSIQ_WALK_NOMAP") != nullptr;      // A/B knob: every cycle walked
-        const bool use_map = !no_map && std::fabs(c) * (double) ns > 24.0;
+        const double span = kind == 0 ? (double) GPSIQ_CA_SEQ_LEN : 1.0;
+        const bool use_map = !no_map && std::fabs(c) * (double) ns > 24.0 * span;
         if (!use_map) {
-            while (n < ns && (neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr))) {}
+            visit(x, n, ns);
+            while (n < ns && cycle(x, n, ns)) {}
             return x;
         }
-        if (!(neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr)) || n == ns) return x;      // to the first wrap
-        const double scale = neg ? 0x1p53 : 0x1p52, unit = neg ? 0x1p-53 : 0x1p-52;
-        const int64_t m_max = neg ? ((int64_t) 1 << 53) - 1 : ((int64_t) 1 << 52) - 1;
+        {   // to the first wrap
+            const double xs0 = x; const long n0 = n;
+            const bool wrapped = cycle(x, n, ns);
+            visit(xs0, n0, wrapped ? n : ns + 1);
+            if (!wrapped || n == ns) return x;
+            ++wraps;
+        }
+        const int uexp = kind == 0 ? 1023 + 9 : neg ? 1022 : 1023;   // biased exponent of the binade whose ulp is the state grid
+        const double scale = std::ldexp(1.0, 1075 - uexp), unit = std::ldexp(1.0, uexp - 1075);
+        const int64_t m_max = kind == 0 ? ((int64_t) GPSIQ_CA_SEQ_LEN << 43) - 1 : neg ? ((int64_t) 1 << 53) - 1 : ((int64_t) 1 << 52) - 1;
         // post-wrap states: [0, c] (positive addend) or [1 + c, 1) (negative), W units wide
         const int64_t W = (int64_t) (std::fabs(c) * scale) + 4;
         const int64_t base = neg ? ((int64_t) 1 << 53) - W : 0;
         int bshift = 0;
         while ((W >> bshift) >= kBuckets) ++bshift;
         Entry tab[kMaxEntries];
-        uint8_t bucket[kBuckets] = {};                                     // 0: no entry covers the whole bucket; else entry index + 1
+        uint8_t bucket[kBuckets] = {};                                // 0: no entry covers the whole bucket; else entry index + 1
         int ntab = 0;
         long min_steps = ns;                                          // shortest cycle seen
         int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
@@ -513,24 +505,31 @@ struct CarrierWalk {
             }
             if (e) {
                 if (e->steps > ns - n) break;                         // the block ends inside this cycle
-                m += e->inc; n += e->steps;
+                if (tk < nt && targets[tk] < n + e->steps) visit((double) m * unit, n, n + e->steps);
+                m += e->inc; n += e->steps; ++wraps;
                 continue;
             }
             // not in the table (or 1.0, outside its domain): walk the cycle, noting how far the start state may move
             x = (double) m * unit;
+            const double xc = x; const long nc = n;
             const bool memo = rel >= 0 && rel < W && ntab < kMaxEntries && (ntab == 0 || ns - n >= 2 * min_steps);
             if (!memo) {
-                if (!(neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr))) return x;
+                const bool wrapped = cycle(x, n, ns);
+                visit(xc, nc, wrapped ? n : ns + 1);
+                if (!wrapped) return x;
+                ++wraps;
                 m = (int64_t) (x * scale);
                 continue;
             }
-            Slack sl = {-m, m_max - m, neg ? 1022 : 1023, true};     // the start state itself stays in [0, 1)
+            Slack sl = {-m, m_max - m, uexp, true};                   // the start state itself stays inside the accumulator's range
             long ne = 0;
             const bool wrapped = neg ? descend<true>(x, ne, ns - n, &sl) : climb<true>(x, ne, ns - n, &sl);
             n += ne;
+            visit(xc, nc, wrapped ? n : ns + 1);
             if (!wrapped) return x;                                   // the block ended inside this cycle
+            ++wraps;
             const int64_t m2 = (int64_t) (x * scale);
-            if (sl.ok && sl.lo <= 0 && sl.hi >= 0 && x < 1.0) {
+            if (sl.ok && sl.lo <= 0 && sl.hi >= 0 && x < wrap && m2 <= m_max) {
                 Entry &t = tab[ntab++];
                 t.first = m + sl.lo; t.last = m + sl.hi; t.inc = m2 - m; t.steps = ne;
                 if (ne < min_steps) min_steps = ne;
@@ -545,18 +544,81 @@ struct CarrierWalk {
         }
         // the last, partial cycle
         x = (double) m * unit;
-        while (n < ns && (neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr))) {}
+        visit(x, n, ns);
+        while (n < ns && cycle(x, n, ns)) {}
         return x;
     }
 };
 
-}  // namespace
-
-static double carrier_after(double x0, double c, long ns)
+// One channel of one block.  ch.carr_phase is the double the block starts from (1.0 included, see below); q its quantised
+// form (quantize_one without carry_in, i.e. seeded from that double).  Returns the carrier phase the reference's accumulator
+// holds after the block (gps.c:2821-2826 nsamp times) and appends the samples where the double path takes another LUT entry or
+// sign than the closed form.  One walk of each accumulator serves both: the candidates are found first (without visiting
+// samples), and the walk that carries the phase to the end of the block reports the state at the candidate samples on its way.
+static double evaluate_block(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double delt, int nsamp, int block, int slot,
+                             CodeCache *codes, std::vector<gpsiq_patch_t> *out)
 {
-    CarrierWalk w;
-    w.setup(c);
-    return w.run(x0, ns);
+    const long ns = nsamp;
+    const double carr_inc = ch.f_carr * delt, code_inc = ch.f_code * delt;
+    NcoWalk cw;
+    cw.setup(carr_inc, 1);
+    if (ns <= 0) return ch.carr_phase;
+    // drift bounds at the end of the block, in units of the fixed-point formats (see the header)
+    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
+    const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
+    std::vector<long> t_carr, t_code, targets;
+    constexpr size_t kCap = 256;
+    bool every = false;
+    if (carr_inc != 0.0)          // a zero addend leaves both paths constant and equal
+        every |= !candidates(q.carr_phase, (uint64_t) q.carr_step, GPSIQ_CARR_FRAC_BITS - 9, w_carr, ns, kCap, &t_carr);
+    every |= !candidates(q.code_frac, q.code_step, GPSIQ_CODE_FRAC_BITS, w_code, ns, kCap, &t_code);
+    if (every) {
+        targets.resize((size_t) ns);
+        for (long n = 0; n < ns; ++n) targets[(size_t) n] = n;
+    } else {
+        targets.resize(t_carr.size() + t_code.size());
+        std::merge(t_carr.begin(), t_carr.end(), t_code.begin(), t_code.end(), targets.begin());
+        targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+    }
+    if (targets.empty()) return cw.run(ch.carr_phase, ns);
+    const int nt = (int) targets.size();
+    std::vector<double> xc((size_t) nt), xk;
+    std::vector<long> periods;
+    const double carr_end = cw.run(ch.carr_phase, ns, targets.data(), nt, xc.data());
+    const bool walk_code = every || !t_code.empty();
+    if (walk_code) {
+        NcoWalk kw;
+        kw.setup(code_inc, 0);
+        xk.resize((size_t) nt); periods.resize((size_t) nt);
+        (void) kw.run(ch.code_phase, targets[(size_t) nt - 1] + 1, targets.data(), nt, xk.data(), periods.data());
+    }
+    const uint8_t *ca = codes->get(ch.prn);
+    for (int k = 0; k < nt; ++k) {
+        const long n = targets[(size_t) k];
+        // fixed-point path (include/gpsiq.h)
+        const uint64_t P = (q.carr_phase + (uint64_t) q.carr_step * (uint64_t) n) & ((UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1);
+        const unsigned idx_f = (unsigned) (P >> (GPSIQ_CARR_FRAC_BITS - 9));
+        const u128 T = (u128) q.code_frac + (u128) q.code_step * (uint64_t) n;
+        const uint64_t A = (uint64_t) q.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+        const unsigned chip_f = (unsigned) (A % GPSIQ_CA_SEQ_LEN);
+        const long per_f = (long) (A / GPSIQ_CA_SEQ_LEN);
+        const unsigned neg_f = ca[chip_f] ^ nav_bit(ch, ((long) ch.icode + per_f) / 20);
+        // double path
+        unsigned idx_d = (unsigned) (int) std::floor(xc[(size_t) k] * 512.0);           // gps.c:2775
+        if (idx_d > 511u) idx_d = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
+        unsigned neg_d = neg_f;
+        if (walk_code) {
+            const unsigned chip_d = (unsigned) (int) xk[(size_t) k];                     // gps.c:2817
+            neg_d = ca[chip_d] ^ nav_bit(ch, ((long) ch.icode + periods[(size_t) k]) / 20);   // gps.c:2791-2811
+        }
+        if (idx_d != idx_f || neg_d != neg_f) {
+            gpsiq_patch_t p;
+            p.block = (uint32_t) block; p.sample = (uint32_t) n;
+            p.slot = (uint8_t) slot; p.neg = (uint8_t) neg_d; p.lut = (uint16_t) idx_d;
+            out->push_back(p);
+        }
+    }
+    return carr_end;
 }
 
 // ---- the host side of GPSIQ_NCO_REFERENCE as ONE pass per channel -------------------------------------------------
@@ -622,12 +684,10 @@ void RefWalk::run_channel(int i)
             // it when the slot gets another satellite, gps.c:2208-2214)
             if ((b == 0 && !have_in) || prev != d.prn) carr = d.carr_phase;
             const double start = carr;
-            // carr == 1.0: a wrap of the block before rounded up to one (see block_patches); the reference goes on from it
-            if (carr >= 0.0 && carr <= 1.0 && std::fabs(d.f_carr * delt) < 0.5)     // else quantize_one reports it below
-                carr = carrier_after(carr, d.f_carr * delt, nsamp);
             prev = d.prn;
-            // a start of exactly 1.0 is phase 0 of the closed form (mod 1); block_patches walks the double from 1.0 and
-            // patches sample 0, where the reference indexes its table at 512
+            // a start of exactly 1.0 (a wrap of the block before that rounded up to one) is phase 0 of the closed form
+            // (mod 1); the walk goes on from 1.0 as the reference does and sample 0, where the reference indexes its table
+            // at 512, is patched
             d.carr_phase = start == 1.0 ? 0.0 : start;
             const int qrc = quantize_one(d, delt, nsamp, nullptr, &qq, nullptr);
             d.carr_phase = start;
@@ -639,7 +699,7 @@ void RefWalk::run_channel(int i)
                 int slot = 0;                                            // device order: active channels first (gpsiq_set_descriptors)
                 for (int j = 0; j < i; ++j) slot += ch[(size_t) b * nchan + j].prn > 0;
                 mine.clear();
-                block_patches(d, qq, delt, nsamp, b, slot, &codes, &mine);
+                carr = evaluate_block(d, qq, delt, nsamp, b, slot, &codes, &mine);
                 if (!mine.empty()) {
                     pthread_mutex_lock(&pmu[i]);
                     patches[i].insert(patches[i].end(), mine.begin(), mine.end());

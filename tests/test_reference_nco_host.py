@@ -202,3 +202,25 @@ def test_wrap_to_wrap_table_chained_over_blocks(oracle):
     for b in range(nb):
         x = np.array([oracle.carrier_chain(x[i], d["f_carr"][b, i] * (1.0 / fs), ns) for i in range(16)])
     assert got.tobytes() == x.tobytes()
+
+
+@pytest.mark.parametrize("fs,ns,seed", [(10e6, 300000, 1), (25e6, 100000, 2), (2.6e6, 130000, 3)])
+def test_candidates_evaluated_from_the_wrap_tables(oracle, fs, ns, seed):
+    """Blocks made to have many candidate samples in both accumulators (carrier phases a hair off LUT boundaries, code phases a
+    hair off chip boundaries, addends that bring them back there again and again): the states the wrap-to-wrap walks report at
+    those samples -- carrier cycles and code periods -- give the reference's LUT index and sign at every one of them."""
+    rng = np.random.default_rng(seed)
+    d = synth_blocks(2, 16, seed=40 + seed)
+    k = rng.integers(0, 512, 16)
+    d["carr_phase"][0] = (k + rng.choice([1e-13, -1e-13, 3e-12, 0.0], 16)) / 512.0 % 1.0
+    d["code_phase"][:] = (rng.integers(0, 1023, (2, 16)) + rng.choice([1e-10, 2e-9, 0.0, 1.0 - 1e-10], (2, 16))) % 1023.0
+    f = rng.uniform(500.0, 6000.0, 16) * rng.choice([-1.0, 1.0], 16)
+    f[:4] = fs / 512.0 / rng.integers(3, 40, 4) * rng.choice([-1.0, 1.0], 4)        # a whole number of samples per LUT step: back on the boundary every time
+    d["f_carr"][:] = f
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    d["f_code"][:, 4:8] = fs / rng.integers(3, 30, 4)                               # a whole number of samples per chip
+    want, carr_want = float_chain(oracle, d, fs, ns, SC16)
+    got, carr, patches = product_chain(oracle, d, fs, ns, SC16)
+    assert np.array_equal(got, want)
+    assert np.array_equal(carr, carr_want)
+    assert len(patches) > 0
