@@ -714,7 +714,8 @@ void RefWalk::run_channel(int i)
 
 void RefWalk::run()
 {
-    parallel_for(nchan, nchan, 1, [](void *p, int i0, int i1) {
+    // a block or two (the drop-in block call): 16 channels x ~6 us here cost less than waking 15 pool threads
+    parallel_for(nchan, nblocks <= 2 ? 1 : nchan, 1, [](void *p, int i0, int i1) {
         RefWalk &w = *static_cast<RefWalk *>(p);
         for (int i = i0; i < i1; ++i) w.run_channel(i);
     }, this);

@@ -322,8 +322,41 @@ def make_config4_golden():
     print("config4_circle: 2999 / 5999 blocks, fit residual %.5f m" % resid, hashlib.sha256("".join(sha600).encode()).hexdigest())
 
 
+def make_config35_golden(which=("cfg3", "cfg5")):
+    """BASELINE configs 3 and 5 as the reference itself renders them: the reference program rebuilt at TX_SAMPLERATE
+    10 000 000 / 25 000 000 and MAX_CHAN 16 (oracle/_ref/gps-sim-ref-10M / -25M), static BASELINE position, 16 satellites in
+    view (tests/golden/synth_static16.21n), --iq16.  Config 3: -d 300 = 2 999 blocks of 10^6 samples (12 GB).  Config 5 is
+    8 GPUs x 450 s; the capture is the first GPU's share, -d 450 = 4 499 blocks of 2.5 * 10^6 samples (45 GB) -- a later
+    share starts from a carrier state only the reference's own run up to there could supply.  SHA-256 of every block and
+    the first 4096 elements of a few; the streams go through a pipe and are never stored."""
+    import tempfile
+    from _program import program, program_block_digests
+    out = {}
+    for name, suffix, fs, seconds, nblocks in (("cfg3", "10M", 10000000, 300, 2999), ("cfg5", "25M", 25000000, 450, 4499)):
+        if name not in which:
+            continue
+        ref = program("gps-sim-ref-" + suffix)
+        assert ref, f"oracle/_ref/gps-sim-ref-{suffix} missing (make -C oracle progs)"
+        keep = (0, 1, 299, 300, 301, nblocks - 1)
+        with tempfile.TemporaryDirectory() as td:
+            sha, heads = program_block_digests(ref, td, None, seconds, nblocks, fs=fs, keep=keep, timeout=3600)
+        out[name + "_sha16"] = np.array(sha)
+        out[name + "_head_blocks"] = np.array(sorted(heads))
+        out[name + "_heads"] = np.stack([heads[k] for k in sorted(heads)])
+        out[name + "_fs"] = fs
+        print(name, nblocks, "blocks", hashlib.sha256("".join(sha).encode()).hexdigest(), flush=True)
+    path = os.path.join(HERE, "program_config35_static.npz")
+    if os.path.exists(path):                       # the two captures can be made one at a time
+        old = dict(np.load(path))
+        old.update(out)
+        out = old
+    np.savez_compressed(path, **out)
+
+
 if __name__ == "__main__":
-    if "--config4-only" in sys.argv:
+    if "--config35-only" in sys.argv:
+        make_config35_golden([a for a in sys.argv[1:] if a in ("cfg3", "cfg5")] or ("cfg3", "cfg5"))
+    elif "--config4-only" in sys.argv:
         make_config4_golden()
     elif "--program-only" in sys.argv:
         make_program_golden()
@@ -347,3 +380,4 @@ if __name__ == "__main__":
         make_alloc_golden()
         make_program_golden()
         make_config4_golden()
+        make_config35_golden()
