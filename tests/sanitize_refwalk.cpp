@@ -1,0 +1,69 @@
+// sanitize_refwalk.cpp -- the one-pass reference walker consumed piece by piece while it runs (what generate_reference and
+// gpsiq_generate_batch_multi do on the device side), host only, for ThreadSanitizer / ASan + UBSan builds: the pieces taken
+// while the walkers run must add up to what one call over the whole timeline gives.  TEST INFRASTRUCTURE.
+#include "gpsiq_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+using namespace gpsiq;
+
+static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
+
+int main()
+{
+    const int nb = 72, nc = 12, ns = 30000;
+    const double fs = 10.0e6, delt = 1.0 / fs;
+    std::mt19937_64 rng(11);
+    std::uniform_real_distribution<double> uf(-5000.0, 5000.0), up(0.0, 1.0);
+    std::vector<gpsiq_chan_t> ch((size_t) nb * nc);
+    for (int b = 0; b < nb; ++b)
+        for (int c = 0; c < nc; ++c) {
+            gpsiq_chan_t &e = ch[(size_t) b * nc + c];
+            std::memset(&e, 0, sizeof e);
+            e.prn = (c == 3 && b >= 40 && b < 55) ? 0 : (c == 5 && b >= 70) ? 29 : 1 + c;      // a slot going out of view, one re-allocated
+            e.f_carr = b == 0 ? uf(rng) : ch[(size_t) (b - 1) * nc + c].f_carr + 0.3;
+            e.f_code = 1.023e6 + e.f_carr / 1540.0;
+            // phases a hair off LUT / chip boundaries: plenty of candidates, some patches
+            e.carr_phase = ((double) (rng() % 512) + 1e-12) / 512.0;
+            e.code_phase = (double) (rng() % 1023) + 1e-9;
+            if (c % 3 == 0) {       // a whole number of samples per LUT step and per chip, phases a hair below a boundary: patches
+                e.f_carr = fs / 512.0 / (double) (5 + c);
+                e.f_code = fs / 25.0;
+                e.carr_phase = (double) (rng() % 512) / 512.0 + 0x1p-12 - 0x1p-50;
+                e.code_phase = (double) (1 + rng() % 6) - 0x1p-41;
+            }
+            e.gain = 0.5; e.iword = (int) (rng() % 50); e.ibit = (int) (rng() % 30); e.icode = (int) (rng() % 20);
+            for (int k = 0; k < GPSIQ_N_DWRD; ++k) e.dwrd[k] = (uint32_t) rng() & 0x3fffffffu;
+        }
+    // one call over the whole timeline
+    std::vector<gpsiq_qchan_t> q0((size_t) nb * nc), q1((size_t) nb * nc);
+    std::vector<gpsiq_patch_t> p0;
+    double carr0[GPSIQ_MAX_CHAN];
+    int prn0[GPSIQ_MAX_CHAN];
+    if (reference_timeline(ch.data(), nb, nc, delt, ns, q0.data(), &p0, carr0, prn0) != GPSIQ_OK) { std::fprintf(stderr, "timeline: %s\n", gpsiq_last_error()); return 1; }
+    // the same, consumed in ragged pieces while the walkers run
+    for (int rep = 0; rep < 2; ++rep) {
+        std::vector<int> ends = {7, 8, 31, 64, 65, nb};      // ragged, incl. a piece of one block
+        RefWalk w(ch.data(), nb, nc, delt, ns, q1.data(), nullptr, nullptr, ends);
+        pthread_t th;
+        if (pthread_create(&th, nullptr, run_walk, &w) != 0) return 1;
+        std::vector<gpsiq_patch_t> all, piece;
+        for (size_t k = 0; k < w.npieces(); ++k) {
+            if (w.wait_piece(k) != GPSIQ_OK) { std::fprintf(stderr, "piece %zu: %s\n", k, w.err); return 1; }
+            w.take_patches(k, &piece, true);
+            const int b0 = k ? w.ends[k - 1] : 0;
+            for (gpsiq_patch_t p : piece) { p.block += (uint32_t) b0; all.push_back(p); }
+            // the piece's descriptors are final as soon as the piece is complete
+            if (std::memcmp(&q1[(size_t) b0 * nc], &q0[(size_t) b0 * nc], (size_t) (w.ends[k] - b0) * nc * sizeof(gpsiq_qchan_t)) != 0) { std::fprintf(stderr, "piece %zu: descriptors differ\n", k); return 1; }
+        }
+        pthread_join(th, nullptr);
+        if (all.size() != p0.size() || (all.size() && std::memcmp(all.data(), p0.data(), all.size() * sizeof(gpsiq_patch_t)) != 0)) { std::fprintf(stderr, "patches differ: %zu vs %zu\n", all.size(), p0.size()); return 1; }
+        for (int c = 0; c < nc; ++c)
+            if (w.carr_end[c] != carr0[c] || w.last_prn[c] != prn0[c]) { std::fprintf(stderr, "end state differs in slot %d\n", c); return 1; }
+    }
+    if (p0.empty()) { std::fprintf(stderr, "the scenario should have patches\n"); return 1; }
+    std::printf("ok\n");
+    return 0;
+}

@@ -88,6 +88,25 @@ def test_host_half_under_sanitizers(tmp_path, san):
         assert r.returncode == 0 and r.stdout.strip() == "ok" and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_reference_walker_consumed_in_pieces_under_sanitizers(tmp_path, san):
+    """The one-pass walker of GPSIQ_NCO_REFERENCE (one host thread per channel through the whole timeline) with a consumer
+    that takes every piece as soon as all channels are through it -- what the device side does while it renders -- under
+    ThreadSanitizer and ASan + UBSan: the pieces add up to the single call's descriptors, patches and end state."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "multi-sdr-gps-sim_amd", "csrc")
+    exe = str(tmp_path / "sanitize_refwalk")
+    flags = ["-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-I" + os.path.join(root, "include"), "-I" + csrc]
+    if "undefined" in san:
+        flags.append("-fno-sanitize-recover=undefined")
+    b = subprocess.run(["g++", *flags, "-o", exe, os.path.join(root, "tests", "sanitize_refwalk.cpp"), os.path.join(csrc, "gpsiq_host.cpp"),
+                        os.path.join(csrc, "gpsiq_exact.cpp"), "-lpthread", "-lm"], capture_output=True, text=True)
+    if b.returncode != 0:
+        pytest.skip("no sanitizer toolchain / runtime here: " + b.stderr[-300:])
+    r = run_sanitized([exe], timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.strip() == "ok" and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
 def test_fifo_header_matches_reference_api():
     """Same nine entry points and the same struct fields as the reference's fifo.h:19-63."""
     txt = open(os.path.join(HOST, "fifo.h")).read()
