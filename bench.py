@@ -21,12 +21,17 @@ all-gather at set-up).  No collective touches the data path (weak scaling: per-G
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     — algorithmic IQ bytes per launch / mean launch duration (HIP events on the launch
                  stream) against the 8 TB/s HBM peak,
+  counters     — instruction-mix-independent fractions of the dominant kernel from committed rocprofv3 PMC passes of this
+                 command (profiles/pmc_counters.json): VALU issue fraction, LDS busy, LDS bank-conflict ratio,
+  reference_nco — the model whose output is the reference's own (GPSIQ_NCO_REFERENCE): whole batch call at the
+                 headline workload and at 25 Msps, host side alone, kernel alone, which of the two bounds it (N = 1),
   cpu_baseline — the reference's own loop (oracle/_ref, kind "reference") or our port of it
                  (oracle/, kind "port") timed on this host, 1 core, bounded sample (N = 1 only),
   end_to_end   — the same per-GPU block count from scratch on every rank: host refresh of its own
                  blocks (gpsiq_refresh_epochs) -> quantise -> carrier seed exchange -> upload -> kernel,
                  once as one serial batch and once as a stream of rounds with the host side of the next
-                 round overlapping the kernel of this one (end_to_end.streamed),
+                 round overlapping the kernel of this one (end_to_end.streamed, with every rank's host and kernel
+                 time per round and which of the two it is bound by),
   extra        — short legs for the other BASELINE configs (each with its own roofline), the
                  host-destination and single-block drop-in calls, GPSIQ_NCO_REFERENCE, first-launch times.
 """
