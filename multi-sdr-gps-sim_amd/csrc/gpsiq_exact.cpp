@@ -409,7 +409,15 @@ struct NcoWalk {
             if (y < 0.0) {
                 const double r = y + 1.0;
                 if (kNote) {
-                    sl->note(-y);                                     // y's own rounding depends on its binade
+                    // y's own rounding depends on its binade -- unless nothing is rounded: with x in the addend's own binade
+                    // both operands are multiples of that binade's ulp and |x + c| < 2^E, so the sum is exact for this x and
+                    // for every translated one (which stays in x's binade, see the note on x); only its sign has to hold
+                    if ((int64_t) (bits_of(x) >> 52) == ec) {
+                        const int64_t h = (int64_t) (-y * 0x1p53) - 2;            // y + d*U < 0, two units short
+                        if (h < sl->hi) sl->hi = h;
+                    } else {
+                        sl->note(-y);
+                    }
                     const double bb = r - y, err = (y - (r - bb)) + (1.0 - bb);
                     if (r >= 1.0 || std::fabs(err) == 0x1p-54) sl->ok = false;   // rounded up to 1.0, or a tie on the grid of [0.5, 1)
                     else sl->note(r);
@@ -417,8 +425,17 @@ struct NcoWalk {
                 x = r;
                 return true;
             }
+            if (kNote) {
+                // x <= 2|c| (and x >= |c|, the sum is not negative): x + c is exact (Sterbenz), for this x and for every
+                // translated one, whatever binade the small difference falls into -- it only has to stay non-negative
+                if (x <= -2.0 * c) {
+                    const int64_t l = 2 - (int64_t) (y * 0x1p53);
+                    if (l > sl->lo) sl->lo = l;
+                } else {
+                    sl->note(y);
+                }
+            }
             x = y;
-            if (kNote) sl->note(x);
             if (n == ns) return false;
         }
     }
