@@ -268,7 +268,7 @@ struct CodeCache {
 // invariant is the wrap itself when it is an exact tie (the kept bit's parity moves with d): such a cycle is never tabled.
 // The addends change with every block (gps.c:2042-2043), so a table lives for one block.
 struct NcoWalk {
-    struct Piece { int64_t dm, k, rem, kdm, span; };
+    struct Piece { int64_t dm, k, rem, kdm, span; bool tie; };
     static constexpr int kLow = 4;                        // binades ec .. ec + kLow: plain additions
     int     kind = 1;                                     // 0: code phase (wrap at 1023 chips), 1: carrier phase (wrap into [0,1))
     double  c = 0.0, thr = 0.0, wrap = 1.0;
@@ -319,9 +319,19 @@ struct NcoWalk {
         for (int s = kLow + 1; s <= top && !general; ++s) {
             int64_t dm = mc >> s;                         // rnd(c / ulp) in ulps of the binade, see Nco::build_piece
             const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
-            if (rem > half) ++dm;
-            else if (rem == half) general = true;         // ties to even depend on x's parity: the probing walk
             Piece &p = T[s];
+            p.tie = false;
+            if (rem > half) ++dm;
+            else if (rem == half) {
+                // c / ulp ends in exactly one half (one addend in 2^s): the sum goes to the even neighbour.  From an even
+                // mantissa that is a constant even step, and one addition makes the mantissa even: the walks below take that
+                // one addition for real and the run after it from the table.  A translated cycle (the wrap-to-wrap table)
+                // keeps its parities as long as the state unit is an even multiple of this binade's ulp -- not so in the top
+                // binade of a descending carrier or of the code phase, whose ulp IS the unit: the probing walk there.
+                if (s == top && (neg || kind == 0)) general = true;
+                p.tie = true;
+                dm += dm & 1;
+            }
             p.dm = dm;
             // the run ends on the last mantissa of the binade -- or, in the code phase's top binade [512, 1024), short of
             // 1023 = 1023 * 2^43 ulps; downwards it must stay strictly above the binade's first value (Nco::build_piece)
@@ -349,7 +359,8 @@ struct NcoWalk {
             const Piece &p = T[(int64_t) (bx >> 52) - ec];
             const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1)), off = mx - one52;
             int64_t run, moved;
-            if (off <= p.rem) { run = p.k; moved = p.kdm; }
+            if (p.tie && (mx & 1)) { run = 0; moved = 0; }            // an odd mantissa in a tie binade: one real addition first
+            else if (off <= p.rem) { run = p.k; moved = p.kdm; }
             else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
             else if (off > p.span) { run = 0; moved = 0; }            // code phase within one step of 1023
             else { run = (p.span - off) / p.dm; moved = run * p.dm; }
@@ -391,7 +402,8 @@ struct NcoWalk {
             const Piece &p = T[(int64_t) (bx >> 52) - ec];
             const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1)), off = (2 * one52 - 1) - mx;
             int64_t run, moved;
-            if (off <= p.rem) { run = p.k; moved = p.kdm; }
+            if (p.tie && (mx & 1)) { run = 0; moved = 0; }            // an odd mantissa in a tie binade: one real addition first
+            else if (off <= p.rem) { run = p.k; moved = p.kdm; }
             else if (off <= p.rem + p.dm) { run = p.k - 1; moved = p.kdm - p.dm; }
             else if (off > p.span) { run = 0; moved = 0; }            // on the binade's first value: the next sum is rounded underneath
             else { run = (p.span - off) / p.dm; moved = run * p.dm; }
@@ -450,11 +462,29 @@ struct NcoWalk {
     }
 
     // wrap-to-wrap table.  Entries are valid each on its own (overlaps are harmless) and are found through 1024 buckets
-    // over the range of post-wrap states: a bucket wholly inside an entry names it (one shift and two loads per cycle, no
-    // search: the states are as good as random, a binary search would mispredict at every level); the few buckets that
-    // straddle an edge fall back to a scan.
+    // over the range of post-wrap states: a bucket wholly inside an entry carries its increment and sample count (one shift,
+    // one load and an add per cycle, no search: the states are as good as random, a binary search would mispredict at every
+    // level); the few buckets that straddle an edge fall back to a scan of the entries.
     struct Entry { int64_t first, last, inc; long steps; };
+    struct Bucket { int64_t inc; long steps; };
     static constexpr int kMaxEntries = 64, kBuckets = 1024;
+
+    // A function of its own (and not inlined): in the middle of run() the compiler keeps the state in memory, and the store
+    // forwarding on it would cost more than the look-up itself.
+    __attribute__((noinline)) static void hits(const Bucket *bkt, int64_t base, int64_t W, int bshift, long limit,
+                                               int64_t *m_io, long *n_io, long *wraps_io)
+    {
+        int64_t m = *m_io;
+        long n = *n_io, wraps = *wraps_io;
+        for (;;) {
+            const uint64_t rel = (uint64_t) (m - base);
+            if (rel >= (uint64_t) W) break;
+            const Bucket &bk = bkt[rel >> bshift];
+            if (bk.steps == 0 || n + bk.steps > limit) break;
+            m += bk.inc; n += bk.steps; ++wraps;
+        }
+        *m_io = m; *n_io = n; *wraps_io = wraps;
+    }
 
     // The state after ns samples from x0.  targets[nt] (ascending, < ns): samples whose state is wanted as well -> xs[nt]
     // and, if wraps_at is given, the number of wraps before each (code: code periods completed, gps.c:2791-2793).
@@ -505,21 +535,21 @@ struct NcoWalk {
         int bshift = 0;
         while ((W >> bshift) >= kBuckets) ++bshift;
         Entry tab[kMaxEntries];
-        uint8_t bucket[kBuckets] = {};                                // 0: no entry covers the whole bucket; else entry index + 1
+        Bucket bkt[kBuckets];                                         // steps == 0: no entry covers the whole bucket
+        for (int i = 0; i < kBuckets; ++i) bkt[i].steps = 0;
         int ntab = 0;
         long min_steps = ns;                                          // shortest cycle seen
         int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
         for (;;) {
+            // the common case, cycle after cycle: the state's bucket lies wholly inside one entry and names its increment.
+            // Stops before a cycle that would pass the end of the block or hold the next target.
+            hits(bkt, base, W, bshift, tk < nt && targets[tk] < ns ? targets[tk] : ns, &m, &n, &wraps);
             if (n >= ns) return (double) m * unit;
             const int64_t rel = m - base;
             const Entry *e = nullptr;
-            if (rel >= 0 && rel < W) {
-                const int id = bucket[rel >> bshift];
-                if (id) e = &tab[id - 1];
-                else
-                    for (int i = 0; i < ntab; ++i)
-                        if (tab[i].first <= m && m <= tab[i].last) { e = &tab[i]; break; }
-            }
+            if (rel >= 0 && rel < W)                                  // a bucket that straddles an edge, a target inside the cycle, the block's end
+                for (int i = 0; i < ntab; ++i)
+                    if (tab[i].first <= m && m <= tab[i].last) { e = &tab[i]; break; }
             if (e) {
                 if (e->steps > ns - n) break;                         // the block ends inside this cycle
                 if (tk < nt && targets[tk] < n + e->steps) visit((double) m * unit, n, n + e->steps);
@@ -555,7 +585,7 @@ struct NcoWalk {
                 int64_t k0 = f <= 0 ? 0 : ((f - 1) >> bshift) + 1;    // first bucket starting at or after `first`
                 int64_t k1 = l >= W ? kBuckets - 1 : ((l + 1) >> bshift) - 1;  // last bucket ending at or before `last`
                 if (k1 > kBuckets - 1) k1 = kBuckets - 1;
-                for (int64_t k = k0; k <= k1; ++k) bucket[k] = (uint8_t) ntab;
+                for (int64_t k = k0; k <= k1; ++k) { bkt[k].inc = t.inc; bkt[k].steps = ne; }
             }
             m = m2;
         }
