@@ -527,6 +527,17 @@ static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nbloc
     return GPSIQ_OK;
 }
 
+// Blocks per piece of a long device-destination batch in the fixed-point model: ~1 ms of kernel, a few hundred microseconds of
+// host work per piece.  GPSIQ_BATCH_PIECE_BLOCKS overrides (read per call); <= 0: one piece.
+static int batch_piece_blocks(int nblocks, int nsamp)
+{
+    long n = nsamp > 0 ? ((long) 1024 * 260000) / nsamp : 1024;
+    if (n > 1024) n = 1024;
+    if (n < 32) n = 32;
+    if (const char *e = std::getenv("GPSIQ_BATCH_PIECE_BLOCKS")) n = std::atoi(e);
+    return n > 0 && 2 * n <= nblocks ? (int) n : nblocks;            // fewer than two pieces' worth: one piece
+}
+
 static int check_gen_args(const gpsiq_ctx *c, const void *ch, const void *dst, int nblocks, int nchan, int nsamp, double fs, int sample_size)
 {
     if (!c || (!ch && nblocks) || (!dst && nblocks && nsamp)) return fail(GPSIQ_E_ARG, "null argument");
@@ -823,14 +834,43 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         cont0[i] = ch[i].prn > 0 && c->carry_prn[i] == ch[i].prn && c->handed[i] == ch[i].carr_phase;
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     int prev_prn[GPSIQ_MAX_CHAN] = {};
-    int qrc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
-    if (qrc) return qrc;
-    const double t2 = trace ? wall_ms() : 0.0;
-    rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
-    if (rc) return rc;
-    if (trace)
-        std::fprintf(stderr, "[gpsiq trace] batch %d blocks: quantise + carrier prefix %.2f ms, upload+kernel%s %.2f ms\n",
-                     nblocks, t2 - t0, dst_is_device ? "" : "+D2H", wall_ms() - t2);
+    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
+    const int piece = batch_piece_blocks(nblocks, nsamp);
+    if (dst_is_device && !(blk_bytes & 15) && !((uintptr_t) dst & 3) && piece < nblocks && nsamp > 0) {
+        // A long batch into device memory: quantise, validate and upload piece k+1 (host threads) under the kernel of
+        // piece k.  The carrier prefix goes from piece to piece exactly as it goes from call to call.
+        bool cont[GPSIQ_MAX_CHAN];
+        uint64_t seed[GPSIQ_MAX_CHAN];
+        for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }
+        for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK; b0 += piece) {
+            const int nb = nblocks - b0 < piece ? nblocks - b0 : piece;
+            gpsiq_qchan_t *qp = q.data() + (size_t) b0 * nchan;
+            rc = quantize_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, cont, seed, qp, carry, prev_prn);
+            if (rc == GPSIQ_OK) rc = gpsiq_set_descriptors(c, qp, nb, nchan);
+            if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, c->stream, kAuto);
+            for (int i = 0; i < nchan; ++i) {
+                // the next piece continues a slot while it keeps its PRN and re-seeds it otherwise, as inside one timeline
+                const gpsiq_chan_t *next = b0 + nb < nblocks ? &ch[(size_t) (b0 + nb) * nchan + i] : nullptr;
+                cont[i] = next && next->prn > 0 && prev_prn[i] == next->prn;
+                seed[i] = carry[i];
+            }
+        }
+        char err[400] = "";
+        if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
+        const int src = gpsiq_synchronize(c, c->stream);              // on every path: the kernels write the caller's buffer
+        if (rc != GPSIQ_OK) return fail(rc, "%s", err);
+        if (src != GPSIQ_OK) return src;
+        if (trace) std::fprintf(stderr, "[gpsiq trace] batch %d blocks in pieces of %d: whole call %.2f ms\n", nblocks, piece, wall_ms() - t0);
+    } else {
+        int qrc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
+        if (qrc) return qrc;
+        const double t2 = trace ? wall_ms() : 0.0;
+        rc = run_to_host_or_device(c, q.data(), nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
+        if (rc) return rc;
+        if (trace)
+            std::fprintf(stderr, "[gpsiq trace] batch %d blocks: quantise + carrier prefix %.2f ms, upload+kernel%s %.2f ms\n",
+                         nblocks, t2 - t0, dst_is_device ? "" : "+D2H", wall_ms() - t2);
+    }
     for (int i = 0; i < nchan; ++i) {
         c->carry_prn[i] = prev_prn[i];
         c->carry[i] = carry[i];

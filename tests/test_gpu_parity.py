@@ -568,3 +568,31 @@ def test_launches_of_one_set_on_two_streams_are_both_waited_for(ctx, oracle):
     ctx.set_descriptors(first)
     alone = run_device(ctx, first, ns, SC08, "auto")
     assert np.array_equal(got, alone)
+
+
+@pytest.mark.parametrize("piece", ["2", "5", "0"])
+def test_device_batch_quantised_and_rendered_in_pieces(ctx, oracle, monkeypatch, piece):
+    """A long gpsiq_generate_batch into device memory quantises, validates and uploads piece k+1 under the kernel of piece k:
+    whatever the piece length (here forced to 2 / 5 blocks / one piece) the blocks are the oracle's with the exact carrier
+    prefix -- slots going out of view and coming back re-seed inside and across pieces -- and the phase handed out chains
+    the next call."""
+    import torch
+    monkeypatch.setenv("GPSIQ_BATCH_PIECE_BLOCKS", piece)
+    fs, ns, nb, nc = 2.6e6, 26000, 13, 9
+    d = synth_blocks(nb, nc, seed=58)
+    d["prn"][3:6, 2] = 0                       # out of view over a piece edge, back with its own phase
+    d["carr_phase"][6:, 2] = 0.5625
+    d["prn"][4:, 5] = 31                       # re-allocated at a piece edge (pieces of 2) / inside a piece (pieces of 5)
+    d["carr_phase"][4:, 5] = 0.1875
+    qo = oracle.quantize_blocks(d, fs, ns)
+    for ss in (SC08, SC16):
+        want = np.stack([oracle.block_fixed(qo[b], ns, ss) for b in range(nb)])
+        buf = torch.zeros(nb * 2 * ns * ss, dtype=torch.uint8, device="cuda")
+        carr = np.zeros(nc)
+        ctx.generate_batch(d[:10], ns, fs, ss, device_ptr=buf.data_ptr(), carr_out=carr)
+        d2 = d[10:].copy()
+        d2["carr_phase"][0] = carr
+        ctx.generate_batch(d2, ns, fs, ss, device_ptr=buf.data_ptr() + 10 * 2 * ns * ss)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().view(np.int8 if ss == SC08 else np.int16).reshape(nb, 2 * ns)
+        assert np.array_equal(got, want), ss
