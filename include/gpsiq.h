@@ -257,7 +257,9 @@ int gpsiq_wait(gpsiq_ctx_t *ctx);
  * blocks continue exactly, re-seeding a slot from its carr_phase only when its prn changes.
  * dst receives nblocks*2*nsamp elements; dst_is_device != 0 means dst is a device
  * pointer on the context's device (no D2H).  carr_phase_out[nchan] (may be NULL) receives
- * the carrier phase after the last block, to be put into the next batch's block 0. */
+ * the carrier phase after the last block, to be put into the next batch's block 0.
+ * A long batch is worked through in pieces, the host side of piece k+1 (quantiser or, in GPSIQ_NCO_REFERENCE, the
+ * carrier walk) under the kernel of piece k; the call returns when everything has landed. */
 int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, int dst_is_device, double *carr_phase_out);
