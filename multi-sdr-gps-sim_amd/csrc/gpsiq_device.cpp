@@ -827,7 +827,6 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out);
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
-    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
     // continue a previous call exactly where the caller hands back what it was given
     bool cont0[GPSIQ_MAX_CHAN];
     for (int i = 0; i < nchan; ++i)
@@ -842,9 +841,10 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         bool cont[GPSIQ_MAX_CHAN];
         uint64_t seed[GPSIQ_MAX_CHAN];
         for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }
+        std::vector<gpsiq_qchan_t> q((size_t) piece * (size_t) nchan);          // one piece's worth, reused (gpsiq_set_descriptors copies it out)
         for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK; b0 += piece) {
             const int nb = nblocks - b0 < piece ? nblocks - b0 : piece;
-            gpsiq_qchan_t *qp = q.data() + (size_t) b0 * nchan;
+            gpsiq_qchan_t *qp = q.data();
             rc = quantize_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, cont, seed, qp, carry, prev_prn);
             if (rc == GPSIQ_OK) rc = gpsiq_set_descriptors(c, qp, nb, nchan);
             if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, c->stream, kAuto);
@@ -862,6 +862,7 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         if (src != GPSIQ_OK) return src;
         if (trace) std::fprintf(stderr, "[gpsiq trace] batch %d blocks in pieces of %d: whole call %.2f ms\n", nblocks, piece, wall_ms() - t0);
     } else {
+        std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
         int qrc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
         if (qrc) return qrc;
         const double t2 = trace ? wall_ms() : 0.0;
