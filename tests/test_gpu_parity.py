@@ -596,3 +596,35 @@ def test_device_batch_quantised_and_rendered_in_pieces(ctx, oracle, monkeypatch,
         torch.cuda.synchronize()
         got = buf.cpu().numpy().view(np.int8 if ss == SC08 else np.int16).reshape(nb, 2 * ns)
         assert np.array_equal(got, want), ss
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_an_error_in_a_late_piece_of_a_batch(ctx, oracle, monkeypatch, mode):
+    """A batch that is worked through in pieces (both NCO models) and has a descriptor outside the NCO format in a LATE
+    piece: the call reports it (the earlier pieces are already on the device, everything queued is drained before the
+    call returns), and the context goes on working."""
+    import torch
+    monkeypatch.setenv("GPSIQ_BATCH_PIECE_BLOCKS", "3")
+    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "3")
+    fs, ns, nb, nc = 2.6e6, 26000, 11, 6
+    d = synth_blocks(nb, nc, seed=91)
+    bad = d.copy()
+    bad["f_code"][8, 2] = 0.0
+    buf = torch.zeros(nb * 2 * ns, dtype=torch.uint8, device="cuda")
+    ctx.set_nco_mode(mode)
+    try:
+        with pytest.raises(gpsiq.GpsiqError) as ei:
+            ctx.generate_batch(bad, ns, fs, SC08, device_ptr=buf.data_ptr())
+        assert "block" in str(ei.value)
+        torch.cuda.synchronize()
+        if mode == 0:
+            got = ctx.generate_batch(d, ns, fs, SC08)
+            qo = oracle.quantize_blocks(d, fs, ns)
+            for b in (0, 5, 10):
+                assert np.array_equal(got[b], oracle.block_fixed(qo[b], ns, SC08)), b
+        else:
+            got = ctx.generate_batch(d[:4], ns, fs, SC08)
+            o, _ = oracle.block_float(d[0], ns, fs, SC08)
+            assert np.array_equal(got[0], o)
+    finally:
+        ctx.set_nco_mode(0)
