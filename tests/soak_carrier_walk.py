@@ -1,4 +1,4 @@
-"""Time-bounded random soak of the carrier chain's wrap-to-wrap table (csrc/gpsiq_exact.cpp, CarrierWalk) against the
+"""Time-bounded random soak of the carrier chain's wrap-to-wrap table (csrc/gpsiq_exact.cpp, NcoWalk) against the
 plain loop of gps.c:2821-2826 (oracle_carrier_chain).  CPU only.   python tests/soak_carrier_walk.py [seconds] [seed]"""
 import os
 import sys

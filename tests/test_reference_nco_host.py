@@ -78,7 +78,7 @@ def test_carrier_walk_fuzz_against_the_plain_loop(oracle):
         ns = int(rng.integers(1, 30000))
         d = synth_blocks(1, 16, seed=1000 + it)
         mag = 10.0 ** rng.uniform(-13.0, np.log10(0.49 * fs), 16)
-        if it % 3 == 1:                                   # Doppler-sized addends: the chain's own walk (carrier_after)
+        if it % 3 == 1:                                   # Doppler-sized addends: the chain's own walk (NcoWalk)
             mag = rng.uniform(1.0, 9000.0, 16)
         d["f_carr"][0] = mag * rng.choice([-1.0, 1.0], 16)
         if it % 5 == 0:                                   # addends that are exact binary fractions of a cycle: ties
@@ -96,7 +96,7 @@ def test_carrier_walk_fuzz_against_the_plain_loop(oracle):
 
 def test_carrier_wrap_that_rounds_to_one(oracle):
     """A negative addend taking the phase a hair below zero: the wrap y + 1.0 rounds to exactly 1.0 (the reference
-    then indexes its table at 512, see block_patches) and the walk goes on from 1.0, outside every binade of [0, 1)."""
+    then indexes its table at 512, see evaluate_block) and the walk goes on from 1.0, outside every binade of [0, 1)."""
     fs, ns = 2.6e6, 5000
     d = synth_blocks(1, 16, seed=9)
     i = np.arange(16)
@@ -163,7 +163,7 @@ def chain_case(oracle, fs, ns, f_carr, x0):
 
 
 def test_wrap_to_wrap_table_against_the_plain_loop(oracle):
-    """The carrier chain's table of whole cycles (csrc/gpsiq_exact.cpp, CarrierWalk): blocks of hundreds of carrier
+    """The carrier chain's table of whole cycles (csrc/gpsiq_exact.cpp, NcoWalk): blocks of hundreds of carrier
     cycles, where all but the first dozen or two cycles are look-ups -- Doppler-sized addends of both signs, addends
     that are short binary fractions (every rounding a tie or exact), start phases on and next to binade edges and on
     the post-wrap grid, whole-run lengths at all four sample rates."""
