@@ -269,7 +269,10 @@ struct CodeCache {
 // The addends change with every block (gps.c:2042-2043), so a table lives for one block.
 struct NcoWalk {
     struct Piece { int64_t dm, k, rem, kdm, span; bool tie; };
-    static constexpr int kLow = 4;                        // binades ec .. ec + kLow: plain additions
+#ifndef GPSIQ_WALK_KLOW
+#define GPSIQ_WALK_KLOW 4
+#endif
+    static constexpr int kLow = GPSIQ_WALK_KLOW;          // binades ec .. ec + kLow: plain additions (scripts/ubench_walk.cpp A/Bs it)
     int     kind = 1;                                     // 0: code phase (wrap at 1023 chips), 1: carrier phase (wrap into [0,1))
     double  c = 0.0, thr = 0.0, wrap = 1.0;
     int64_t ec = 0;
