@@ -251,8 +251,8 @@ struct CodeCache {
 // Nco::advance costs a dozen dependent pieces per carrier cycle / code period, ~70 ns.  For the common case (a normal
 // addend well below the accumulator's range, no exact-tie binade) NcoWalk has the same walk in a leaner form -- between
 // two wraps the phase climbs (or, with a negative carrier addend, descends) through the binades from the addend's own to
-// the top one; the lowest five hold 1, 2, 4, 8, 16 steps: plain additions there cost less than a table piece each; above
-// them one piece per binade, with the run length from a per-binade table -- and, on top of it, a map from wrap to wrap.
+// the top one; the lowest three hold 1, 2, 4 steps: plain additions there cost less than a table piece each (five binades
+// measured 5 % slower on the GPU box's host, scripts/ubench_walk.cpp); above them one piece per binade, with the run length from a per-binade table -- and, on top of it, a map from wrap to wrap.
 // Right after a wrap the state is a multiple of U = the ulp of the binade the wrap is taken in (carrier: 2^-52 for
 // y - 1.0 with y in [1, 2), 2^-53 for y + 1.0 in [0.5, 1); code: 2^-43 for y - 1023.0 with y in [512, 1024)).  Start the
 // same cycle from x0 + d*U instead of x0: as long as every RESULT of the cycle's additions stays inside the binade it had
@@ -270,7 +270,7 @@ struct CodeCache {
 struct NcoWalk {
     struct Piece { int64_t dm, k, rem, kdm, span; bool tie; };
 #ifndef GPSIQ_WALK_KLOW
-#define GPSIQ_WALK_KLOW 4
+#define GPSIQ_WALK_KLOW 2
 #endif
     static constexpr int kLow = GPSIQ_WALK_KLOW;          // binades ec .. ec + kLow: plain additions (scripts/ubench_walk.cpp A/Bs it)
     int     kind = 1;                                     // 0: code phase (wrap at 1023 chips), 1: carrier phase (wrap into [0,1))
@@ -343,7 +343,7 @@ struct NcoWalk {
             else p.span = ((int64_t) 1 << 52) - 1;
             p.k = p.span / dm; p.kdm = p.k * dm; p.rem = p.span - p.kdm;
         }
-        if (!general) thr = from_bits((uint64_t) (ec + kLow + 1) << 52);   // first value the table handles; |c| < thr / 16
+        if (!general) thr = from_bits((uint64_t) (ec + kLow + 1) << 52);   // first value the table handles; |c| < thr / 2^kLow
     }
 
     // Positive addend: from x (sample n) up to the next wrap.  true: wrapped, x is the state after the wrap (sample n);
@@ -352,7 +352,7 @@ struct NcoWalk {
     inline bool climb(double &x, long &n, long ns, Slack *sl) const
     {
         constexpr int64_t one52 = (int64_t) 1 << 52;
-        while (x < thr) {                                             // cannot wrap: x + c < thr + thr / 16
+        while (x < thr) {                                             // cannot wrap: x + c < thr + thr / 2^kLow
             x += c;
             if (kNote) sl->note(x);
             if (++n == ns) return false;
@@ -414,7 +414,7 @@ struct NcoWalk {
             x = from_bits((bx & ~kMant) | ((uint64_t) (mx - moved) & kMant));
             n += run;
             if (kNote && run) sl->note(x);
-            x += c;                                                   // into the binade underneath; x >= thr > 16 |c|: still positive
+            x += c;                                                   // into the binade underneath; x >= thr >= 2^kLow |c|: still positive
             if (kNote) sl->note(x);
             if (++n == ns) return false;
         }

@@ -228,7 +228,7 @@ def test_candidates_evaluated_from_the_wrap_tables(oracle, fs, ns, seed):
 
 def test_wrap_to_wrap_table_with_exact_tie_binades(oracle):
     """Addends whose mantissa ends in 1 followed by s - 1 zeros: in the binade s above the addend's own, c / ulp ends in exactly
-    one half and every addition there is a tie (to even).  One addend in 16 has such a binade above the plain additions; the
+    one half and every addition there is a tie (to even).  One addend in 4 has such a binade above the plain additions; the
     fast walk takes one real addition to make the mantissa even and the even step from its table after that, and tables
     whole cycles as for any other addend (except a tie in the top binade of a descending carrier: the probing walk)."""
     rng = np.random.default_rng(99)
@@ -237,7 +237,7 @@ def test_wrap_to_wrap_table_with_exact_tie_binades(oracle):
     ties = 0
     for it in range(24):
         f = rng.uniform(400.0, 6000.0, 16) * rng.choice([-1.0, 1.0], 16)
-        s = rng.integers(5, 13, 16).astype(np.uint64)                  # tie binade: the addend's low s bits = 100..0
+        s = rng.integers(2, 13, 16).astype(np.uint64)                  # tie binade: the addend's low s bits = 100..0
         want = (((f * delt).view(np.uint64) >> s << s) | (np.uint64(1) << (s - np.uint64(1)))).view(np.float64)
         f = want / delt                                                # the library forms the addend as f_carr * (1 / fs): aim at it
         for _ in range(4):                                             # ... and step f until the product is the wanted double
