@@ -477,6 +477,8 @@ def main():
                            "host_refresh_and_quantise_ms_per_round": round(best_s[1] / R * 1e3, 2), "seed_exchange": exchange,
                            "what": "the chain above over one continuous timeline in rounds, launches asynchronous: the host side of round "
                                    "m+1 overlaps the kernel of round m (double-buffered descriptor sets); slowest rank, best of 2 passes"}
+        # what the rounds of a long run are bound by on the slowest rank (the serial batch above is host + kernel by construction)
+        e2e["bound"] = e2e["streamed"]["bound"]
         if not dry:
             ctx.set_descriptors(q)
 

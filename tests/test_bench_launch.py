@@ -59,3 +59,4 @@ def test_gpus_8_dry_run_is_one_line_from_eight_ranks():
     assert [p["rank"] for p in st["per_rank"]] == list(range(8))
     assert all(p["host_ms_per_round"] > 0.0 and p["threads"] == out["config"]["host_threads_per_rank"] for p in st["per_rank"])
     assert st["bound"] is None and all(p["kernel_ms_per_round"] is None for p in st["per_rank"])       # no device in a dry run
+    assert "bound" in out["end_to_end"] and out["end_to_end"]["bound"] is None
