@@ -192,7 +192,10 @@ def roofline_obj(alg_bytes, launch_ms, traffic=None):
 def counters_obj(key, launch_ms):
     """Counter-based fractions of the dominant kernel: rocprofv3 --pmc passes of this very command, committed under
     profiles/ (scripts/gpu_prof.sh -> scripts/prof_summary.py -> profiles/pmc_counters.json), per launch, against the
-    launch duration measured live in this run.  Independent of the kernel's own instruction mix (unlike issue_roofline)."""
+    launch duration measured live in this run.  Independent of the kernel's own instruction mix (unlike issue_roofline).
+    The counts are replayed, not measured here: they are only emitted when the profile was taken from a library built
+    from the same device code as the one loaded now (gpsiq_kernels_id), else {"stale_profile": true} and nothing else."""
+    import gpsiq
     path = os.path.join(ROOT, "profiles", "pmc_counters.json")
     try:
         c = json.load(open(path)).get(key)
@@ -200,9 +203,13 @@ def counters_obj(key, launch_ms):
         c = None
     if not c:
         return None
+    if c.get("kernels_id") != gpsiq.kernels_id():
+        return {"stale_profile": True, "profile_kernels_id": c.get("kernels_id"), "loaded_kernels_id": gpsiq.kernels_id(),
+                "source": c.get("source")}
     valu_peak = 256 * 4 * 2.4e9 / 2.0                     # wave64 VALU instructions/s: 1024 SIMD-32s, 2 cycles each, 2.4 GHz
     cu_cycles = c["GRBM_GUI_ACTIVE"] / 8.0                 # cycles the launch was resident, per XCD = per CU
-    out = {"source": c.get("source"), "collected_with": "rocprofv3 --pmc (SQ passes alone, no tracing), averages per launch of the dominant kernel",
+    out = {"source": c.get("source"), "kernels_id": c.get("kernels_id"), "stale_profile": False,
+           "collected_with": "rocprofv3 --pmc (SQ passes alone, no tracing), averages per launch of the dominant kernel",
            "valu_wave_insts_per_launch": int(c["SQ_INSTS_VALU"]),
            "valu_issue_frac": round(c["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / valu_peak, 4),
            "valu_issue_peak": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 /s",
@@ -212,6 +219,21 @@ def counters_obj(key, launch_ms):
            "clock_ghz_under_load": round(cu_cycles / c["_avg_duration_ns_pmc_sq1"], 3),
            "profiled_launch_ms": round(c["_avg_duration_ns_pmc_sq1"] * 1e-6, 4)}
     return out
+
+
+def replayed_traffic(key):
+    """HBM bytes per launch from the committed WRITE_SIZE / FETCH_SIZE passes (profiles/pmc_traffic.json), or None when
+    there is no profile of this workload or it was taken from another kernel than the loaded library's."""
+    import gpsiq
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None, False
+    if key not in d:
+        return None, False
+    if (d.get(key + "_detail") or {}).get("kernels_id") != gpsiq.kernels_id():
+        return None, True
+    return d[key], False
 
 
 class Scenario:
@@ -496,13 +518,7 @@ def main():
         forced_packed = os.environ.get("GPSIQ_NO_FAST", "0") not in ("", "0")
         plain_add = (ss == 1 or int(np.floor(250.0 * np.abs(q["gain"])).sum(axis=1).max()) <= 32767) and not forced_packed
         core_cycles = 23.85 if plain_add else 26.7
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(f"{int(fs)}_{nchan}_{ss}_{nblocks}")
-            except Exception:
-                traffic = None
+        traffic, stale_traffic = replayed_traffic(f"{int(fs)}_{nchan}_{ss}_{nblocks}")
         out = {
             "metric": "IQ Msamples/s @16ch int8" if (nchan == 16 and ss == 1) else f"IQ Msamples/s @{nchan}ch int{8 * ss}",
             "value": None if dry else round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -524,6 +540,8 @@ def main():
             out["dry_run"] = True
         else:
             out["roofline"] = roofline_obj(alg_bytes, launch_ms, traffic)
+            if stale_traffic:
+                out["roofline"]["stale_profile"] = True     # profiles/pmc_traffic.json is of another kernel than the loaded library's
             # informational: the limiter actually hit.  Per (channel, 64-sample row)
             # and SIMD the row-kernel core costs, with the single-instruction rates measured on this
             # chip (profiles/r01_ubench_valu_encodings.txt: 4.3 nominal cycles for SGPR-operand / VOP3 /

@@ -152,6 +152,9 @@ typedef struct gpsiq_patch {
 
 /* ---- [boundary] library / tables (no device needed) ----------------------- */
 const char *gpsiq_version(void);
+/* first 16 hex digits of the SHA-256 of the device-code source (csrc/gpsiq_kernels.hip) this library was built from: a
+ * profile taken from one library (profiles/pmc_*.json record it) is only replayed next to measurements of the same one */
+const char *gpsiq_kernels_id(void);
 /* last error text of the calling thread ("" if none) */
 const char *gpsiq_last_error(void);
 /* C/A code of one PRN as 0/1 chips; replaces codegen() gps.c:272-309 */

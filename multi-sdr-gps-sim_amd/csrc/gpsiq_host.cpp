@@ -292,7 +292,12 @@ using namespace gpsiq;
 
 extern "C" {
 
-const char *gpsiq_version(void) { return "gpsiq 0.2 (gfx950)"; }
+const char *gpsiq_version(void) { return "gpsiq 0.3 (gfx950)"; }
+
+#ifndef GPSIQ_KERNELS_SHA16
+#define GPSIQ_KERNELS_SHA16 "unknown"       // host-only test builds (no device code linked)
+#endif
+const char *gpsiq_kernels_id(void) { return GPSIQ_KERNELS_SHA16; }
 
 const char *gpsiq_last_error(void) { return g_err; }
 

@@ -64,6 +64,7 @@ def _sig(name, restype, *argtypes):
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 _version = _sig("gpsiq_version", C.c_char_p)
 _last_error = _sig("gpsiq_last_error", C.c_char_p)
+_kernels_id = _sig("gpsiq_kernels_id", C.c_char_p)
 _prn_code = _sig("gpsiq_prn_code", _i, _i, _vp)
 _carrier_table = _sig("gpsiq_carrier_table", None, _vp, _vp)
 _quantize = _sig("gpsiq_quantize", _i, _vp, _i, _d, _i, _vp, _vp, _vp)
@@ -123,6 +124,11 @@ def _p(a):
 
 def version():
     return _version().decode()
+
+
+def kernels_id():
+    """Identity of the device code in the loaded library (see gpsiq_kernels_id in include/gpsiq.h)."""
+    return _kernels_id().decode()
 
 
 def variants():

@@ -10,6 +10,15 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 os.makedirs("profiles", exist_ok=True)
 
 
+def kernels_id():
+    """What libgpsiq's gpsiq_kernels_id() returns for a library built from the tree these profiles were taken in: the
+    first 16 hex digits of the SHA-256 of csrc/gpsiq_kernels.hip (csrc/Makefile).  Stored next to every replayed counter so
+    that bench.py can tell a profile of another kernel from one of the library it has loaded."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return hashlib.sha256(open(os.path.join(root, "multi-sdr-gps-sim_amd", "csrc", "gpsiq_kernels.hip"), "rb").read()).hexdigest()[:16]
+
+
 def q(db, sql):
     con = sqlite3.connect(db)
     try:
@@ -69,7 +78,7 @@ if w is not None and f is not None:
     path = "profiles/pmc_traffic.json"
     d = json.load(open(path)) if os.path.exists(path) else {}
     d[key] = int(w * 1024 + 2 * f * 1024)
-    d[key + "_detail"] = {"WRITE_SIZE_KiB": w, "FETCH_SIZE_KiB_raw": f, "fetch_correction": "x2 (gfx950)", "source": f"profiles/{tag}_pmc_counters.txt"}
+    d[key + "_detail"] = {"kernels_id": kernels_id(), "WRITE_SIZE_KiB": w, "FETCH_SIZE_KiB_raw": f, "fetch_correction": "x2 (gfx950)", "source": f"profiles/{tag}_pmc_counters.txt"}
     json.dump(d, open(path, "w"), indent=1)
     print("traffic bytes/launch:", d[key])
 
@@ -87,6 +96,7 @@ if sq:
     path = "profiles/pmc_counters.json"
     d = json.load(open(path)) if os.path.exists(path) else {}
     sq["source"] = f"profiles/{tag}_pmc_counters.txt"
+    sq["kernels_id"] = kernels_id()
     d[key] = sq
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
     print("SQ counters per launch:", {k: v for k, v in sq.items() if not k.startswith("_")})

@@ -77,6 +77,35 @@ def run_program(binary, workdir, seconds=30, iq16=False, env_extra=None, timeout
     return data
 
 
+def run_program_lossy(binary, workdir, seconds=30, iq16=False, timeout=300, fs=FS, rinex=RINEX):
+    """-> bytes of iqdata.bin of a program whose FIFO may lose blocks (the reference's own fifo.c, fifo.c:166-168): the
+    file's final size is not known in advance, so the run is over when the file has stopped growing for three seconds."""
+    args = [binary, "-e", rinex, "-l", LLH, "-r", "iqfile", "-d", str(seconds), "--disable-almanac"] + (["--iq16"] if iq16 else [])
+    env = dict(os.environ, LINES="50", COLUMNS="160", TERM="xterm")
+    out = os.path.join(workdir, "iqdata.bin")
+    if os.path.exists(out):
+        os.remove(out)
+    p = subprocess.Popen(args, cwd=workdir, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        t0, last, stable = time.time(), -1, 0
+        while time.time() - t0 < timeout and stable < 6:
+            time.sleep(0.5)
+            if p.poll() is not None:
+                raise RuntimeError(f"{binary} exited with {p.returncode} before the run was complete")
+            size = os.path.getsize(out) if os.path.exists(out) else 0
+            stable = stable + 1 if (size == last and size > 0) else 0
+            last = size
+    finally:
+        if p.poll() is None:
+            p.send_signal(signal.SIGTERM)
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return open(out, "rb").read()
+
+
 # ---- BASELINE config 4: the reference's own circle.csv -------------------------------------------------------
 CONFIG4 = os.path.join(ROOT, "tests", "golden", "program_config4_circle.npz")
 

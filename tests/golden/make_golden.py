@@ -332,14 +332,14 @@ def make_config35_golden(which=("cfg3", "cfg5")):
     import tempfile
     from _program import program, program_block_digests
     out = {}
-    for name, suffix, fs, seconds, nblocks in (("cfg3", "10M", 10000000, 300, 2999), ("cfg5", "25M", 25000000, 450, 4499)):
+    for name, suffix, fs, seconds, nblocks in (("cfg3", "10M", 10000000, 300, 2999), ("cfg5", "25M", 25000000, 900, 8999)):
         if name not in which:
             continue
         ref = program("gps-sim-ref-" + suffix)
         assert ref, f"oracle/_ref/gps-sim-ref-{suffix} missing (make -C oracle progs)"
-        keep = (0, 1, 299, 300, 301, nblocks - 1)
+        keep = (0, 1, 299, 300, 301, nblocks - 1) if name == "cfg3" else (0, 1, 299, 300, 301, 4498, 4499, 4500, 4501, nblocks - 1)
         with tempfile.TemporaryDirectory() as td:
-            sha, heads = program_block_digests(ref, td, None, seconds, nblocks, fs=fs, keep=keep, timeout=3600)
+            sha, heads = program_block_digests(ref, td, None, seconds, nblocks, fs=fs, keep=keep, timeout=7200)
         out[name + "_sha16"] = np.array(sha)
         out[name + "_head_blocks"] = np.array(sorted(heads))
         out[name + "_heads"] = np.stack([heads[k] for k in sorted(heads)])
@@ -353,8 +353,64 @@ def make_config35_golden(which=("cfg3", "cfg5")):
     np.savez_compressed(path, **out)
 
 
+def make_t2_golden():
+    """Tier T2 made exact: WHICH blocks of a run in the default (fixed-point) NCO model hold an element that differs from the
+    reference program's capture.  Deterministic (fixed inputs, integer arithmetic), so the GPU tests compare the list, not a
+    count against a tolerance.  Computed with the checker: the library's host chain gives the run's descriptors (that they
+    are the reference's is checked first -- in GPSIQ_NCO_REFERENCE form the oracle reproduces the captured digests of a
+    few blocks), gpsiq_quantize_batch the exact carrier carry, the oracle's closed form every block, SHA-256 against the
+    capture.  Stored as `fixed_differing_blocks` in program_config4_circle.npz (BASELINE config 4, 2 999 blocks: 632 of
+    them) and `fixed_differing_blocks_sha8` in program_static_30s.npz (the reference as shipped, 30 s int8: 4 of 299)."""
+    import gpsiq
+    from _oracle import apply_patches, load_oracle
+    from _program import CONFIG4, LLH, RINEX, RINEX16
+    from gpsiq.abi import SC08, SC16
+    from gpsiq.pipeline import RunAheadAllocating
+    orc = load_oracle()
+
+    def start_time(eph):
+        sv = int(np.nonzero(eph[0]["vflg"])[0][0])
+        return int(eph[0, sv]["toc_week"]), float(eph[0, sv]["nav"]["toc_sec"])
+
+    def differing(desc, fs, ns, ss, want, check_ref=(0, 1, 150)):
+        qr, patches, _ = gpsiq.reference_blocks(desc[:max(check_ref) + 1], float(fs), ns)
+        for b in check_ref:
+            o = orc.block_fixed(qr[b], ns, ss, seq=True)
+            apply_patches(orc, qr[b], o, patches[patches["block"] == b], ss)
+            assert hashlib.sha256(o.tobytes()).hexdigest() == want[b], ("the host chain does not reproduce the capture", b)
+        q, _ = gpsiq.quantize_blocks(desc, float(fs), ns)
+        return np.array([b for b in range(len(desc))
+                         if hashlib.sha256(orc.block_fixed(q[b], ns, ss, seq=True).tobytes()).hexdigest() != want[b]], dtype=np.int32)
+
+    def update(path, **kw):
+        z = dict(np.load(path))
+        z.update(kw)
+        np.savez_compressed(path, **z)
+
+    z = np.load(CONFIG4)
+    eph, utc, n = gpsiq.rinex_read(RINEX16, 2)
+    week, sec = start_time(eph)
+    xyz = z["xyz_mm"][:3000] / 1000.0
+    desc = RunAheadAllocating(eph[:n], utc, 16, week, sec, xyz[0], ieph=gpsiq.rinex_select(eph, n, week, sec)).descriptors(xyz[1:])
+    lst = differing(desc, 2600000, 260000, SC16, [str(s) for s in z["sha16"]])
+    update(CONFIG4, fixed_differing_blocks=lst)
+    print("config 4, fixed-point model:", len(lst), "of 2999 blocks differ from the reference")
+    path = os.path.join(HERE, "program_static_30s.npz")
+    z = np.load(path)
+    eph, utc, n = gpsiq.rinex_read(RINEX, 2)
+    week, sec = start_time(eph)
+    lat, lon, h = (float(v) for v in LLH.split(","))
+    xyz = np.tile(gpsiq.llh_to_ecef(lat / 57.2957795131, lon / 57.2957795131, h), (300, 1))     # gps.c:2480-2490
+    desc = RunAheadAllocating(eph[:n], utc, 12, week, sec, xyz[0], ieph=gpsiq.rinex_select(eph, n, week, sec)).descriptors(xyz[1:])
+    lst = differing(desc, 3000000, 300000, SC08, [str(s) for s in z["sha8"]])
+    update(path, fixed_differing_blocks_sha8=lst)
+    print("static 30 s int8, fixed-point model:", list(lst), "of 299 blocks differ from the reference")
+
+
 if __name__ == "__main__":
-    if "--config35-only" in sys.argv:
+    if "--t2-only" in sys.argv:
+        make_t2_golden()
+    elif "--config35-only" in sys.argv:
         make_config35_golden([a for a in sys.argv[1:] if a in ("cfg3", "cfg5")] or ("cfg3", "cfg5"))
     elif "--config4-only" in sys.argv:
         make_config4_golden()
@@ -381,3 +437,4 @@ if __name__ == "__main__":
         make_program_golden()
         make_config4_golden()
         make_config35_golden()
+        make_t2_golden()

@@ -95,3 +95,39 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "_oracle" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace(
                     "anything under oracle/", "").replace("on anything under oracle", ""), os.path.join(dirpath, f)
+
+
+def test_replayed_counters_are_bound_to_the_loaded_kernel(tmp_path, monkeypatch):
+    """bench.py's `counters` / `roofline.traffic` are rocprofv3 counts committed under profiles/, divided by the live
+    launch time: they may only be replayed next to the library they were taken from.  gpsiq_kernels_id() is the SHA-256
+    of the kernel source the loaded library was built from; scripts/prof_summary.py stores the same id with every
+    profile; a profile of any other kernel is reported as {"stale_profile": true} and its counts are withheld."""
+    import hashlib
+    import json
+    import sys
+    src = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc", "gpsiq_kernels.hip")
+    assert gpsiq.kernels_id() == hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "libgpsiq.so is older than gpsiq_kernels.hip: rebuild"
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    good = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
+    key = sorted(good)[0]
+    for kid, stale in ((gpsiq.kernels_id(), False), ("0123456789abcdef", True), (None, True)):
+        c = dict(good[key])
+        c.pop("kernels_id", None)
+        if kid:
+            c["kernels_id"] = kid
+        json.dump({key: c}, open(prof / "pmc_counters.json", "w"))
+        json.dump({key: 123, key + "_detail": {"kernels_id": kid} if kid else {}}, open(prof / "pmc_traffic.json", "w"))
+        out = bench.counters_obj(key, 2.85)
+        assert out["stale_profile"] is stale
+        assert ("valu_issue_frac" in out) is (not stale)
+        assert bench.replayed_traffic(key) == ((None, True) if stale else (123, False))
+    assert bench.replayed_traffic("no_such_workload") == (None, False)
+    # the committed profiles belong to the committed kernel
+    for name in ("pmc_counters.json", "pmc_traffic.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        ids = {(v.get("kernels_id") if isinstance(v, dict) else None) for k, v in d.items() if isinstance(v, dict)}
+        assert ids == {gpsiq.kernels_id()}, (name, ids)

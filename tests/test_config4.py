@@ -167,6 +167,10 @@ def test_config4_run_ahead_chain_fixed_point_nco(cfg4, oracle, tmp_path):
     q, _ = gpsiq.quantize_blocks(desc, float(FS), NS)
     for b in check:
         assert np.array_equal(kept[b], oracle.block_fixed(q[b], NS, SC16)), b
-    differing = sum(s != w for s, w in zip(sha, cfg4["sha"][:2999]))
-    print("config 4, fixed-point NCO: %d of 2999 blocks hold an element that differs from the reference" % differing)
-    assert sha[0] == cfg4["sha"][0] and differing <= 1000        # measured: 632 (a fifth of the blocks hold one of the ~6 in 10^7 elements)
+    differing = [b for b in range(2999) if sha[b] != cfg4["sha"][b]]
+    print("config 4, fixed-point NCO: %d of 2999 blocks hold an element that differs from the reference" % len(differing))
+    # deterministic (fixed inputs, integer arithmetic): exactly the blocks the oracle's closed form with the exact carry
+    # differs in (tests/golden/make_golden.py --t2-only: 632 blocks, a fifth hold one of the ~6 in 10^7 elements); a changed
+    # list is a changed model
+    want = [int(b) for b in np.load(CONFIG4)["fixed_differing_blocks"]]
+    assert len(want) == 632 and differing == want, (len(differing), sorted(set(differing) ^ set(want))[:10])
