@@ -507,6 +507,12 @@ def main():
     extra = {}
     if not dry and rank == 0 and world == 1 and not args.no_extra:
         extra = extra_legs(ctx, ring, stream, args, first)
+    if not dry and world == 1 and os.environ.get("GPSIQ_BENCH_NO_RCCL_SELFTEST", "0") in ("", "0"):
+        # also under --no-extra: the driver's N = 1 run must have executed the collective stack of its N > 1 runs
+        extra["rccl_selftest"] = rccl_selftest(dev)
+        # and the library still works next to an initialised-and-destroyed RCCL: one more launch, timed
+        ctx.set_descriptors(q)                            # the extra legs left their own sets resident
+        extra["rccl_selftest"]["launch_after_ms"] = round(ctx.time_launches(0, nblocks, nsamp, ss, ring.data_ptr(), stride, 1, stream=stream, variant=variant), 3)
     if not dry and args.sweep and rank == 0:
         sweep_legs(ctx, ring, stream, args, q, nblocks, nsamp, ss, stride)
 
@@ -570,6 +576,72 @@ def main():
         ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def rccl_selftest(dev, backend="nccl"):
+    """Pre-flight of the N > 1 branch on the one GPU of the default run: everything `bench.py --gpus N` asks of
+    torch.distributed -- init_process_group("nccl", device_id=...) (RCCL), a float64 all_reduce(MAX) and a uint8 all_gather on
+    device tensors (gpsiq/shard.py), barrier, a gloo side group under the RCCL default group and an all_gather on it, a
+    device-tensor send/recv to itself being impossible at world size 1 left out, destroy_process_group -- as a world of ONE
+    rank, in this process, AFTER gpsiq.Context has been created and used: libgpsiq and torch (with RCCL inside) must share one
+    HIP runtime.  Never fatal: the outcome goes into the JSON."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gpsiq.shard import max_over_ranks, torch_all_gather_bytes
+    xd = "cuda" if backend == "nccl" else "cpu"            # backend "gloo": the CPU tests' walk through the same statements
+    out = {"ok": False, "backend": "nccl (RCCL)" if backend == "nccl" else backend, "world_size": 1, "after_gpsiq_context": backend == "nccl"}
+    if dist.is_initialized():
+        out["error"] = "torch.distributed already initialised"
+        return out
+    t0 = time.perf_counter()
+    step = "free port"
+    try:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        step = "init_process_group(nccl, device_id)"
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        t1 = time.perf_counter()
+        step = "all_reduce(MAX) float64 on the device"
+        tt = torch.tensor([1.25], dtype=torch.float64, device=xd)     # max_over_ranks' statement (it short-cuts a world of one)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        assert float(tt.item()) == 1.25 and max_over_ranks(1.25, dist, device=xd) == 1.25
+        step = "all_gather uint8 on the device"
+        t = torch.arange(512, dtype=torch.int32).to(torch.uint8).to(xd) ^ 0x5a
+        outs = [torch.empty_like(t)]
+        dist.all_gather(outs, t)
+        assert torch.equal(outs[0], t)
+        step = "barrier"
+        dist.barrier()
+        if xd == "cuda":
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        step = "new_group(gloo) beside the RCCL group"
+        side = dist.new_group(backend="gloo")
+        step = "all_gather on the gloo side group"
+        c = torch.arange(512, dtype=torch.int32).to(torch.uint8)
+        outs = [torch.empty_like(c)]
+        dist.all_gather(outs, c, group=side)
+        assert torch.equal(outs[0], c)
+        assert torch_all_gather_bytes(dist, "cpu", group=side)(b"seed") == [b"seed"]
+        t3 = time.perf_counter()
+        step = "destroy_process_group"
+        dist.destroy_process_group()
+        out.update(ok=True, ms=round((time.perf_counter() - t0) * 1e3, 1), init_ms=round((t1 - t0) * 1e3, 1),
+                   device_collectives_ms=round((t2 - t1) * 1e3, 1), gloo_side_group_ms=round((t3 - t2) * 1e3, 1),
+                   rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None)
+    except Exception as ex:                                # the headline must survive a broken collective stack
+        out["error"] = f"{step}: {type(ex).__name__}: {ex}"[:400]
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+    return out
 
 
 def extra_legs(ctx, ring, stream, args, first):

@@ -197,6 +197,39 @@ int gpsiq_reference_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double
                           gpsiq_qchan_t *out, gpsiq_patch_t *patches, int max_patches, int *npatches,
                           double *carr_phase_out);
 
+/* The two halves of gpsiq_reference_batch on their own, for hosts that spread GPSIQ_NCO_REFERENCE over devices or processes.
+ * Only the carrier chain is serial in time (gps.c:2821-2826: block b of a channel starts where the double accumulator left
+ * block b-1); everything else about a block follows from its start state alone.
+ *   gpsiq_reference_chain   the chain: the double every channel's accumulator holds at the START of every block.  It reads
+ *                           three fields per channel and block (gpsiq_chain_in_t; gpsiq_chain_inputs extracts them), so a
+ *                           process that refreshed only its own blocks can be sent the rest (24 bytes each), and the channels
+ *                           are independent: rank r may walk channels [c0, c1) of the WHOLE timeline (pass those columns,
+ *                           nchan = c1 - c0) while the other ranks walk theirs -- nchan-fold parallel, one thread per channel.
+ *                           carr_in / prn_in (both or neither): accumulator and satellite of every slot after the block before
+ *                           block 0 when the timeline continues an earlier one.  carr_start is [nblocks][nchan] (0.0 for an unused
+ *                           slot); carr_end / last_prn (may be NULL): the state after the last block.
+ *   gpsiq_reference_seeded  the rest, for blocks whose start states are known (carr_start[nblocks][nchan] from the chain;
+ *                           ch[b][i].carr_phase itself is not read): descriptors seeded from them and the patches, exactly the
+ *                           rows gpsiq_reference_batch over the whole timeline gives for these blocks (patch block indices count
+ *                           from this call's block 0).  Blocks are independent: any split over threads, devices, processes.
+ * Both host only, threaded over the shared pool (GPSIQ_THREADS). */
+typedef struct gpsiq_chain_in {
+    double  f_carr;       /* gpsiq_chan_t.f_carr */
+    double  carr_phase;   /* gpsiq_chan_t.carr_phase: read where the slot is (re-)allocated (gps.c:2208-2214) */
+    int32_t prn;          /* <= 0: unused slot */
+    int32_t reserved;
+} gpsiq_chain_in_t;
+/* Counts since the process started, over every GPSIQ_NCO_REFERENCE evaluation: out[0] accumulator states that had to be known
+ * (candidate samples; carrier and code count separately), out[1] of them decided from the block's start state by the drift
+ * enclosure, out[2] / out[3] carrier / code states that took a walk of the accumulator from the block's start. */
+void gpsiq_reference_stats(uint64_t out[4]);
+void gpsiq_chain_inputs(const gpsiq_chan_t *ch, int n /* nblocks*nchan */, gpsiq_chain_in_t *out);
+int gpsiq_reference_chain(const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
+                          const double *carr_in, const int32_t *prn_in,
+                          double *carr_start, double *carr_end, int32_t *last_prn);
+int gpsiq_reference_seeded(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp, const double *carr_start,
+                           gpsiq_qchan_t *out, gpsiq_patch_t *patches, int max_patches, int *npatches);
+
 /* Contiguous balanced split of a block timeline over `world` devices/processes:
  * rank r owns [*begin, *end); the first nblocks % world ranks own one block more. */
 int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end);

@@ -548,9 +548,9 @@ static int check_gen_args(const gpsiq_ctx *c, const void *ch, const void *dst, i
 }
 
 // ---- GPSIQ_NCO_REFERENCE: walk and render in pieces ------------------------------------------
-// The carrier walk is serial in time on the host, the render is not: the timeline is cut into pieces, and while the device
-// renders (and copies out) piece k the walkers (RefWalk, gpsiq_exact.cpp: one host thread per channel, one pass) are in
-// the pieces behind it.  RefRender is the device side of one context: begin() sizes the staging once, piece() queues
+// The carrier chain is serial in time on the host, the render is not: the timeline is cut into pieces, and while the device
+// renders (and copies out) piece k the host threads (RefWalk, gpsiq_exact.cpp: a chain task and an evaluation task per channel
+// and piece, taken piece-major from the shared pool) are in the pieces behind it.  RefRender is the device side of one context: begin() sizes the staging once, piece() queues
 // descriptors + patches + kernel (+ the copy to the destination) without waiting, finish() drains.  generate_reference
 // drives one from the calling thread; gpsiq_generate_batch_multi gives every device one, fed through a queue.
 static int ref_chunk_blocks(int nblocks, int nsamp)
@@ -666,7 +666,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         if (trace) { t_wait += tp - tw; t_queue += wall_ms() - tp; }
     }
     char err[400] = "";
-    if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
+    if (rc != GPSIQ_OK) { std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); w.abort(); }     // nothing further is walked for a call that has failed
     if (threaded) pthread_join(th, nullptr);                 // the walkers read ch and write q: never leave them running
     const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();
@@ -764,9 +764,10 @@ int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan
         a.out_cap = stride ? stride : 16;
     }
     if (!patches.empty() && patches.size() > a.patch_cap) {      // the slot is idle here (its event was waited for above)
-        if (a.d_patch) HIP_TRY(hipFree(a.d_patch));
-        if (a.h_patch) HIP_TRY(hipHostFree(a.h_patch));
-        a.d_patch = a.h_patch = nullptr; a.patch_cap = 0;
+        // each pointer is forgotten before its free can fail: a second call (or gpsiq_destroy) must not free it again
+        { gpsiq_patch_t *dp = a.d_patch, *hp = a.h_patch; a.d_patch = a.h_patch = nullptr; a.patch_cap = 0;
+          const hipError_t f0 = dp ? hipFree(dp) : hipSuccess, f1 = hp ? hipHostFree(hp) : hipSuccess;
+          if (f0 != hipSuccess || f1 != hipSuccess) return fail(GPSIQ_E_DEVICE, "patch staging: %s", hipGetErrorString(f0 != hipSuccess ? f0 : f1)); }
         const size_t cap = patches.size() < 256 ? 256 : patches.size();
         HIP_TRY(hipMalloc((void **) &a.d_patch, cap * sizeof(gpsiq_patch_t)));
         HIP_TRY(hipHostMalloc((void **) &a.h_patch, cap * sizeof(gpsiq_patch_t), hipHostMallocDefault));
@@ -967,6 +968,8 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
             if (wrc == GPSIQ_OK) {
                 wrc = w.wait_piece(k);
                 if (wrc != GPSIQ_OK) std::snprintf(werr, sizeof werr, "%s", w.err);
+                for (int j = 0; j < ndev && wrc == GPSIQ_OK; ++j)                  // a device that has failed: stop walking for it
+                    if (__atomic_load_n(&devs[(size_t) j].rc, __ATOMIC_RELAXED) != GPSIQ_OK) w.abort();
             }
             const int i = owner[k];
             for (; open_dev < i; ++open_dev) {                        // the walk has left device open_dev's range: no more pieces for it

@@ -469,24 +469,38 @@ struct NcoWalk {
     // one load and an add per cycle, no search: the states are as good as random, a binary search would mispredict at every
     // level); the few buckets that straddle an edge fall back to a scan of the entries.
     struct Entry { int64_t first, last, inc; long steps; };
-    struct Bucket { int64_t inc; long steps; };
     static constexpr int kMaxEntries = 64, kBuckets = 1024;
+    // The buckets live per thread and are never cleared: a bucket belongs to the table of the run (= block) whose stamp it
+    // carries (clearing 1024 of them per block cost as much as a hundred look-ups).  Increment and sample count sit in two
+    // arrays, so that the chain state -> shift -> load -> add that every cycle waits for is those three instructions and
+    // nothing else; stamp and count are read beside it.
+    struct Buckets {
+        int64_t  inc[kBuckets];
+        uint64_t tag[kBuckets];              // (stamp << 32) | samples of the cycle
+        uint32_t stamp = 0;
+        Buckets() { for (int i = 0; i < kBuckets; ++i) tag[i] = 0; }
+        uint32_t next_stamp()
+        {
+            if (++stamp == 0) { for (int i = 0; i < kBuckets; ++i) tag[i] = 0; stamp = 1; }
+            return stamp;
+        }
+    };
 
     // A function of its own (and not inlined): in the middle of run() the compiler keeps the state in memory, and the store
-    // forwarding on it would cost more than the look-up itself.
-    __attribute__((noinline)) static void hits(const Bucket *bkt, int64_t base, int64_t W, int bshift, long limit,
-                                               int64_t *m_io, long *n_io, long *wraps_io)
+    // forwarding on it would cost more than the look-up itself.  rel = state - base.
+    __attribute__((noinline)) static void hits(const Buckets *bk, uint32_t stamp, int64_t W, int bshift, long limit,
+                                               int64_t *rel_io, long *n_io, long *wraps_io)
     {
-        int64_t m = *m_io;
+        uint64_t rel = (uint64_t) *rel_io;
         long n = *n_io, wraps = *wraps_io;
         for (;;) {
-            const uint64_t rel = (uint64_t) (m - base);
             if (rel >= (uint64_t) W) break;
-            const Bucket &bk = bkt[rel >> bshift];
-            if (bk.steps == 0 || n + bk.steps > limit) break;
-            m += bk.inc; n += bk.steps; ++wraps;
+            const uint64_t idx = rel >> bshift, tag = bk->tag[idx];
+            const long steps = (long) (uint32_t) tag;
+            if ((uint32_t) (tag >> 32) != stamp || n + steps > limit) break;
+            rel += (uint64_t) bk->inc[idx]; n += steps; ++wraps;
         }
-        *m_io = m; *n_io = n; *wraps_io = wraps;
+        *rel_io = (int64_t) rel; *n_io = n; *wraps_io = wraps;
     }
 
     // The state after ns samples from x0.  targets[nt] (ascending, < ns): samples whose state is wanted as well -> xs[nt]
@@ -530,7 +544,7 @@ struct NcoWalk {
             ++wraps;
         }
         const int uexp = kind == 0 ? 1023 + 9 : neg ? 1022 : 1023;   // biased exponent of the binade whose ulp is the state grid
-        const double scale = std::ldexp(1.0, 1075 - uexp), unit = std::ldexp(1.0, uexp - 1075);
+        const double scale = from_bits((uint64_t) (1023 + 1075 - uexp) << 52), unit = from_bits((uint64_t) (1023 + uexp - 1075) << 52);   // 2^(1075 - uexp) and its inverse
         const int64_t m_max = kind == 0 ? ((int64_t) GPSIQ_CA_SEQ_LEN << 43) - 1 : neg ? ((int64_t) 1 << 53) - 1 : ((int64_t) 1 << 52) - 1;
         // post-wrap states: [0, c] (positive addend) or [1 + c, 1) (negative), W units wide
         const int64_t W = (int64_t) (std::fabs(c) * scale) + 4;
@@ -538,17 +552,18 @@ struct NcoWalk {
         int bshift = 0;
         while ((W >> bshift) >= kBuckets) ++bshift;
         Entry tab[kMaxEntries];
-        Bucket bkt[kBuckets];                                         // steps == 0: no entry covers the whole bucket
-        for (int i = 0; i < kBuckets; ++i) bkt[i].steps = 0;
+        static thread_local Buckets bkt;
+        const uint32_t stamp = bkt.next_stamp();
         int ntab = 0;
         long min_steps = ns;                                          // shortest cycle seen
         int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
         for (;;) {
             // the common case, cycle after cycle: the state's bucket lies wholly inside one entry and names its increment.
             // Stops before a cycle that would pass the end of the block or hold the next target.
-            hits(bkt, base, W, bshift, tk < nt && targets[tk] < ns ? targets[tk] : ns, &m, &n, &wraps);
+            int64_t rel = m - base;
+            hits(&bkt, stamp, W, bshift, tk < nt && targets[tk] < ns ? targets[tk] : ns, &rel, &n, &wraps);
+            m = rel + base;
             if (n >= ns) return (double) m * unit;
-            const int64_t rel = m - base;
             const Entry *e = nullptr;
             if (rel >= 0 && rel < W)                                  // a bucket that straddles an edge, a target inside the cycle, the block's end
                 for (int i = 0; i < ntab; ++i)
@@ -588,7 +603,10 @@ struct NcoWalk {
                 int64_t k0 = f <= 0 ? 0 : ((f - 1) >> bshift) + 1;    // first bucket starting at or after `first`
                 int64_t k1 = l >= W ? kBuckets - 1 : ((l + 1) >> bshift) - 1;  // last bucket ending at or before `last`
                 if (k1 > kBuckets - 1) k1 = kBuckets - 1;
-                for (int64_t k = k0; k <= k1; ++k) { bkt[k].inc = t.inc; bkt[k].steps = ne; }
+                if (ne <= 0xffffffffL) {
+                    const uint64_t tag = ((uint64_t) stamp << 32) | (uint64_t) ne;
+                    for (int64_t k = k0; k <= k1; ++k) { bkt.inc[k] = t.inc; bkt.tag[k] = tag; }
+                }
             }
             m = m2;
         }
@@ -600,19 +618,153 @@ struct NcoWalk {
     }
 };
 
-// One channel of one block.  ch.carr_phase is the double the block starts from (1.0 included, see below); q its quantised
-// form (quantize_one without carry_in, i.e. seeded from that double).  Returns the carrier phase the reference's accumulator
-// holds after the block (gps.c:2821-2826 nsamp times) and appends the samples where the double path takes another LUT entry or
-// sign than the closed form.  One walk of each accumulator serves both: the candidates are found first (without visiting
-// samples), and the walk that carries the phase to the end of the block reports the state at the candidate samples on its way.
-static double evaluate_block(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, double delt, int nsamp, int block, int slot,
-                             CodeCache *codes, std::vector<gpsiq_patch_t> *out)
+// The double accumulator at sample n WITHOUT walking it: a rigorous enclosure.
+//
+// Every addition of the reference loop is the exact sum plus a rounding error e_j, so the unwrapped phase after n samples is
+// U_n = x_0 + n*c + d_n with d_n = e_0 + ... + e_{n-1} (wraps are exact; the carrier's y + 1.0 is one more rounding).  While
+// state and sum lie in one binade b (ulp u_b) the state is a multiple of u_b and the sum is rounded on that grid, so the
+// addition adds S_b = rnd(|c|/u_b)*u_b and e_j = +-(S_b - |c|) =: +-eps_b, a constant of the binade (ties to even: constant
+// from the second addition inside the binade on).  Let G be the piecewise linear function on [0, L] with slope eps_b/S_b
+// in binade b (0 below the lowest binade counted), continued over the wraps as G^(U) = floor(U/L)*G(L) + G(U mod L).  A steady
+// step moves the phase by +-S_b and G^ by +-eps_b = e_j exactly, so the steady steps telescope:
+//     d_n = G^(U_n) - G(x_0) + sum over the IRREGULAR steps j of (e_j - [G^(U_{j+1}) - G^(U_j)]),
+// and the irregular steps of one cycle are few and each is bounded by the ulp of its binade: the step that enters a binade
+// (rounded on the new, coarser grid from a state on the finer one: <= 1.001 u_b; twice that where |c|/u_b ends in exactly one
+// half and the first addition from an odd mantissa rounds the other way), the wrap (carrier: the sum in [1, 2) or y + 1.0,
+// <= 1.51 u_top; code: an ordinary addition in [512, 1024) followed by an exact subtraction, 0.51 u_top for the piece of G it
+// skips) and the handful of additions below 8|c| (G is flat there; <= 3 u of the lowest binade counted).  Since G^ is
+// Lipschitz with a constant of ~2^-44, U_n on the right may be replaced by R_n = x_0 + n*c (exact integer arithmetic in
+// units of c's ulp) at a cost far below one unit.  The enclosure is ~0.3 % as wide as the a-priori window n * 2^-54 the
+// candidates are found with (tests/test_reference_nco_host.py holds it against the walked accumulator on adversarial
+// addends: ties, binade-edge starts; observed use of the half-width <= 0.6), so nearly every candidate is decided here, from
+// the block's start state alone -- which is what lets the blocks of a timeline be evaluated on any thread, device or
+// process once the serial carrier chain has given their start states.
+struct Drift {
+    typedef __int128 i128;
+    bool    valid = false;
+    int     kind = 1;
+    bool    neg = false;
+    double  L = 1.0;
+    int64_t ec = 0, mc = 0;           // |c| = mc * 2^(ec - 1075)
+    int     b_lo = 0, b_top = 0;      // biased exponents of the binades that count
+    double  ulp_c = 0.0;
+    double  g[64], Gedge[65];         // slope in binade b_lo + i; G at its lower edge
+    double  edge_lo = 0.0;            // lower edge of binade b_lo (G = 0 below)
+    double  GL = 0.0, gmax = 0.0, Acyc = 0.0;
+    int     cell_shift = 0;           // log2(cell / ulp_c): a cell is 1/512 cycle (carrier) or one chip (code)
+    i128    Lint = 0;                 // L / ulp_c
+
+    void setup(double c, int kind_)
+    {
+        kind = kind_;
+        L = kind == 0 ? (double) GPSIQ_CA_SEQ_LEN : 1.0;
+        const int top_exp = kind == 0 ? 1023 + 9 : 1022;
+        neg = c < 0.0;
+        const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
+        ec = (int64_t) (bc >> 52);
+        mc = (int64_t) ((bc & kMant) | (kMant + 1));
+        // the same addends NcoWalk's fast walk takes: at least 2^6 below the top binade, not absurdly small, the code phase only climbs
+        valid = !(ec > top_exp - 6 || ec < top_exp - 40 || (kind == 0 && neg));
+        if (!valid) return;
+        ulp_c = from_bits((uint64_t) (ec - 52) << 52);
+        b_lo = (int) ec + 3; b_top = top_exp;
+        edge_lo = from_bits((uint64_t) b_lo << 52);
+        double G = 0.0, allow = 0.0;
+        gmax = 0.0;
+        for (int b = b_lo; b <= b_top; ++b) {
+            const int s = b - (int) ec;
+            int64_t dm = mc >> s;
+            const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
+            bool tie = false;
+            if (rem > half) ++dm;
+            else if (rem == half) { tie = true; dm += dm & 1; }
+            const double delta = (double) ((dm << s) - mc);                  // eps_b / ulp_c, exact
+            const double Sb = (double) dm * (double) ((int64_t) 1 << s);     // S_b / ulp_c, exact
+            const double gb = delta / Sb;
+            const double lo = from_bits((uint64_t) b << 52);
+            const double width = (kind == 0 && b == b_top) ? L - lo : lo;    // [512, 1023) for the code phase's top binade
+            g[b - b_lo] = gb;
+            Gedge[b - b_lo] = G;
+            G += gb * width;
+            if (std::fabs(gb) > gmax) gmax = std::fabs(gb);
+            allow += 1.001 * from_bits((uint64_t) (b - 52) << 52) * (tie ? 2.0 : 1.0);
+        }
+        Gedge[b_top - b_lo + 1] = G;
+        GL = G;
+        const double u_top = from_bits((uint64_t) (b_top - 52) << 52), u_lo = from_bits((uint64_t) (b_lo - 52) << 52);
+        Acyc = allow + 3.0 * u_lo + (kind == 0 ? 0.51 : 1.51) * u_top;
+        cell_shift = kind == 0 ? (int) (1075 - ec) : (int) (1075 - ec - 9);
+        Lint = kind == 0 ? (i128) GPSIQ_CA_SEQ_LEN << (1075 - ec) : (i128) 1 << (1075 - ec);
+    }
+
+    inline double Gof(double x) const            // 0 <= x <= L
+    {
+        if (x < edge_lo) return 0.0;
+        if (x >= L) return GL;
+        const int b = (int) (bits_of(x) >> 52);
+        return Gedge[b - b_lo] + g[b - b_lo] * (x - from_bits((uint64_t) b << 52));
+    }
+
+    // x0 in units of ulp_c, cut below one unit
+    inline i128 units(double x0) const
+    {
+        const uint64_t bx = bits_of(x0);
+        const int64_t ex = (int64_t) (bx >> 52);
+        if (ex == 0) return 0;
+        const i128 mx = (i128) ((bx & kMant) | (kMant + 1));
+        const int64_t sh = ex - ec;
+        return sh >= 0 ? mx << sh : (sh > -64 ? mx >> -sh : (i128) 0);
+    }
+
+    // The cell (LUT step or chip, counted from phase 0 of the block's first cycle / code period, unwrapped) that holds the double
+    // path's phase at sample n, when the enclosure lies inside one cell; false: undecided (a boundary inside the enclosure -- also
+    // every phase the reference wraps to exactly 1.0 --, a start outside [0, L), an addend the fast walk does not take).
+    bool cell_at(double x0, long n, i128 *cell) const
+    {
+        if (!valid || !(x0 >= 0.0 && x0 < L)) return false;
+        const i128 R = neg ? units(x0) - (i128) n * mc : units(x0) + (i128) n * mc;     // x0 + n*c
+        i128 q = R / Lint, r = R % Lint;
+        if (r < 0) { r += Lint; q -= 1; }
+        const double core = (double) q * GL + Gof((double) r * ulp_c) - Gof(x0);
+        const double I = ((double) (q < 0 ? -q : q) + 3.0) * Acyc;
+        const double eta = 4.0 * gmax * (std::fabs(core) + I) + 1e-12 * (std::fabs(core) + std::fabs((double) q * GL)) + 4.0 * gmax * L * 0x1p-52;
+        const i128 lo = R + (i128) std::floor((core - I - eta) / ulp_c) - 2, hi = R + (i128) std::ceil((core + I + eta) / ulp_c) + 2;
+        const i128 c0 = lo >> cell_shift, c1 = hi >> cell_shift;                          // arithmetic shifts: floor for negative phases too
+        if (c0 != c1) return false;
+        *cell = c0;
+        return true;
+    }
+};
+
+// process-wide counts (gpsiq_reference_stats): candidates seen, decided from the start state alone, walked (carrier / code)
+static std::atomic<uint64_t> g_stats[4];
+
+// The serial half: the accumulator after the block's nsamp additions of f_carr*delt (gps.c:2821-2826), from `start`.
+static inline double chain_block(double f_carr, double delt, int nsamp, double start)
 {
-    const long ns = nsamp;
-    const double carr_inc = ch.f_carr * delt, code_inc = ch.f_code * delt;
     NcoWalk cw;
-    cw.setup(carr_inc, 1);
-    if (ns <= 0) return ch.carr_phase;
+    cw.setup(f_carr * delt, 1);
+    return cw.run(start, nsamp);
+}
+
+// The parallel half: one channel of one block, given the double the reference's accumulator holds at its start (1.0 included,
+// see below).  Quantises the descriptor seeded from it (-> q) and appends the samples where the double path takes another LUT
+// entry or sign than the closed form.  The candidates are found without visiting samples (candidates()); each is decided by
+// the drift enclosure from the block's start state, and only where a boundary lies inside the enclosure are the accumulators
+// walked (from the block's start, to the last undecided sample).
+static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int nsamp, int block, int slot,
+                      CodeCache *codes, gpsiq_qchan_t *qq, std::vector<gpsiq_patch_t> *out)
+{
+    gpsiq_chan_t ch = ch_in;
+    // a start of exactly 1.0 (a wrap of the block before that rounded up to one) is phase 0 of the closed form (mod 1); the
+    // reference goes on from 1.0, and sample 0, where it indexes its table at 512, is patched
+    ch.carr_phase = start == 1.0 ? 0.0 : start;
+    const int qrc = quantize_one(ch, delt, nsamp, nullptr, qq, nullptr);
+    if (qrc != GPSIQ_OK) return qrc;
+    const gpsiq_qchan_t &q = *qq;
+    const long ns = nsamp;
+    if (ns <= 0) return GPSIQ_OK;
+    const double carr_inc = ch.f_carr * delt, code_inc = ch.f_code * delt;
     // drift bounds at the end of the block, in units of the fixed-point formats (see the header)
     const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
     const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
@@ -626,23 +778,57 @@ static double evaluate_block(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, dou
         targets.resize((size_t) ns);
         for (long n = 0; n < ns; ++n) targets[(size_t) n] = n;
     } else {
+        if (t_carr.empty() && t_code.empty()) return GPSIQ_OK;
         targets.resize(t_carr.size() + t_code.size());
         std::merge(t_carr.begin(), t_carr.end(), t_code.begin(), t_code.end(), targets.begin());
         targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
     }
-    if (targets.empty()) return cw.run(ch.carr_phase, ns);
     const int nt = (int) targets.size();
-    std::vector<double> xc((size_t) nt), xk;
+    // 1. decide from the start state alone
+    std::vector<int> idx_d((size_t) nt, -1);                 // LUT index of the double path, -1: undecided
+    std::vector<long> chips_d((size_t) nt, -1);              // chips since the start of the block's first code period, -1: undecided
+    std::vector<long> open_c, open_k;                        // samples the accumulators have to be walked to
+    const bool walk_code = every || !t_code.empty();         // without a code candidate the chip index is the closed form's everywhere
+    static const bool no_drift = std::getenv("GPSIQ_NO_DRIFT") != nullptr;      // A/B + test knob: every candidate walked
+    if (!every && !no_drift) {
+        Drift dc, dk;
+        dc.setup(carr_inc, 1);
+        if (walk_code) dk.setup(code_inc, 0);
+        for (int k = 0; k < nt; ++k) {
+            Drift::i128 cell;
+            if (carr_inc == 0.0) idx_d[(size_t) k] = -2;     // stands still: the closed form's index
+            else if (dc.cell_at(ch.carr_phase == 0.0 && start == 1.0 ? 1.0 : start, targets[(size_t) k], &cell)) idx_d[(size_t) k] = (int) (cell & 511);
+            else open_c.push_back(targets[(size_t) k]);
+            if (walk_code) {
+                if (dk.cell_at(ch.code_phase, targets[(size_t) k], &cell)) chips_d[(size_t) k] = (long) cell;
+                else open_k.push_back(targets[(size_t) k]);
+            }
+        }
+    } else {
+        open_c = targets;
+        if (walk_code) open_k = targets;
+    }
+    // 2. walk what is left (from the block's start: the walk reports the state at its targets on the way)
+    std::vector<double> xc, xk;
     std::vector<long> periods;
-    const double carr_end = cw.run(ch.carr_phase, ns, targets.data(), nt, xc.data());
-    const bool walk_code = every || !t_code.empty();
-    if (walk_code) {
+    if (!open_c.empty()) {
+        NcoWalk cw;
+        cw.setup(carr_inc, 1);
+        xc.resize(open_c.size());
+        (void) cw.run(start, open_c.back() + 1, open_c.data(), (int) open_c.size(), xc.data());
+    }
+    if (!open_k.empty()) {
         NcoWalk kw;
         kw.setup(code_inc, 0);
-        xk.resize((size_t) nt); periods.resize((size_t) nt);
-        (void) kw.run(ch.code_phase, targets[(size_t) nt - 1] + 1, targets.data(), nt, xk.data(), periods.data());
+        xk.resize(open_k.size()); periods.resize(open_k.size());
+        (void) kw.run(ch.code_phase, open_k.back() + 1, open_k.data(), (int) open_k.size(), xk.data(), periods.data());
     }
+    g_stats[0].fetch_add((uint64_t) nt * (walk_code ? 2u : 1u), std::memory_order_relaxed);
+    g_stats[1].fetch_add((uint64_t) nt * (walk_code ? 2u : 1u) - open_c.size() - open_k.size(), std::memory_order_relaxed);
+    g_stats[2].fetch_add(open_c.size(), std::memory_order_relaxed);
+    g_stats[3].fetch_add(open_k.size(), std::memory_order_relaxed);
     const uint8_t *ca = codes->get(ch.prn);
+    size_t jc = 0, jk = 0;
     for (int k = 0; k < nt; ++k) {
         const long n = targets[(size_t) k];
         // fixed-point path (include/gpsiq.h)
@@ -654,32 +840,45 @@ static double evaluate_block(const gpsiq_chan_t &ch, const gpsiq_qchan_t &q, dou
         const long per_f = (long) (A / GPSIQ_CA_SEQ_LEN);
         const unsigned neg_f = ca[chip_f] ^ nav_bit(ch, ((long) ch.icode + per_f) / 20);
         // double path
-        unsigned idx_d = (unsigned) (int) std::floor(xc[(size_t) k] * 512.0);           // gps.c:2775
-        if (idx_d > 511u) idx_d = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
+        unsigned idx;
+        if (idx_d[(size_t) k] == -2) idx = idx_f;
+        else if (idx_d[(size_t) k] >= 0) idx = (unsigned) idx_d[(size_t) k];
+        else {
+            idx = (unsigned) (int) std::floor(xc[jc++] * 512.0);                          // gps.c:2775
+            if (idx > 511u) idx = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
+        }
         unsigned neg_d = neg_f;
         if (walk_code) {
-            const unsigned chip_d = (unsigned) (int) xk[(size_t) k];                     // gps.c:2817
-            neg_d = ca[chip_d] ^ nav_bit(ch, ((long) ch.icode + periods[(size_t) k]) / 20);   // gps.c:2791-2811
+            unsigned chip_d;
+            long per_d;
+            if (chips_d[(size_t) k] >= 0) { chip_d = (unsigned) (chips_d[(size_t) k] % GPSIQ_CA_SEQ_LEN); per_d = chips_d[(size_t) k] / GPSIQ_CA_SEQ_LEN; }
+            else { chip_d = (unsigned) (int) xk[jk]; per_d = periods[jk]; ++jk; }         // gps.c:2817, 2791-2793
+            neg_d = ca[chip_d] ^ nav_bit(ch, ((long) ch.icode + per_d) / 20);             // gps.c:2791-2811
         }
-        if (idx_d != idx_f || neg_d != neg_f) {
+        if (idx != idx_f || neg_d != neg_f) {
             gpsiq_patch_t p;
             p.block = (uint32_t) block; p.sample = (uint32_t) n;
-            p.slot = (uint8_t) slot; p.neg = (uint8_t) neg_d; p.lut = (uint16_t) idx_d;
+            p.slot = (uint8_t) slot; p.neg = (uint8_t) neg_d; p.lut = (uint16_t) idx;
             out->push_back(p);
         }
     }
-    return carr_end;
+    return GPSIQ_OK;
 }
 
-// ---- the host side of GPSIQ_NCO_REFERENCE as ONE pass per channel -------------------------------------------------
-// Everything a channel needs for block b -- the accumulator the reference holds at its start, the quantised descriptor
-// seeded from it, the samples where the double path leaves the closed form -- depends on that channel's own history only
-// (the patch slot is the count of active channels before it in the block, read off the descriptors).  So one host thread
-// per channel walks the whole timeline once, block after block, and counts the pieces it has finished; whoever renders
-// (the calling thread of a batch, the device queues of a multi-device batch) waits for a piece to be complete in all
-// channels and takes its descriptors and patches while the walkers are already in the pieces behind it.  No barrier
-// between the carrier chain and the candidate search, no thread woken per piece, and the work per thread is the same for
-// every channel whatever the piece length.
+// ---- the host side of GPSIQ_NCO_REFERENCE as tasks ---------------------------------------------------------------
+// Only the carrier chain is serial: block b of a channel starts where the double accumulator left block b-1 (gps.c:2821
+// carries chan[i].carr_phase; allocateChannel re-initialises it when the slot gets another satellite, gps.c:2208-2214).
+// Everything else a block needs -- the quantised descriptor seeded from its start state, the samples where the double path
+// leaves the closed form (eval_block) -- depends on that start state alone.  So the timeline is cut into pieces and the work
+// into 2 * nchan tasks per piece: CHAIN(i, k) carries channel i through piece k and publishes the start state of each of its
+// blocks (after CHAIN(i, k-1)); EVAL(i, k) quantises and patches channel i's blocks of piece k (after CHAIN(i, k), on any
+// thread).  The threads of the shared pool (never more than GPSIQ_THREADS allows) take the runnable task of the LOWEST
+// piece, chain before evaluation: with a thread per channel every thread alternates between its chain and its evaluations,
+// with fewer the timeline is worked through piece-major -- all channels through piece k before anyone starts piece k+1 -- so
+// whoever renders (the calling thread of a batch, the device queues of a multi-device batch: they wait for a piece to be
+// complete in all channels) still gets its pieces in order and early, and a thread that finds nothing at the front runs a
+// chain ahead.  With the start states given (RefWalk::seeds: another process or device walked the chain) only the
+// evaluations run; with chain_only only the chains (gpsiq_reference_chain).
 RefWalk::RefWalk(const gpsiq_chan_t *ch_, int nblocks_, int nchan_, double delt_, int nsamp_, gpsiq_qchan_t *q_,
                  const double *carr_in_, const int *prn_in_, const std::vector<int> &piece_ends)
     : ch(ch_), nblocks(nblocks_), nchan(nchan_), nsamp(nsamp_), delt(delt_), q(q_), ends(piece_ends), have_in(carr_in_ && prn_in_)
@@ -688,20 +887,80 @@ RefWalk::RefWalk(const gpsiq_chan_t *ch_, int nblocks_, int nchan_, double delt_
     for (int i = 0; i < GPSIQ_MAX_CHAN; ++i) {
         carr_in[i] = have_in && i < nchan ? carr_in_[i] : 0.0;
         prn_in[i] = have_in && i < nchan ? prn_in_[i] : 0;
-        carr_end[i] = 0.0; last_prn[i] = 0; taken[i] = 0;
-        pthread_mutex_init(&pmu[i], nullptr);
+        carr_end[i] = 0.0; last_prn[i] = 0;
+        chain_next[i] = 0; chain_busy[i] = false; eval_next[i] = 0;
+        carr[i] = carr_in[i]; prev[i] = prn_in[i];
     }
+    patches.resize((size_t) nchan * ends.size());
     done.reset(new std::atomic<int>[ends.size()]);
     for (size_t k = 0; k < ends.size(); ++k) done[k].store(0, std::memory_order_relaxed);
     pthread_mutex_init(&mu, nullptr);
     pthread_cond_init(&cv, nullptr);
+    pthread_cond_init(&task_cv, nullptr);
 }
 
 RefWalk::~RefWalk()
 {
-    for (int i = 0; i < GPSIQ_MAX_CHAN; ++i) pthread_mutex_destroy(&pmu[i]);
     pthread_mutex_destroy(&mu);
     pthread_cond_destroy(&cv);
+    pthread_cond_destroy(&task_cv);
+}
+
+void RefWalk::set_error(int code, const char *text, int block)
+{
+    pthread_mutex_lock(&mu);
+    if (rc == GPSIQ_OK) { rc = code; std::snprintf(err, sizeof err, "block %d: %.280s", block, text); }
+    pthread_mutex_unlock(&mu);
+    abort_flag.store(true, std::memory_order_release);       // the tasks still to come finish at once (their pieces complete, waiters wake)
+}
+
+// channel i through piece k: the start state of every block, then the accumulator after it
+void RefWalk::chain_task(int i, size_t k)
+{
+    const int b0 = k ? ends[k - 1] : 0, b1 = ends[k];
+    double c = carr[i];
+    int pv = prev[i];
+    for (int b = b0; b < b1; ++b) {
+        const size_t at = (size_t) b * nchan + i;
+        const double f_carr = in ? in[at].f_carr : ch[at].f_carr, phase0 = in ? in[at].carr_phase : ch[at].carr_phase;
+        const int prn = in ? in[at].prn : ch[at].prn;
+        if (prn <= 0) { pv = 0; c = 0.0; start_out[at] = 0.0; continue; }
+        if ((b == 0 && !have_in) || pv != prn) c = phase0;
+        pv = prn;
+        start_out[at] = c;
+        if (abort_flag.load(std::memory_order_acquire)) continue;
+        // what quantize_one checks of the carrier (the evaluation reports the rest): an addend the walk is defined for
+        const double inc = f_carr * delt;
+        if (!(c >= 0.0 && c <= 1.0) || !(std::fabs(inc) < 0.5)) {
+            set_error(GPSIQ_E_RANGE, "carrier phase or Doppler outside the NCO format", b);
+            continue;
+        }
+        c = chain_block(f_carr, delt, nsamp, c);
+    }
+    carr[i] = c; prev[i] = pv;
+}
+
+// channel i's blocks of piece k: descriptors and patches from their start states
+void RefWalk::eval_task(int i, size_t k, CodeCache *codes)
+{
+    const int b0 = k ? ends[k - 1] : 0, b1 = ends[k];
+    // the task's own list: two evaluations of one channel may run at the same time (pieces k and k+1 on two threads), and
+    // whoever takes piece k's patches does so after done[k] has counted this task (release / acquire)
+    std::vector<gpsiq_patch_t> *mine = &patches[(size_t) i * ends.size() + k];
+    for (int b = b0; b < b1; ++b) {
+        const size_t at = (size_t) b * nchan + i;
+        const gpsiq_chan_t &d = ch[at];
+        if (d.prn <= 0 || abort_flag.load(std::memory_order_acquire)) {
+            gpsiq_chan_t none = d;
+            none.prn = 0;
+            (void) quantize_one(none, delt, nsamp, nullptr, &q[at], nullptr);           // an unused slot: zeroes
+            continue;
+        }
+        int slot = 0;                                            // device order: active channels first (gpsiq_set_descriptors)
+        for (int j = 0; j < i; ++j) slot += ch[(size_t) b * nchan + j].prn > 0;
+        const int erc = eval_block(d, start[at], delt, nsamp, b, slot, codes, &q[at], mine);
+        if (erc != GPSIQ_OK) set_error(erc, gpsiq_last_error(), b);
+    }
 }
 
 void RefWalk::finish_piece(size_t k)
@@ -713,62 +972,71 @@ void RefWalk::finish_piece(size_t k)
     }
 }
 
-void RefWalk::run_channel(int i)
+// one thread of the job: take tasks until none is left
+void RefWalk::work()
 {
     CodeCache codes;
-    std::vector<gpsiq_patch_t> mine;
-    // carr_in / prn_in: this timeline goes on where another call stopped: the slot's accumulator and satellite after that
-    // call's last block
-    double carr = carr_in[i];
-    int prev = prn_in[i];
-    size_t k = 0;
-    while (k < ends.size() && ends[k] == 0) finish_piece(k++);          // empty pieces in front
-    for (int b = 0; b < nblocks; ++b) {
-        gpsiq_chan_t d = ch[(size_t) b * nchan + i];
-        gpsiq_qchan_t &qq = q[(size_t) b * nchan + i];
-        if (d.prn <= 0) {
-            prev = 0; carr = 0.0;
-            (void) quantize_one(d, delt, nsamp, nullptr, &qq, nullptr);  // an unused slot: zeroes
-        } else {
-            // the carrier chain (gps.c:2821 carries chan[i].carr_phase from block to block; allocateChannel re-initialises
-            // it when the slot gets another satellite, gps.c:2208-2214)
-            if ((b == 0 && !have_in) || prev != d.prn) carr = d.carr_phase;
-            const double start = carr;
-            prev = d.prn;
-            // a start of exactly 1.0 (a wrap of the block before that rounded up to one) is phase 0 of the closed form
-            // (mod 1); the walk goes on from 1.0 as the reference does and sample 0, where the reference indexes its table
-            // at 512, is patched
-            d.carr_phase = start == 1.0 ? 0.0 : start;
-            const int qrc = quantize_one(d, delt, nsamp, nullptr, &qq, nullptr);
-            d.carr_phase = start;
-            if (qrc != GPSIQ_OK) {
-                pthread_mutex_lock(&mu);
-                if (rc == GPSIQ_OK) { rc = qrc; std::snprintf(err, sizeof err, "block %d: %.280s", b, gpsiq_last_error()); }
-                pthread_mutex_unlock(&mu);
-            } else {
-                int slot = 0;                                            // device order: active channels first (gpsiq_set_descriptors)
-                for (int j = 0; j < i; ++j) slot += ch[(size_t) b * nchan + j].prn > 0;
-                mine.clear();
-                carr = evaluate_block(d, qq, delt, nsamp, b, slot, &codes, &mine);
-                if (!mine.empty()) {
-                    pthread_mutex_lock(&pmu[i]);
-                    patches[i].insert(patches[i].end(), mine.begin(), mine.end());
-                    pthread_mutex_unlock(&pmu[i]);
-                }
+    const size_t np = ends.size();
+    pthread_mutex_lock(&mu);
+    for (;;) {
+        // the runnable task of the lowest piece; chain before evaluation, then the lower channel
+        int best_i = -1;
+        size_t best_k = np;
+        bool best_chain = false, pending = false;
+        for (int i = 0; i < nchan; ++i) {
+            if (!seeds && chain_next[i] < np) {
+                pending = true;
+                if (!chain_busy[i] && (chain_next[i] < best_k || (chain_next[i] == best_k && !best_chain))) { best_i = i; best_k = chain_next[i]; best_chain = true; }
+            }
+            if (!chain_only && eval_next[i] < np) {
+                pending = true;
+                const size_t ready = seeds ? np : chain_next[i];                      // pieces whose start states are known
+                if (eval_next[i] < ready && eval_next[i] < best_k) { best_i = i; best_k = eval_next[i]; best_chain = false; }
             }
         }
-        while (k < ends.size() && ends[k] == b + 1) finish_piece(k++);
+        if (best_i < 0) {
+            if (!pending) break;                                                      // everything is taken (running tasks finish on their threads)
+            pthread_cond_wait(&task_cv, &mu);                                         // a chain in flight will make more runnable
+            continue;
+        }
+        const int i = best_i;
+        const size_t k = best_k;
+        if (best_chain) chain_busy[i] = true; else ++eval_next[i];
+        pthread_mutex_unlock(&mu);
+        if (best_chain) {
+            chain_task(i, k);
+            if (chain_only) finish_piece(k);
+            pthread_mutex_lock(&mu);
+            chain_busy[i] = false;
+            ++chain_next[i];
+            pthread_cond_broadcast(&task_cv);                                         // EVAL(i, k) and CHAIN(i, k+1) are runnable now
+        } else {
+            eval_task(i, k, &codes);
+            finish_piece(k);
+            pthread_mutex_lock(&mu);
+        }
     }
-    carr_end[i] = carr; last_prn[i] = prev;
+    pthread_mutex_unlock(&mu);
 }
 
 void RefWalk::run()
 {
-    // a block or two (the drop-in block call): 16 channels x ~6 us here cost less than waking 15 pool threads
-    parallel_for(nchan, nblocks <= 2 ? 1 : nchan, 1, [](void *p, int i0, int i1) {
-        RefWalk &w = *static_cast<RefWalk *>(p);
-        for (int i = i0; i < i1; ++i) w.run_channel(i);
-    }, this);
+    const size_t total = (size_t) nblocks * (size_t) nchan;
+    if (seeds) start = seeds;
+    else if (!start_out) { own_start.assign(total ? total : 1, 0.0); start_out = own_start.data(); }
+    if (!seeds) start = start_out;
+    size_t k0 = 0;
+    while (k0 < ends.size() && ends[k0] == 0) ++k0;                                   // empty pieces in front
+    for (int i = 0; i < nchan; ++i) { chain_next[i] = k0; eval_next[i] = k0; }
+    for (size_t k = 0; k < k0; ++k) done[k].store(nchan, std::memory_order_release);
+    if (k0) { pthread_mutex_lock(&mu); pthread_cond_broadcast(&cv); pthread_mutex_unlock(&mu); }
+    // a block or two (the drop-in block call): 16 channels x a few microseconds cost less than waking the pool
+    const int want = nblocks <= 2 ? 1 : (chain_only || seeds ? nchan : 2 * nchan);
+    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    if (trace && want > 1 && host_threads() < nchan)
+        std::fprintf(stderr, "[gpsiq trace] reference NCO: %d host threads for %d channels: pieces are worked through piece-major\n", host_threads(), nchan);
+    run_job([](void *p) { static_cast<RefWalk *>(p)->work(); }, this, want);
+    for (int i = 0; i < nchan; ++i) { carr_end[i] = carr[i]; last_prn[i] = prev[i]; }
 }
 
 int RefWalk::wait_piece(size_t k)
@@ -782,14 +1050,11 @@ int RefWalk::wait_piece(size_t k)
 
 void RefWalk::take_patches(size_t k, std::vector<gpsiq_patch_t> *out, bool relative)
 {
-    const uint32_t b0 = k ? (uint32_t) ends[k - 1] : 0u, b1 = (uint32_t) ends[k];
+    const uint32_t b0 = k ? (uint32_t) ends[k - 1] : 0u;
     out->clear();
     for (int i = 0; i < nchan; ++i) {
-        pthread_mutex_lock(&pmu[i]);
-        size_t t = taken[i];
-        while (t < patches[i].size() && patches[i][t].block < b1) out->push_back(patches[i][t++]);
-        taken[i] = t;
-        pthread_mutex_unlock(&pmu[i]);
+        const std::vector<gpsiq_patch_t> &v = patches[(size_t) i * ends.size() + k];
+        out->insert(out->end(), v.begin(), v.end());
     }
     std::sort(out->begin(), out->end(), [](const gpsiq_patch_t &a, const gpsiq_patch_t &b) {
         if (a.block != b.block) return a.block < b.block;
@@ -804,10 +1069,19 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
                        gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
                        const double *carr_in, const int *prn_in)
 {
-    RefWalk w(ch, nblocks, nchan, delt, nsamp, q, carr_in, prn_in, std::vector<int>());
+    // a handful of pieces so that a thread-starved host still overlaps chains and evaluations; a short timeline is one piece
+    std::vector<int> ends;
+    const int chunk = nblocks > 64 ? (nblocks + 15) / 16 : nblocks;
+    for (int b = chunk; b < nblocks; b += chunk) ends.push_back(b);
+    RefWalk w(ch, nblocks, nchan, delt, nsamp, q, carr_in, prn_in, ends);
     w.run();
     if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
-    w.take_patches(0, patches, false);
+    patches->clear();
+    std::vector<gpsiq_patch_t> part;
+    for (size_t k = 0; k < w.npieces(); ++k) {
+        w.take_patches(k, &part, false);
+        patches->insert(patches->end(), part.begin(), part.end());
+    }
     for (int i = 0; i < nchan; ++i) {
         if (carr_end) carr_end[i] = w.carr_end[i];
         if (last_prn) last_prn[i] = w.last_prn[i];
@@ -818,6 +1092,63 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
 }  // namespace gpsiq
 
 using namespace gpsiq;
+
+extern "C" int gpsiq_reference_chain(const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
+                                     const double *carr_in, const int32_t *prn_in, double *carr_start, double *carr_end, int32_t *last_prn)
+{
+    if ((!in || !carr_start) && nblocks) return fail(GPSIQ_E_ARG, "null pointer");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0 || !(fs > 0.0) || (!carr_in != !prn_in)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g / continuation state", nsamp, fs);
+    std::vector<int> ends;
+    const int chunk = nblocks > 64 ? (nblocks + 15) / 16 : nblocks;
+    for (int b = chunk; b < nblocks; b += chunk) ends.push_back(b);
+    RefWalk w(nullptr, nblocks, nchan, 1.0 / fs, nsamp, nullptr, carr_in, prn_in, ends);
+    w.in = in; w.chain_only = true; w.start_out = carr_start;
+    w.run();
+    if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
+    for (int i = 0; i < nchan; ++i) {
+        if (carr_end) carr_end[i] = w.carr_end[i];
+        if (last_prn) last_prn[i] = w.last_prn[i];
+    }
+    return GPSIQ_OK;
+}
+
+extern "C" int gpsiq_reference_seeded(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp, const double *carr_start,
+                                      gpsiq_qchan_t *q, gpsiq_patch_t *patches, int max_patches, int *npatches)
+{
+    if ((!ch || !q || !carr_start) && nblocks) return fail(GPSIQ_E_ARG, "null pointer");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
+    if (nsamp < 0 || !(fs > 0.0) || max_patches < 0 || !npatches || (max_patches && !patches))
+        return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g / patch buffer", nsamp, fs);
+    for (size_t k = 0; k < (size_t) nblocks * (size_t) nchan; ++k)
+        if (ch[k].prn > 0 && !(carr_start[k] >= 0.0 && carr_start[k] <= 1.0)) return fail(GPSIQ_E_RANGE, "start phase %zu outside [0, 1]", k);
+    std::vector<int> ends;
+    const int chunk = nblocks > 64 ? (nblocks + 15) / 16 : nblocks;
+    for (int b = chunk; b < nblocks; b += chunk) ends.push_back(b);
+    RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q, nullptr, nullptr, ends);
+    w.seeds = carr_start;
+    w.run();
+    if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
+    std::vector<gpsiq_patch_t> v, part;
+    for (size_t k = 0; k < w.npieces(); ++k) {
+        w.take_patches(k, &part, false);
+        v.insert(v.end(), part.begin(), part.end());
+    }
+    *npatches = (int) v.size();
+    if (v.size() > (size_t) max_patches) return fail(GPSIQ_E_RANGE, "%zu patches, room for %d", v.size(), max_patches);
+    if (!v.empty()) std::memcpy(patches, v.data(), v.size() * sizeof(gpsiq_patch_t));
+    return GPSIQ_OK;
+}
+
+extern "C" void gpsiq_reference_stats(uint64_t out[4])
+{
+    for (int k = 0; k < 4; ++k) out[k] = g_stats[k].load(std::memory_order_relaxed);
+}
+
+extern "C" void gpsiq_chain_inputs(const gpsiq_chan_t *ch, int n, gpsiq_chain_in_t *out)
+{
+    for (int k = 0; k < n; ++k) { out[k].f_carr = ch[k].f_carr; out[k].carr_phase = ch[k].carr_phase; out[k].prn = ch[k].prn; out[k].reserved = 0; }
+}
 
 extern "C" int gpsiq_reference_batch(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp,
                                      gpsiq_qchan_t *q, gpsiq_patch_t *patches, int max_patches, int *npatches,

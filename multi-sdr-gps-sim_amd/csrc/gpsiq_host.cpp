@@ -26,56 +26,48 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-// ---- parallel_for: a small persistent worker pool -----------------------------
-// Spawning threads per call costs more than the work of a 4000-block batch on a 256-core
-// host (measured: 65 pthread_create/join ~ 2.4 ms vs 0.6 ms of quantising), so the workers
-// are created once, on first use, and sleep on a condition variable between jobs.  Ranges are
-// handed out in chunks from a shared counter; the caller works too.  One job at a time: a
-// second caller (or a nested call) simply runs its range inline.  The workers are detached
-// and never exit; the library is not meant to be dlclose()d.
+// ---- the host worker pool ---------------------------------------------------------------------------------
+// Spawning threads per call costs more than the work of a 4000-block batch on a 256-core host (measured: 65
+// pthread_create/join ~ 2.4 ms vs 0.6 ms of quantising), so the workers are created once, on first use, and sleep on a
+// condition variable between jobs.  A JOB is a function that any number of threads may run at the same time until it
+// returns (it hands out its own work: an atomic chunk counter in parallel_for, the task scheduler of RefWalk); submitting
+// one puts `helpers` tickets on a list, every idle worker takes a ticket of the oldest job that still has one, and the
+// submitting thread runs the function too -- so a job always makes progress, however busy the pool is, and SEVERAL JOBS
+// SHARE THE POOL (two contexts walking a reference-NCO timeline on two host threads, a batched refresh running ahead
+// while a walk is in flight): none of them falls back to one thread, and together they never run more threads than the
+// pool has.  Its size is the number of online CPUs, capped by GPSIQ_THREADS (several ranks of a time-sharded run share one
+// host): the cap holds for every caller, also for those that ask for a thread count of their own.  The workers are
+// detached and never exit; the library is not meant to be dlclose()d.
 namespace {
 constexpr int kMaxWorkers = 63;
+struct Job {
+    void (*entry)(void *);
+    void  *ctx;
+    int    tickets;        // helpers still wanted
+    int    running;        // helpers inside entry()
+    Job   *next;
+};
 struct Pool {
-    pthread_mutex_t submit, m;
+    pthread_mutex_t m;
     pthread_cond_t  go, done;
     int             nworkers;
-    unsigned long   gen;                 // job generation, bumped under m
-    unsigned long   start_gen[kMaxWorkers];
-    int             want, pending;       // workers [0, want) take part; pending = not finished yet
-    void          (*fn)(void *, int, int);
-    void           *ctx;
-    long            n, chunk, next;
+    Job            *head, *tail;         // jobs with tickets left, oldest first
 };
-Pool g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
-               0, 0, {}, 0, 0, nullptr, nullptr, 0, 0, 0};
+Pool g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, nullptr, nullptr};
 
-void pool_run_chunks()
+void *pool_worker(void *)
 {
     Pool &p = g_pool;
+    pthread_mutex_lock(&p.m);
     for (;;) {
-        const long b = __atomic_fetch_add(&p.next, p.chunk, __ATOMIC_RELAXED);
-        if (b >= p.n) break;
-        const long e = b + p.chunk < p.n ? b + p.chunk : p.n;
-        p.fn(p.ctx, (int) b, (int) e);
-    }
-}
-
-void *pool_worker(void *arg)
-{
-    Pool &p = g_pool;
-    const int idx = (int) (intptr_t) arg;
-    unsigned long seen = p.start_gen[idx];
-    for (;;) {
-        pthread_mutex_lock(&p.m);
-        while (p.gen == seen) pthread_cond_wait(&p.go, &p.m);
-        seen = p.gen;
-        const bool mine = idx < p.want;
+        while (!p.head) pthread_cond_wait(&p.go, &p.m);
+        Job *j = p.head;
+        ++j->running;
+        if (--j->tickets == 0) { p.head = j->next; if (!p.head) p.tail = nullptr; }
         pthread_mutex_unlock(&p.m);
-        if (!mine) continue;
-        pool_run_chunks();
+        j->entry(j->ctx);
         pthread_mutex_lock(&p.m);
-        if (--p.pending == 0) pthread_cond_signal(&p.done);
-        pthread_mutex_unlock(&p.m);
+        if (--j->running == 0 && j->tickets == 0) pthread_cond_broadcast(&p.done);
     }
     return nullptr;
 }
@@ -83,32 +75,32 @@ void *pool_worker(void *arg)
 void pool_after_fork_in_child()          // the child has none of the parent's threads
 {
     Pool &p = g_pool;
-    pthread_mutex_init(&p.submit, nullptr);
     pthread_mutex_init(&p.m, nullptr);
     pthread_cond_init(&p.go, nullptr);
     pthread_cond_init(&p.done, nullptr);
     p.nworkers = 0;
-    p.want = p.pending = 0;
+    p.head = p.tail = nullptr;
 }
 }  // namespace
 
-void parallel_for(int n, int nthreads, int grain, void (*fn)(void *, int, int), void *ctx)
+int host_threads()
 {
-    if (n <= 0) return;
-    if (grain < 1) grain = 1;
-    if (nthreads <= 0) {
-        // default: one per online CPU; GPSIQ_THREADS caps it (several ranks of a time-sharded run share one host)
-        static const int cap = [] { const char *e = std::getenv("GPSIQ_THREADS"); return e ? std::atoi(e) : 0; }();
-        long c = sysconf(_SC_NPROCESSORS_ONLN);
-        nthreads = c > 0 ? (int) c : 1;
-        if (cap > 0 && nthreads > cap) nthreads = cap;
-        const int useful = n / grain + 1;
-        if (nthreads > useful) nthreads = useful;
-    }
-    if (nthreads > n) nthreads = n;
-    if (nthreads > kMaxWorkers + 1) nthreads = kMaxWorkers + 1;
+    static const int cap = [] { const char *e = std::getenv("GPSIQ_THREADS"); return e ? std::atoi(e) : 0; }();
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    int n = c > 0 ? (int) c : 1;
+    if (cap > 0 && n > cap) n = cap;
+    if (n > kMaxWorkers + 1) n = kMaxWorkers + 1;
+    return n;
+}
+
+void run_job(void (*entry)(void *), void *ctx, int nthreads)
+{
+    const int lim = host_threads();
+    if (nthreads <= 0 || nthreads > lim) nthreads = lim;
+    if (nthreads <= 1) { entry(ctx); return; }
     Pool &p = g_pool;
-    if (nthreads <= 1 || pthread_mutex_trylock(&p.submit) != 0) { fn(ctx, 0, n); return; }
+    Job job = {entry, ctx, 0, 0, nullptr};
+    pthread_mutex_lock(&p.m);
     static bool atfork_set = false;
     if (!atfork_set) { pthread_atfork(nullptr, nullptr, pool_after_fork_in_child); atfork_set = true; }
     while (p.nworkers < nthreads - 1) {
@@ -116,27 +108,60 @@ void parallel_for(int n, int nthreads, int grain, void (*fn)(void *, int, int), 
         pthread_attr_t at;
         pthread_attr_init(&at);
         pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
-        p.start_gen[p.nworkers] = p.gen;                  // no job is in flight while we hold submit
-        const int rc = pthread_create(&th, &at, pool_worker, (void *) (intptr_t) p.nworkers);
+        const int rc = pthread_create(&th, &at, pool_worker, nullptr);
         pthread_attr_destroy(&at);
         if (rc != 0) break;
         ++p.nworkers;
     }
-    const int helpers = nthreads - 1 < p.nworkers ? nthreads - 1 : p.nworkers;
-    if (helpers == 0) { pthread_mutex_unlock(&p.submit); fn(ctx, 0, n); return; }
-    pthread_mutex_lock(&p.m);
-    p.fn = fn; p.ctx = ctx; p.n = n; p.next = 0;
-    const long per = ((long) n + (long) (helpers + 1) * 4 - 1) / ((long) (helpers + 1) * 4);
-    p.chunk = per > grain ? per : grain;
-    p.want = p.pending = helpers;
-    ++p.gen;
-    pthread_cond_broadcast(&p.go);
+    job.tickets = nthreads - 1 < p.nworkers ? nthreads - 1 : p.nworkers;
+    if (job.tickets > 0) {
+        if (p.tail) p.tail->next = &job; else p.head = &job;
+        p.tail = &job;
+        if (job.tickets == 1) pthread_cond_signal(&p.go); else pthread_cond_broadcast(&p.go);
+    }
     pthread_mutex_unlock(&p.m);
-    pool_run_chunks();
+    entry(ctx);
     pthread_mutex_lock(&p.m);
-    while (p.pending) pthread_cond_wait(&p.done, &p.m);
+    if (job.tickets > 0) {                                 // helpers that never came: take the job off the list
+        job.tickets = 0;
+        Job **pp = &p.head, *prev = nullptr;
+        while (*pp && *pp != &job) { prev = *pp; pp = &(*pp)->next; }
+        if (*pp) { *pp = job.next; if (p.tail == &job) p.tail = prev; }
+    }
+    while (job.running) pthread_cond_wait(&p.done, &p.m);
     pthread_mutex_unlock(&p.m);
-    pthread_mutex_unlock(&p.submit);
+}
+
+namespace {
+struct Chunks { void (*fn)(void *, int, int); void *ctx; long n, chunk, next; };
+void run_chunks(void *arg)
+{
+    Chunks &c = *static_cast<Chunks *>(arg);
+    for (;;) {
+        const long b = __atomic_fetch_add(&c.next, c.chunk, __ATOMIC_RELAXED);
+        if (b >= c.n) break;
+        const long e = b + c.chunk < c.n ? b + c.chunk : c.n;
+        c.fn(c.ctx, (int) b, (int) e);
+    }
+}
+}  // namespace
+
+void parallel_for(int n, int nthreads, int grain, void (*fn)(void *, int, int), void *ctx)
+{
+    if (n <= 0) return;
+    if (grain < 1) grain = 1;
+    const int lim = host_threads();
+    if (nthreads <= 0) {
+        nthreads = lim;
+        const int useful = n / grain + 1;
+        if (nthreads > useful) nthreads = useful;
+    }
+    if (nthreads > lim) nthreads = lim;                     // GPSIQ_THREADS holds for explicit counts too
+    if (nthreads > n) nthreads = n;
+    if (nthreads <= 1) { fn(ctx, 0, n); return; }
+    const long per = ((long) n + (long) nthreads * 4 - 1) / ((long) nthreads * 4);
+    Chunks c = {fn, ctx, n, per > grain ? per : grain, 0};
+    run_job(run_chunks, &c, nthreads);
 }
 
 // C/A code of one PRN (replaces codegen(), reference gps.c:272-309): G1 = x^10+x^3+1,

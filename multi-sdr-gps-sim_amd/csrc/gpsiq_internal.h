@@ -42,20 +42,24 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
                        gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
                        const double *carr_in = nullptr, const int *prn_in = nullptr);
 
-// The same as a walker that can be consumed piece by piece while it runs (gpsiq_exact.cpp): one host thread per channel goes
-// through the whole timeline once; piece k = blocks [ends[k-1], ends[k]) is complete when every channel has finished it.
+// The same as a walker that can be consumed piece by piece while it runs (gpsiq_exact.cpp): the timeline is cut into pieces,
+// piece k = blocks [ends[k-1], ends[k]); per piece and channel one CHAIN task (serial down the channel: the start state of
+// every block) and one EVAL task (descriptors + patches from the start states, any thread); piece k is complete when every
+// channel's EVAL (chain_only: CHAIN) of it has finished.
+struct CodeCache;
 struct RefWalk {
     RefWalk(const gpsiq_chan_t *ch, int nblocks, int nchan, double delt, int nsamp, gpsiq_qchan_t *q,
             const double *carr_in, const int *prn_in, const std::vector<int> &piece_ends);
     ~RefWalk();
     RefWalk(const RefWalk &) = delete;
     RefWalk &operator=(const RefWalk &) = delete;
-    void run();                                   // returns when every channel has walked every block; call from any ONE thread
+    void run();                                   // returns when every task has run; call from any ONE thread (it works too)
     int  wait_piece(size_t k);                    // blocks until piece k is complete; the first error so far (GPSIQ_OK if none)
-    // the patches of piece k (pieces must be taken in ascending order), sorted by (block, sample, slot); relative: block
+    // the patches of piece k (complete: wait_piece(k) first, or after run()), sorted by (block, sample, slot); relative: block
     // indices counted from the piece's first block
     void take_patches(size_t k, std::vector<gpsiq_patch_t> *out, bool relative);
     size_t npieces() const { return ends.size(); }
+    void abort() { abort_flag.store(true, std::memory_order_release); }     // the remaining tasks finish at once (pieces still complete)
 
     const gpsiq_chan_t *ch; int nblocks, nchan, nsamp; double delt; gpsiq_qchan_t *q;
     std::vector<int> ends;
@@ -63,18 +67,38 @@ struct RefWalk {
     double carr_in[GPSIQ_MAX_CHAN]; int prn_in[GPSIQ_MAX_CHAN];
     double carr_end[GPSIQ_MAX_CHAN]; int last_prn[GPSIQ_MAX_CHAN];       // valid after run()
     int rc = GPSIQ_OK; char err[320] = "";
+    // set before run():
+    const gpsiq_chain_in_t *in = nullptr;         // chain inputs in compact form instead of ch (chain_only)
+    const double *seeds = nullptr;                // [nblocks][nchan] start states known: no chain tasks
+    bool    chain_only = false;                   // no EVAL tasks (q, ch may be null when `in` is given)
+    double *start_out = nullptr;                  // where the chain publishes the start states (default: own storage)
 private:
-    void run_channel(int i);
+    void work();
+    void chain_task(int i, size_t k);
+    void eval_task(int i, size_t k, CodeCache *codes);
     void finish_piece(size_t k);
-    std::vector<gpsiq_patch_t> patches[GPSIQ_MAX_CHAN];
-    size_t taken[GPSIQ_MAX_CHAN];
-    pthread_mutex_t pmu[GPSIQ_MAX_CHAN], mu;
-    pthread_cond_t cv;
+    void set_error(int code, const char *text, int block);
+    std::vector<std::vector<gpsiq_patch_t>> patches;                    // [channel][piece]: written by that EVAL task alone
+    pthread_mutex_t mu;
+    pthread_cond_t cv, task_cv;
     std::unique_ptr<std::atomic<int>[]> done;
+    std::atomic<bool> abort_flag{false};
+    // scheduler state, under mu
+    size_t chain_next[GPSIQ_MAX_CHAN], eval_next[GPSIQ_MAX_CHAN];
+    bool   chain_busy[GPSIQ_MAX_CHAN];
+    double carr[GPSIQ_MAX_CHAN]; int prev[GPSIQ_MAX_CHAN];               // the chain's state per channel (owned by the running CHAIN task)
+    const double *start = nullptr;
+    std::vector<double> own_start;
 };
 
+// Host threads this process may use: online CPUs, capped by GPSIQ_THREADS (read once).
+int host_threads();
+// Run entry(ctx) on the calling thread and on up to nthreads - 1 workers of the shared pool at the same time (<= 0: as many
+// as host_threads() allows; never more than that).  entry hands out its own work and returns when none is left; run_job
+// returns when every thread that entered has returned.  Jobs of several callers share the pool (gpsiq_host.cpp).
+void run_job(void (*entry)(void *ctx), void *ctx, int nthreads);
 // Run fn(ctx, begin, end) over [0, n) on up to nthreads host threads (<= 0: one per online
-// CPU, but at least `grain` items per thread).  Returns after all parts are done.
+// CPU, but at least `grain` items per thread; never more than host_threads()).  Returns after all parts are done.
 void parallel_for(int n, int nthreads, int grain, void (*fn)(void *ctx, int begin, int end), void *ctx);
 
 // |gain| bound of every entry point that takes a gain: (int)(250*|gain|) of 16 channels must fit the 32-bit sums with

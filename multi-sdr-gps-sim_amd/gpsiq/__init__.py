@@ -77,6 +77,10 @@ _generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i,
 _generate_quantized = _sig("gpsiq_generate_quantized", _i, _vp, _vp, _i, _i, _i, _i, _vp, _i)
 _quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp)
 _reference_batch = _sig("gpsiq_reference_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _i, C.POINTER(C.c_int), _vp)
+_reference_chain = _sig("gpsiq_reference_chain", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp)
+_reference_seeded = _sig("gpsiq_reference_seeded", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp, _i, C.POINTER(C.c_int))
+_reference_stats = _sig("gpsiq_reference_stats", None, _vp)
+_chain_inputs = _sig("gpsiq_chain_inputs", None, _vp, _i, _vp)
 _set_patches = _sig("gpsiq_set_patches", _i, _vp, _vp, _i)
 _set_nco_mode = _sig("gpsiq_set_nco_mode", _i, _vp, _i)
 _generate_batch_multi = _sig("gpsiq_generate_batch_multi", _i, _vp, _i, _vp, _i, _i, _i, _d, _i, _vp, _vp, _vp)
@@ -188,6 +192,57 @@ def reference_blocks(desc, fs, nsamp):
             continue
         _check(rc)
         return q, pt[: n.value].copy(), carr
+
+
+def chain_inputs(desc):
+    """gpsiq_chain_inputs: the three fields per channel and block the serial carrier chain reads, [nblocks][nchan] x 24 bytes."""
+    from .abi import CHAIN_IN_DTYPE
+    desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+    out = np.zeros(desc.shape, dtype=CHAIN_IN_DTYPE)
+    _chain_inputs(_p(desc), desc.size, _p(out))
+    return out
+
+
+def reference_chain(cin, fs, nsamp, carr_in=None, prn_in=None):
+    """gpsiq_reference_chain: the serial half of GPSIQ_NCO_REFERENCE alone.  cin [nblocks][nchan] (chain_inputs, or any
+    subset of its columns: the channels are independent) -> (carr_start[nblocks][nchan], carr_end[nchan], last_prn[nchan])."""
+    from .abi import CHAIN_IN_DTYPE
+    cin = np.ascontiguousarray(cin, dtype=CHAIN_IN_DTYPE)
+    nb, nc = cin.shape
+    start = np.zeros((nb, nc), dtype=np.float64)
+    end = np.zeros(nc, dtype=np.float64)
+    last = np.zeros(nc, dtype=np.int32)
+    ci = None if carr_in is None else np.ascontiguousarray(carr_in, dtype=np.float64)
+    pi = None if prn_in is None else np.ascontiguousarray(prn_in, dtype=np.int32)
+    _check(_reference_chain(_p(cin), nb, nc, float(fs), int(nsamp), None if ci is None else _p(ci), None if pi is None else _p(pi),
+                            _p(start), _p(end), _p(last)))
+    return start, end, last
+
+
+def reference_seeded(desc, fs, nsamp, carr_start):
+    """gpsiq_reference_seeded: the parallel half -- (q, patches) of blocks whose start states are known."""
+    desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+    nb, nc = desc.shape
+    st = np.ascontiguousarray(carr_start, dtype=np.float64)
+    assert st.shape == (nb, nc)
+    q = np.zeros((nb, nc), dtype=QCHAN_DTYPE)
+    n = C.c_int(0)
+    cap = 64 + 8 * nb
+    while True:
+        pt = np.zeros(cap, dtype=PATCH_DTYPE)
+        rc = _reference_seeded(_p(desc), nb, nc, float(fs), int(nsamp), _p(st), _p(q), _p(pt), cap, C.byref(n))
+        if rc == -2 and n.value > cap:
+            cap = n.value
+            continue
+        _check(rc)
+        return q, pt[: n.value].copy()
+
+
+def reference_stats():
+    """gpsiq_reference_stats: (states needed, decided from the start state, carrier walks, code walks) since the process started."""
+    out = np.zeros(4, dtype=np.uint64)
+    _reference_stats(_p(out))
+    return tuple(int(v) for v in out)
 
 
 def shard_carry(q, nsamp):

@@ -29,6 +29,9 @@ assert QCHAN_DTYPE.itemsize == 48
 PATCH_DTYPE = np.dtype([("block", "<u4"), ("sample", "<u4"), ("slot", "u1"), ("neg", "u1"), ("lut", "<u2")], align=True)
 assert PATCH_DTYPE.itemsize == 12
 NCO_FIXED, NCO_REFERENCE = 0, 1
+# gpsiq_chain_in_t (the three fields of gpsiq_chan_t the serial carrier chain of GPSIQ_NCO_REFERENCE reads)
+CHAIN_IN_DTYPE = np.dtype([("f_carr", "<f8"), ("carr_phase", "<f8"), ("prn", "<i4"), ("reserved", "<i4")], align=True)
+assert CHAIN_IN_DTYPE.itemsize == 24
 # gpsiq_shard_carry_t
 SHARD_CARRY_DTYPE = np.dtype([("end_phase", "<u8"), ("advance", "<u8"), ("first_prn", "<i4"), ("last_prn", "<i4"),
                               ("reseeded", "<i4"), ("nblocks", "<i4")], align=True)

@@ -55,6 +55,56 @@ def seed_own_shard(q, nsamp, rank, world, all_gather_bytes, history=None):
     return seeded
 
 
+def gather_ragged(all_gather_bytes, payload):
+    """all_gather_bytes for payloads whose length differs from rank to rank (the first nblocks % world ranks own one
+    block more; the channels of the chain do not divide evenly either): lengths first, then the payloads padded."""
+    lens = [int.from_bytes(b, "little") for b in all_gather_bytes(len(payload).to_bytes(8, "little"))]
+    width = max(lens)
+    parts = all_gather_bytes(payload + bytes(width - len(payload)))
+    return [p[:n] for p, n in zip(parts, lens)]
+
+
+def reference_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes):
+    """GPSIQ_NCO_REFERENCE time-sharded over processes: this rank's rows of gpsiq_reference_batch over the WHOLE timeline
+    -- (q_own, patches_own with block indices counted from its first block, carr_end[nchan] after the last block of the
+    whole timeline) -- from its own blocks' descriptors.  Only the carrier chain is serial in time, and it is serial per
+    channel: so the chain is sharded by CHANNEL (rank r walks channels [c0, c1) of the whole timeline: 24 bytes per channel and
+    block in, 8 bytes out), everything else by time (every rank evaluates its own blocks from their start states):
+        1. all-gather the chain inputs of everybody's blocks (gpsiq_chain_inputs: f_carr, carr_phase, prn);
+        2. gpsiq_reference_chain over this rank's channels, all blocks;
+        3. all-gather the start states;
+        4. gpsiq_reference_seeded over this rank's blocks, all channels.
+    Two small host-side exchanges at set-up (a gloo group, MPI, pipes ...); nothing on the data path."""
+    from . import chain_inputs, reference_chain, reference_seeded, shard_range
+    from .abi import CHAIN_IN_DTYPE
+    desc_own = np.ascontiguousarray(desc_own)
+    nchan = desc_own.shape[1]
+    parts = gather_ragged(all_gather_bytes, chain_inputs(desc_own).tobytes())
+    cin = np.concatenate([np.frombuffer(p, dtype=CHAIN_IN_DTYPE).reshape(-1, nchan) for p in parts])       # timeline order = rank order
+    first = sum(len(p) // (CHAIN_IN_DTYPE.itemsize * nchan) for p in parts[:rank])
+    c0, c1 = shard_range(nchan, rank, world)
+    if c1 > c0:
+        st, end, last = reference_chain(np.ascontiguousarray(cin[:, c0:c1]), fs, nsamp)
+    else:
+        st, end, last = np.zeros((len(cin), 0)), np.zeros(0), np.zeros(0, dtype=np.int32)
+    cols = gather_ragged(all_gather_bytes, st.tobytes() + end.tobytes() + last.astype(np.int32).tobytes())
+    start = np.zeros((len(cin), nchan))
+    carr_end = np.zeros(nchan)
+    last_prn = np.zeros(nchan, dtype=np.int32)
+    for r, blob in enumerate(cols):
+        a0, a1 = shard_range(nchan, r, world)
+        w = a1 - a0
+        if w == 0:
+            continue
+        n_st = len(cin) * w * 8
+        start[:, a0:a1] = np.frombuffer(blob[:n_st], dtype=np.float64).reshape(len(cin), w)
+        carr_end[a0:a1] = np.frombuffer(blob[n_st:n_st + 8 * w], dtype=np.float64)
+        last_prn[a0:a1] = np.frombuffer(blob[n_st + 8 * w:n_st + 12 * w], dtype=np.int32)
+    q, patches = reference_seeded(desc_own, fs, nsamp, start[first:first + len(desc_own)])
+    # what gpsiq_reference_batch hands out after the last block: the accumulator of a slot in use, the descriptor's own phase otherwise
+    return q, patches, carr_end, last_prn
+
+
 def torch_all_gather_bytes(dist, device="cpu", group=None):
     """all_gather_bytes over a torch.distributed process group (gloo on CPU tensors, RCCL on GPU tensors).
     A run that prepares its next round while the GPUs are busy wants a gloo group here: an RCCL collective

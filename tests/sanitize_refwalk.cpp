@@ -1,6 +1,8 @@
 // sanitize_refwalk.cpp -- the one-pass reference walker consumed piece by piece while it runs (what generate_reference and
 // gpsiq_generate_batch_multi do on the device side), host only, for ThreadSanitizer / ASan + UBSan builds: the pieces taken
-// while the walkers run must add up to what one call over the whole timeline gives.  TEST INFRASTRUCTURE.
+// while the walkers run must add up to what one call over the whole timeline gives; two timelines walked at once on two host
+// threads; the chain and the evaluation called on their own (channel subsets, time ranges).  Run once with the default pool
+// and once under GPSIQ_THREADS=2 (fewer threads than channels: piece-major order).  TEST INFRASTRUCTURE.
 #include "gpsiq_internal.h"
 
 #include <cstdio>
@@ -62,6 +64,50 @@ int main()
         if (all.size() != p0.size() || (all.size() && std::memcmp(all.data(), p0.data(), all.size() * sizeof(gpsiq_patch_t)) != 0)) { std::fprintf(stderr, "patches differ: %zu vs %zu\n", all.size(), p0.size()); return 1; }
         for (int c = 0; c < nc; ++c)
             if (w.carr_end[c] != carr0[c] || w.last_prn[c] != prn0[c]) { std::fprintf(stderr, "end state differs in slot %d\n", c); return 1; }
+    }
+    // two timelines walked at the same time on two host threads (two contexts of one process): they share the pool, neither
+    // falls back to one thread, both equal the single call
+    {
+        std::vector<gpsiq_qchan_t> qa((size_t) nb * nc), qb((size_t) nb * nc);
+        std::vector<int> ends = {16, 40, nb};
+        RefWalk wa(ch.data(), nb, nc, delt, ns, qa.data(), nullptr, nullptr, ends), wb(ch.data(), nb, nc, delt, ns, qb.data(), nullptr, nullptr, ends);
+        pthread_t ta, tb;
+        if (pthread_create(&ta, nullptr, run_walk, &wa) != 0 || pthread_create(&tb, nullptr, run_walk, &wb) != 0) return 1;
+        pthread_join(ta, nullptr); pthread_join(tb, nullptr);
+        if (wa.rc != GPSIQ_OK || wb.rc != GPSIQ_OK) { std::fprintf(stderr, "concurrent walks: %s %s\n", wa.err, wb.err); return 1; }
+        if (std::memcmp(qa.data(), q0.data(), qa.size() * sizeof(gpsiq_qchan_t)) != 0 || std::memcmp(qb.data(), q0.data(), qb.size() * sizeof(gpsiq_qchan_t)) != 0) { std::fprintf(stderr, "concurrent walks: descriptors differ\n"); return 1; }
+        for (int c = 0; c < nc; ++c)
+            if (wa.carr_end[c] != carr0[c] || wb.carr_end[c] != carr0[c]) { std::fprintf(stderr, "concurrent walks: end state differs in slot %d\n", c); return 1; }
+    }
+    // the two halves on their own: the chain over channel subsets (as ranks of a sharded run walk them), then the blocks
+    // evaluated from their start states in two time ranges == the single call
+    {
+        std::vector<gpsiq_chain_in_t> cin((size_t) nb * nc);
+        gpsiq_chain_inputs(ch.data(), nb * nc, cin.data());
+        std::vector<double> start((size_t) nb * nc);
+        const int split = 5;
+        for (int part = 0; part < 2; ++part) {
+            const int c0 = part ? split : 0, c1 = part ? nc : split, w = c1 - c0;
+            std::vector<gpsiq_chain_in_t> cols((size_t) nb * w);
+            std::vector<double> st((size_t) nb * w), end((size_t) w);
+            std::vector<int32_t> last((size_t) w);
+            for (int b = 0; b < nb; ++b) for (int c = 0; c < w; ++c) cols[(size_t) b * w + c] = cin[(size_t) b * nc + c0 + c];
+            if (gpsiq_reference_chain(cols.data(), nb, w, fs, ns, nullptr, nullptr, st.data(), end.data(), last.data()) != GPSIQ_OK) { std::fprintf(stderr, "chain: %s\n", gpsiq_last_error()); return 1; }
+            for (int b = 0; b < nb; ++b) for (int c = 0; c < w; ++c) start[(size_t) b * nc + c0 + c] = st[(size_t) b * w + c];
+            for (int c = 0; c < w; ++c)
+                if (end[(size_t) c] != carr0[c0 + c] || last[(size_t) c] != prn0[c0 + c]) { std::fprintf(stderr, "chain: end state differs in slot %d\n", c0 + c); return 1; }
+        }
+        std::vector<gpsiq_qchan_t> qs((size_t) nb * nc);
+        std::vector<gpsiq_patch_t> ps(p0.size() + 8), all;
+        const int cut = 29;
+        for (int part = 0; part < 2; ++part) {
+            const int b0 = part ? cut : 0, b1 = part ? nb : cut;
+            int np = 0;
+            if (gpsiq_reference_seeded(&ch[(size_t) b0 * nc], b1 - b0, nc, fs, ns, &start[(size_t) b0 * nc], &qs[(size_t) b0 * nc], ps.data(), (int) ps.size(), &np) != GPSIQ_OK) { std::fprintf(stderr, "seeded: %s\n", gpsiq_last_error()); return 1; }
+            for (int k = 0; k < np; ++k) { gpsiq_patch_t p = ps[(size_t) k]; p.block += (uint32_t) b0; all.push_back(p); }
+        }
+        if (std::memcmp(qs.data(), q0.data(), qs.size() * sizeof(gpsiq_qchan_t)) != 0) { std::fprintf(stderr, "seeded: descriptors differ\n"); return 1; }
+        if (all.size() != p0.size() || std::memcmp(all.data(), p0.data(), all.size() * sizeof(gpsiq_patch_t)) != 0) { std::fprintf(stderr, "seeded: patches differ: %zu vs %zu\n", all.size(), p0.size()); return 1; }
     }
     if (p0.empty()) { std::fprintf(stderr, "the scenario should have patches\n"); return 1; }
     std::printf("ok\n");

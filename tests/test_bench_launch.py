@@ -60,3 +60,19 @@ def test_gpus_8_dry_run_is_one_line_from_eight_ranks():
     assert all(p["host_ms_per_round"] > 0.0 and p["threads"] == out["config"]["host_threads_per_rank"] for p in st["per_rank"])
     assert st["bound"] is None and all(p["kernel_ms_per_round"] is None for p in st["per_rank"])       # no device in a dry run
     assert "bound" in out["end_to_end"] and out["end_to_end"]["bound"] is None
+
+
+def test_collective_selftest_statements_run_over_gloo():
+    """bench.py's default N = 1 run executes rccl_selftest(): the collective stack of its N > 1 branch as a world of one
+    rank over RCCL, after gpsiq.Context exists.  Here the same statements over gloo (no GPU): init with an explicit
+    tcp://127.0.0.1 rendezvous, all_reduce(MAX) float64, all_gather uint8, barrier, a gloo side group, destroy."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.rccl_selftest(0, backend="gloo")
+    assert out["ok"] is True and "error" not in out, out
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    # a failure is reported, not raised
+    out = bench.rccl_selftest(0, backend="no_such_backend")
+    assert out["ok"] is False and "init_process_group" in out["error"]

@@ -103,8 +103,32 @@ def test_reference_walker_consumed_in_pieces_under_sanitizers(tmp_path, san):
                         os.path.join(csrc, "gpsiq_exact.cpp"), "-lpthread", "-lm"], capture_output=True, text=True)
     if b.returncode != 0:
         pytest.skip("no sanitizer toolchain / runtime here: " + b.stderr[-300:])
-    r = run_sanitized([exe], timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
-    assert r.returncode == 0 and r.stdout.strip() == "ok" and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+    for threads in (None, "2", "1"):      # the default pool; fewer threads than channels (piece-major); no helpers at all
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+        if threads:
+            env["GPSIQ_THREADS"] = threads
+        r = run_sanitized([exe], timeout=900, env=env)
+        assert r.returncode == 0 and r.stdout.strip() == "ok" and "WARNING: ThreadSanitizer" not in r.stderr, (threads, (r.stdout + r.stderr)[-3000:])
+
+
+def test_drift_enclosure_holds_the_walked_accumulator(tmp_path):
+    """The decision GPSIQ_NCO_REFERENCE takes WITHOUT walking an accumulator (Drift in csrc/gpsiq_exact.cpp: an enclosure of
+    the reference's double phase at sample n from the block's start state alone) against the accumulator walked exactly
+    (Nco::advance, itself pinned to the plain loop of gps.c:2789-2792 / 2821-2826 by test_reference_nco_host.py): 400 000
+    random and adversarial cases per seed -- carrier both signs and code, four sample rates, addends with trailing zero
+    mantissas (exact-tie binades), tiny and binade-edge start states -- every one inside the enclosure, no more than 0.7 of
+    its half-width used, and the enclosure two orders of magnitude narrower than the a-priori window."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "multi-sdr-gps-sim_amd", "csrc")
+    exe = str(tmp_path / "drift_enclosure")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"), "-I" + csrc, "-o", exe,
+                    os.path.join(root, "tests", "drift_enclosure.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), "-lpthread", "-lm"], check=True)
+    for seed in ("1", "7"):
+        r = subprocess.run([exe, seed], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = dict(kv.split("=") for kv in r.stdout.split())
+        assert int(f["bad"]) == 0 and int(f["checked"]) > 300000
+        assert float(f["max_use"]) < 0.7 and float(f["mean_width"]) < 0.01 and float(f["worst_width"]) < 0.1, r.stdout
 
 
 def test_fifo_header_matches_reference_api():

@@ -77,3 +77,79 @@ def test_two_rank_time_sharding_is_seamless(oracle):
     assert [got[b] for b in range(NBLOCKS)] == want
     assert shard_range(7, 0, 2) == (0, 4) and shard_range(7, 1, 2) == (4, 7)
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+# ---- GPSIQ_NCO_REFERENCE over processes ---------------------------------------------------------------------------
+RFS, RNS, RNB, RNCH = 10.0e6, 200000, 11, 7
+
+
+def _ref_timeline():
+    """Phases a hair off LUT / chip boundaries and whole numbers of samples per LUT step and chip on some channels (plenty of
+    candidates and patches), a slot going out of view and one re-allocated."""
+    from gpsiq.scenario import synth_blocks
+    rng = np.random.default_rng(5)
+    d = synth_blocks(RNB, RNCH, seed=23)
+    d["carr_phase"][:] = (rng.integers(0, 512, (RNB, RNCH)) + 1e-12) / 512.0
+    d["code_phase"][:] = rng.integers(0, 1023, (RNB, RNCH)) + 1e-9
+    for c in (0, 3):
+        d["f_carr"][:, c] = RFS / 512.0 / (5 + c)
+        d["f_code"][:, c] = RFS / 25.0
+        d["carr_phase"][:, c] = rng.integers(0, 512, RNB) / 512.0 + 2.0 ** -12 - 2.0 ** -50
+        d["code_phase"][:, c] = rng.integers(1, 7, RNB) - 2.0 ** -41
+    d["prn"][4:7, 2] = 0
+    d["prn"][8:, 5] = 29
+    return d
+
+
+def _ref_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+    import torch.distributed as dist
+    import gpsiq
+    from gpsiq.shard import reference_own_shard, shard_range, torch_all_gather_bytes
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    b0, b1 = shard_range(RNB, rank, world)
+    # this rank sees ONLY its own rows of the timeline
+    q, patches, carr_end, last_prn = reference_own_shard(_ref_timeline()[b0:b1], RFS, RNS, rank, world, torch_all_gather_bytes(dist))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (b0, b1, q.tobytes(), patches.tobytes(), carr_end.tobytes(), last_prn.tobytes()))
+    if rank == 0:
+        out.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_nco_shards_equal_the_whole_timeline(world):
+    """Two (three) gloo ranks, each holding only its own blocks' descriptors: the carrier chain sharded by channel
+    (gpsiq_reference_chain over each rank's channels of the whole timeline), everything else by time
+    (gpsiq_reference_seeded over each rank's blocks) -- descriptors, patches and the carried phase equal
+    gpsiq_reference_batch over the whole timeline in one process."""
+    import gpsiq
+    from gpsiq.abi import PATCH_DTYPE, QCHAN_DTYPE
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_ref_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = _ref_timeline()
+    q, patches, carr = gpsiq.reference_blocks(d, RFS, RNS)
+    assert len(patches) > 20
+    seen = 0
+    for b0, b1, qb, pb, cb, lb in gathered:
+        assert np.frombuffer(qb, dtype=QCHAN_DTYPE).reshape(-1, RNCH).tobytes() == q[b0:b1].tobytes(), (b0, b1)
+        want = patches[(patches["block"] >= b0) & (patches["block"] < b1)].copy()
+        want["block"] -= b0
+        assert np.frombuffer(pb, dtype=PATCH_DTYPE).tobytes() == want.tobytes(), (b0, b1)
+        seen += len(want)
+        act = d[-1]["prn"] > 0
+        assert np.array_equal(np.frombuffer(cb)[act], carr[act])              # every rank knows the state after the whole timeline
+        assert np.array_equal(np.frombuffer(lb, dtype=np.int32), np.where(act, d[-1]["prn"], 0))
+    assert seen == len(patches)
