@@ -501,6 +501,9 @@ def main():
                                    "m+1 overlaps the kernel of round m (double-buffered descriptor sets); slowest rank, best of 2 passes"}
         # what the rounds of a long run are bound by on the slowest rank (the serial batch above is host + kernel by construction)
         e2e["bound"] = e2e["streamed"]["bound"]
+        ref_sharded = None
+        if world > 1 and not args.no_extra:
+            ref_sharded = reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather, dry, xdev)
         if not dry:
             ctx.set_descriptors(q)
 
@@ -571,6 +574,9 @@ def main():
             if "reference_nco" in extra:
                 out["reference_nco"] = extra.pop("reference_nco")
             out["extra"] = extra
+        if ref_sharded is not None:
+            out["reference_nco"] = dict(ref_sharded, nco_mode="reference (GPSIQ_NCO_REFERENCE), time-sharded: see `what`",
+                                        value=ref_sharded["legs"]["2M6_int8_16ch"]["value"], unit="Msamples/s")
         print(json.dumps(out), flush=True)
     if ctx is not None:
         ctx.close()
@@ -641,6 +647,69 @@ def rccl_selftest(dev, backend="nccl"):
                 dist.destroy_process_group()
         except Exception:
             pass
+    return out
+
+
+def reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather, dry, xdev):
+    """GPSIQ_NCO_REFERENCE (the model whose output IS the reference's) time-sharded over the ranks, per rank: its own blocks'
+    descriptors -> gpsiq/shard.py reference_own_shard (carrier chain sharded by CHANNEL: 24 B per channel and block all-gathered,
+    gpsiq_reference_chain over this rank's channels of the whole timeline, 8 B per channel and block all-gathered back;
+    gpsiq_reference_seeded over its own blocks) -> gpsiq_set_descriptors + gpsiq_set_patches -> one gpsiq_launch.  Reported per
+    rank with what bounds it; `value` = all ranks' samples / slowest rank's time, best of 2 passes."""
+    import gpsiq
+    from gpsiq.abi import NCO_REFERENCE  # noqa: F401
+    from gpsiq.scenario import synth_blocks
+    from gpsiq.shard import max_over_ranks, reference_own_shard, shard_range
+    out = {"legs": {}}
+    pat = synth_blocks(64, args.nchan, seed=args.seed)
+    for label, fs_r, ss_r, nb_r in (("2M6_int8_16ch", args.fs, args.sample_size, 2000), ("25M_int16_16ch", 25e6, 2, 200)):
+        ns_r = int(round(fs_r / 10))
+        blk_r = 2 * ns_r * ss_r
+        if ring is not None:
+            nb_r = min(nb_r, ring.numel() // blk_r)
+        b0, b1 = shard_range(nb_r * world, rank, world)            # nb_r blocks per rank: weak scaling, like the headline
+        d_own = pat[np.arange(b0, b1) % 64]
+        best = None
+        for _ in range(2):
+            if dist is not None:
+                dist.barrier()
+            parts = {}
+            t0 = time.perf_counter()
+
+            def timed_gather(b, _p=parts):
+                t = time.perf_counter()
+                r = cpu_gather(b)
+                _p["exchange"] = _p.get("exchange", 0.0) + time.perf_counter() - t
+                return r
+            q_r, patches, _, _ = reference_own_shard(d_own, fs_r, ns_r, rank, world, timed_gather)
+            t1 = time.perf_counter()
+            if not dry:
+                ctx.set_descriptors(q_r)
+                ctx.set_patches(patches)
+                t2 = time.perf_counter()
+                ctx.launch(0, len(q_r), ns_r, ss_r, ring.data_ptr(), blk_r, stream=stream)
+                import torch
+                torch.cuda.synchronize()
+            else:
+                t2 = time.perf_counter()
+            t3 = time.perf_counter()
+            tot = max_over_ranks(t3 - t0, dist, device=xdev)
+            if best is None or tot < best[0]:
+                best = (tot, t1 - t0, parts.get("exchange", 0.0), t2 - t1, t3 - t2, len(patches))
+        tot, host, exch, upload, kern, npatch = best
+        mine = {"rank": rank, "host_chain_and_evaluation_ms": round((host - exch) * 1e3, 3), "exchange_ms": round(exch * 1e3, 3),
+                "validate_upload_ms": round(upload * 1e3, 3), "kernel_and_patches_ms": None if dry else round(kern * 1e3, 3),
+                "patched_samples": npatch, "threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus()}
+        mine["bound"] = None if dry else ("host" if host > kern else "kernel")
+        per_rank = [json.loads(b.decode()) for b in cpu_gather(json.dumps(mine).ljust(320).encode())]
+        out["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks per GPU, one serial pass "
+                                          "(host chain + evaluation, upload, one launch)",
+                              "value": None if dry else round(nb_r * world * ns_r / tot / 1e6, 1), "unit": "Msamples/s",
+                              "x_realtime": None if dry else round(nb_r * world * 0.1 / tot, 1), "seconds": round(tot, 5), "per_rank": per_rank,
+                              "bound": None if dry else ("host" if any(r["bound"] == "host" for r in per_rank) else "kernel")}
+    out["what"] = ("GPSIQ_NCO_REFERENCE time-sharded over the ranks: carrier chain sharded by channel (two small host all-gathers), evaluation and "
+                   "rendering by time; the chain is the only serial part (per channel), so the host side is bounded below by "
+                   "blocks x chain time x channels / host threads whatever the number of GPUs")
     return out
 
 
@@ -761,10 +830,23 @@ def extra_legs(ctx, ring, stream, args, first):
             ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
             dt = min(dt, time.perf_counter() - t1)
         th = float("inf")
-        for _ in range(2):
+        for _ in range(3):
             t1 = time.perf_counter()
             q_r, patches, _ = gpsiq.reference_blocks(d_r, fs_r, ns_r)
             th = min(th, time.perf_counter() - t1)
+        # the two halves on their own: the serial carrier chain (what no number of GPUs speeds up), and the evaluation of the
+        # blocks from their start states (what shards over threads, devices and ranks)
+        cin = gpsiq.chain_inputs(d_r)
+        tc = te = float("inf")
+        s0 = gpsiq.reference_stats()
+        for _ in range(3):
+            t1 = time.perf_counter()
+            starts, _, _ = gpsiq.reference_chain(cin, fs_r, ns_r)
+            tc = min(tc, time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            gpsiq.reference_seeded(d_r, fs_r, ns_r, starts)
+            te = min(te, time.perf_counter() - t1)
+        s1 = gpsiq.reference_stats()
         ctx.set_descriptors(q_r)
         ctx.set_patches(patches)
         ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 3, stream=stream)
@@ -772,16 +854,22 @@ def extra_legs(ctx, ring, stream, args, first):
         ref["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks, gpsiq_generate_batch -> device memory",
                               "value": round(nb_r * ns_r / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / dt, 1),
                               "call_ms": round(dt * 1e3, 3), "host_walk_and_candidates_ms": round(th * 1e3, 3),
+                              "host_chain_only_ms": round(tc * 1e3, 3), "host_evaluation_only_ms": round(te * 1e3, 3),
+                              "chain_us_per_block_and_thread": round(tc * 1e6 * min(effective_cpus(), args.nchan) / (nb_r * args.nchan), 3),
+                              "candidate_states_decided_without_a_walk": round((s1[1] - s0[1]) / max(1, s1[0] - s0[0]), 5),
+                              "gpus_the_chain_can_feed": round(km / (tc * 1e3), 2),
                               "kernel_and_patches_ms": round(km, 3), "patched_samples": int(len(patches)),
-                              "bound": "host carrier walk" if th * 1e3 > km else "kernel",
+                              "bound": "host" if th * 1e3 > km else "kernel",
                               "roofline": roofline_obj(nb_r * blk_r, dt * 1e3),
                               "roofline_kernel_only": roofline_obj(nb_r * blk_r, km)}
     ref["value"] = ref["legs"]["2M6_int8_16ch"]["value"]
     ref["unit"] = "Msamples/s"
     ref["roofline"] = ref["legs"]["2M6_int8_16ch"]["roofline"]
-    ref["what"] = ("whole gpsiq_generate_batch call (walk + candidates + upload + kernel + patches) at the headline workload; the walk is "
-                   "serial in time per channel (one host thread per channel), so this leg is host-bound at 2.6 Msps and approaches "
-                   "the kernel at 25 Msps, where a block is ten times the device work for the same walk")
+    ref["what"] = ("whole gpsiq_generate_batch call (carrier chain + evaluation + upload + kernel + patches) at the headline workload.  Only the "
+                   "chain is serial in time (per channel: host_chain_only_ms on min(cpus, channels) threads); the evaluation of a block needs its "
+                   "start state alone and nearly every candidate is decided without walking an accumulator "
+                   "(candidate_states_decided_without_a_walk).  gpus_the_chain_can_feed = kernel time / chain time on this host: above it more "
+                   "GPUs wait for the chain")
     ex["reference_nco"] = ref
     ctx.set_nco_mode(NCO_FIXED)
     # the batch call with a device destination from double-precision descriptors: host quantiser + upload + kernel

@@ -723,8 +723,13 @@ struct Drift {
     {
         if (!valid || !(x0 >= 0.0 && x0 < L)) return false;
         const i128 R = neg ? units(x0) - (i128) n * mc : units(x0) + (i128) n * mc;     // x0 + n*c
-        i128 q = R / Lint, r = R % Lint;
-        if (r < 0) { r += Lint; q -= 1; }
+        // floor(R / L) and the rest, without a 128-bit division: L = 2^sh (carrier) or 1023 * 2^sh units
+        const int sh = (int) (1075 - ec);
+        const int64_t hi_part = (int64_t) (R >> sh);                                    // floor(R / 2^sh): cycles, or chips (< 2^40)
+        int64_t q;
+        if (kind == 1) q = hi_part;
+        else { q = hi_part / GPSIQ_CA_SEQ_LEN; if (hi_part % GPSIQ_CA_SEQ_LEN < 0) --q; }
+        const i128 r = R - (i128) q * Lint;
         const double core = (double) q * GL + Gof((double) r * ulp_c) - Gof(x0);
         const double I = ((double) (q < 0 ? -q : q) + 3.0) * Acyc;
         const double eta = 4.0 * gmax * (std::fabs(core) + I) + 1e-12 * (std::fabs(core) + std::fabs((double) q * GL)) + 4.0 * gmax * L * 0x1p-52;
@@ -768,49 +773,50 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
     // drift bounds at the end of the block, in units of the fixed-point formats (see the header)
     const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
     const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
-    std::vector<long> t_carr, t_code, targets;
+    // scratch that keeps its capacity from block to block (an evaluation task runs thousands of these back to back)
+    static thread_local std::vector<long> t_carr, t_code, open_c, open_k;
+    static thread_local std::vector<double> xc, xk;
+    static thread_local std::vector<long> periods;
+    t_carr.clear(); t_code.clear(); open_c.clear(); open_k.clear();
     constexpr size_t kCap = 256;
     bool every = false;
     if (carr_inc != 0.0)          // a zero addend leaves both paths constant and equal
         every |= !candidates(q.carr_phase, (uint64_t) q.carr_step, GPSIQ_CARR_FRAC_BITS - 9, w_carr, ns, kCap, &t_carr);
     every |= !candidates(q.code_frac, q.code_step, GPSIQ_CODE_FRAC_BITS, w_code, ns, kCap, &t_code);
-    if (every) {
-        targets.resize((size_t) ns);
-        for (long n = 0; n < ns; ++n) targets[(size_t) n] = n;
-    } else {
-        if (t_carr.empty() && t_code.empty()) return GPSIQ_OK;
-        targets.resize(t_carr.size() + t_code.size());
-        std::merge(t_carr.begin(), t_carr.end(), t_code.begin(), t_code.end(), targets.begin());
-        targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+    if (every) {                  // too many to list (a sample rate far outside the format's design range): every sample, both accumulators
+        t_carr.resize((size_t) ns);
+        for (long n = 0; n < ns; ++n) t_carr[(size_t) n] = n;
+        t_code = t_carr;
     }
-    const int nt = (int) targets.size();
-    // 1. decide from the start state alone
-    std::vector<int> idx_d((size_t) nt, -1);                 // LUT index of the double path, -1: undecided
-    std::vector<long> chips_d((size_t) nt, -1);              // chips since the start of the block's first code period, -1: undecided
-    std::vector<long> open_c, open_k;                        // samples the accumulators have to be walked to
-    const bool walk_code = every || !t_code.empty();         // without a code candidate the chip index is the closed form's everywhere
+    if (t_carr.empty() && t_code.empty()) return GPSIQ_OK;
+    // A sample that is no candidate of an accumulator has that accumulator's closed-form index by construction: the carrier is
+    // looked at in the carrier's candidates only, the code phase in the code's.
+    // 1. decide from the start state alone: cells[k] >= 0 the double path's cell, -1 undecided (walk)
+    static thread_local std::vector<long> cell_c, cell_k;
+    cell_c.assign(t_carr.size(), -1); cell_k.assign(t_code.size(), -1);
     static const bool no_drift = std::getenv("GPSIQ_NO_DRIFT") != nullptr;      // A/B + test knob: every candidate walked
+    const double x0c = start;                                                   // 1.0 included: undecided by construction, walked
     if (!every && !no_drift) {
-        Drift dc, dk;
-        dc.setup(carr_inc, 1);
-        if (walk_code) dk.setup(code_inc, 0);
-        for (int k = 0; k < nt; ++k) {
-            Drift::i128 cell;
-            if (carr_inc == 0.0) idx_d[(size_t) k] = -2;     // stands still: the closed form's index
-            else if (dc.cell_at(ch.carr_phase == 0.0 && start == 1.0 ? 1.0 : start, targets[(size_t) k], &cell)) idx_d[(size_t) k] = (int) (cell & 511);
-            else open_c.push_back(targets[(size_t) k]);
-            if (walk_code) {
-                if (dk.cell_at(ch.code_phase, targets[(size_t) k], &cell)) chips_d[(size_t) k] = (long) cell;
-                else open_k.push_back(targets[(size_t) k]);
-            }
+        Drift::i128 cell;
+        if (!t_carr.empty()) {
+            Drift dc;
+            dc.setup(carr_inc, 1);
+            for (size_t k = 0; k < t_carr.size(); ++k)
+                if (dc.cell_at(x0c, t_carr[k], &cell)) cell_c[k] = (long) (cell & 511);
+                else open_c.push_back(t_carr[k]);
+        }
+        if (!t_code.empty()) {
+            Drift dk;
+            dk.setup(code_inc, 0);
+            for (size_t k = 0; k < t_code.size(); ++k)
+                if (dk.cell_at(ch.code_phase, t_code[k], &cell)) cell_k[k] = (long) cell;
+                else open_k.push_back(t_code[k]);
         }
     } else {
-        open_c = targets;
-        if (walk_code) open_k = targets;
+        open_c = t_carr;
+        open_k = t_code;
     }
     // 2. walk what is left (from the block's start: the walk reports the state at its targets on the way)
-    std::vector<double> xc, xk;
-    std::vector<long> periods;
     if (!open_c.empty()) {
         NcoWalk cw;
         cw.setup(carr_inc, 1);
@@ -823,14 +829,15 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
         xk.resize(open_k.size()); periods.resize(open_k.size());
         (void) kw.run(ch.code_phase, open_k.back() + 1, open_k.data(), (int) open_k.size(), xk.data(), periods.data());
     }
-    g_stats[0].fetch_add((uint64_t) nt * (walk_code ? 2u : 1u), std::memory_order_relaxed);
-    g_stats[1].fetch_add((uint64_t) nt * (walk_code ? 2u : 1u) - open_c.size() - open_k.size(), std::memory_order_relaxed);
+    g_stats[0].fetch_add(t_carr.size() + t_code.size(), std::memory_order_relaxed);
+    g_stats[1].fetch_add(t_carr.size() + t_code.size() - open_c.size() - open_k.size(), std::memory_order_relaxed);
     g_stats[2].fetch_add(open_c.size(), std::memory_order_relaxed);
     g_stats[3].fetch_add(open_k.size(), std::memory_order_relaxed);
     const uint8_t *ca = codes->get(ch.prn);
-    size_t jc = 0, jk = 0;
-    for (int k = 0; k < nt; ++k) {
-        const long n = targets[(size_t) k];
+    size_t ic = 0, ik = 0, jc = 0, jk = 0;                     // merge of the two ascending candidate lists
+    while (ic < t_carr.size() || ik < t_code.size()) {
+        const long n = ik >= t_code.size() || (ic < t_carr.size() && t_carr[ic] <= t_code[ik]) ? t_carr[ic] : t_code[ik];
+        const bool in_c = ic < t_carr.size() && t_carr[ic] == n, in_k = ik < t_code.size() && t_code[ik] == n;
         // fixed-point path (include/gpsiq.h)
         const uint64_t P = (q.carr_phase + (uint64_t) q.carr_step * (uint64_t) n) & ((UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1);
         const unsigned idx_f = (unsigned) (P >> (GPSIQ_CARR_FRAC_BITS - 9));
@@ -840,20 +847,23 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
         const long per_f = (long) (A / GPSIQ_CA_SEQ_LEN);
         const unsigned neg_f = ca[chip_f] ^ nav_bit(ch, ((long) ch.icode + per_f) / 20);
         // double path
-        unsigned idx;
-        if (idx_d[(size_t) k] == -2) idx = idx_f;
-        else if (idx_d[(size_t) k] >= 0) idx = (unsigned) idx_d[(size_t) k];
-        else {
-            idx = (unsigned) (int) std::floor(xc[jc++] * 512.0);                          // gps.c:2775
-            if (idx > 511u) idx = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
+        unsigned idx = idx_f;
+        if (in_c) {
+            if (cell_c[ic] >= 0) idx = (unsigned) cell_c[ic];
+            else {
+                idx = (unsigned) (int) std::floor(xc[jc++] * 512.0);                      // gps.c:2775
+                if (idx > 511u) idx = 511u;   // carr_phase == 1.0 (a negative phase within 2^-54 of zero): the reference indexes past its table there
+            }
+            ++ic;
         }
         unsigned neg_d = neg_f;
-        if (walk_code) {
+        if (in_k) {
             unsigned chip_d;
             long per_d;
-            if (chips_d[(size_t) k] >= 0) { chip_d = (unsigned) (chips_d[(size_t) k] % GPSIQ_CA_SEQ_LEN); per_d = chips_d[(size_t) k] / GPSIQ_CA_SEQ_LEN; }
+            if (cell_k[ik] >= 0) { chip_d = (unsigned) (cell_k[ik] % GPSIQ_CA_SEQ_LEN); per_d = cell_k[ik] / GPSIQ_CA_SEQ_LEN; }
             else { chip_d = (unsigned) (int) xk[jk]; per_d = periods[jk]; ++jk; }         // gps.c:2817, 2791-2793
             neg_d = ca[chip_d] ^ nav_bit(ch, ((long) ch.icode + per_d) / 20);             // gps.c:2791-2811
+            ++ik;
         }
         if (idx != idx_f || neg_d != neg_f) {
             gpsiq_patch_t p;

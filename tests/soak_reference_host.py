@@ -39,4 +39,5 @@ while time.time()-t0 < float(sys.argv[2]):
     act=d[-1]["prn"]>0
     if not np.array_equal(cend[act],carr[act]): print("CARR MISMATCH"); sys.exit(1)
     runs+=1; npatch+=len(patches)
-print(runs,"runs",npatch,"patches, all equal to the float loop")
+st=gpsiq.reference_stats()
+print(runs,"runs",npatch,"patches, all equal to the float loop; candidate states %d, decided from the start state %d, walked: carrier %d code %d"%st)

@@ -60,6 +60,13 @@ def test_gpus_8_dry_run_is_one_line_from_eight_ranks():
     assert all(p["host_ms_per_round"] > 0.0 and p["threads"] == out["config"]["host_threads_per_rank"] for p in st["per_rank"])
     assert st["bound"] is None and all(p["kernel_ms_per_round"] is None for p in st["per_rank"])       # no device in a dry run
     assert "bound" in out["end_to_end"] and out["end_to_end"]["bound"] is None
+    # GPSIQ_NCO_REFERENCE time-sharded over the 8 ranks (chain by channel: two channels per rank; evaluation by time), per rank
+    ref = out["reference_nco"]
+    for leg in ("2M6_int8_16ch", "25M_int16_16ch"):
+        pr = ref["legs"][leg]["per_rank"]
+        assert [p["rank"] for p in pr] == list(range(8)) and ref["legs"][leg]["value"] is None
+        assert all(p["host_chain_and_evaluation_ms"] > 0.0 and p["exchange_ms"] > 0.0 and p["kernel_and_patches_ms"] is None for p in pr)
+        assert len({p["patched_samples"] for p in pr}) >= 1 and sum(p["patched_samples"] for p in pr) > 0
 
 
 def test_collective_selftest_statements_run_over_gloo():
