@@ -758,7 +758,7 @@ static inline double chain_block(double f_carr, double delt, int nsamp, double s
 // the drift enclosure from the block's start state, and only where a boundary lies inside the enclosure are the accumulators
 // walked (from the block's start, to the last undecided sample).
 static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int nsamp, int block, int slot,
-                      CodeCache *codes, gpsiq_qchan_t *qq, std::vector<gpsiq_patch_t> *out)
+                      CodeCache *codes, gpsiq_qchan_t *qq, std::vector<gpsiq_patch_t> *out, bool no_drift = false)
 {
     gpsiq_chan_t ch = ch_in;
     // a start of exactly 1.0 (a wrap of the block before that rounded up to one) is phase 0 of the closed form (mod 1); the
@@ -794,7 +794,6 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
     // 1. decide from the start state alone: cells[k] >= 0 the double path's cell, -1 undecided (walk)
     static thread_local std::vector<long> cell_c, cell_k;
     cell_c.assign(t_carr.size(), -1); cell_k.assign(t_code.size(), -1);
-    static const bool no_drift = std::getenv("GPSIQ_NO_DRIFT") != nullptr;      // A/B + test knob: every candidate walked
     const double x0c = start;                                                   // 1.0 included: undecided by construction, walked
     if (!every && !no_drift) {
         Drift::i128 cell;
@@ -968,7 +967,7 @@ void RefWalk::eval_task(int i, size_t k, CodeCache *codes)
         }
         int slot = 0;                                            // device order: active channels first (gpsiq_set_descriptors)
         for (int j = 0; j < i; ++j) slot += ch[(size_t) b * nchan + j].prn > 0;
-        const int erc = eval_block(d, start[at], delt, nsamp, b, slot, codes, &q[at], mine);
+        const int erc = eval_block(d, start[at], delt, nsamp, b, slot, codes, &q[at], mine, no_drift);
         if (erc != GPSIQ_OK) set_error(erc, gpsiq_last_error(), b);
     }
 }
@@ -1042,6 +1041,7 @@ void RefWalk::run()
     if (k0) { pthread_mutex_lock(&mu); pthread_cond_broadcast(&cv); pthread_mutex_unlock(&mu); }
     // a block or two (the drop-in block call): 16 channels x a few microseconds cost less than waking the pool
     const int want = nblocks <= 2 ? 1 : (chain_only || seeds ? nchan : 2 * nchan);
+    no_drift = std::getenv("GPSIQ_NO_DRIFT") != nullptr;      // A/B + test knob, read per call: every candidate walked
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     if (trace && want > 1 && host_threads() < nchan)
         std::fprintf(stderr, "[gpsiq trace] reference NCO: %d host threads for %d channels: pieces are worked through piece-major\n", host_threads(), nchan);

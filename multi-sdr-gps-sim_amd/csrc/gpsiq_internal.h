@@ -83,6 +83,7 @@ private:
     pthread_cond_t cv, task_cv;
     std::unique_ptr<std::atomic<int>[]> done;
     std::atomic<bool> abort_flag{false};
+    bool no_drift = false;                        // GPSIQ_NO_DRIFT: walk every candidate (A/B and tests)
     // scheduler state, under mu
     size_t chain_next[GPSIQ_MAX_CHAN], eval_next[GPSIQ_MAX_CHAN];
     bool   chain_busy[GPSIQ_MAX_CHAN];

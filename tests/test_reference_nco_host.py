@@ -249,3 +249,18 @@ def test_wrap_to_wrap_table_with_exact_tie_binades(oracle):
         x0 = np.where(rng.random(16) < 0.3, rng.integers(0, 2 ** 40, 16) * 2.0 ** -52, x0)
         chain_case(oracle, fs, ns if it % 3 else 70001, f, np.clip(x0, 0.0, np.nextafter(1.0, 0.0)))
     assert ties > 200                                                  # most of the 384 addends really are of that kind
+
+
+def test_candidates_decided_from_the_start_state_equal_the_walked_ones():
+    """The evaluation half decides nearly every candidate from the block's START state (the drift enclosure, which is what
+    lets blocks be evaluated on any thread, device or rank once the chain has run); GPSIQ_NO_DRIFT=1 walks both accumulators to
+    every candidate instead (the round-3 path).  Same descriptors, patches and carried phases on random timelines at 10-25 Msps
+    (about one candidate per block and channel, start states pushed next to LUT / chip boundaries); tests/soak_drift.py is the
+    time-bounded form (1.4 M decisions per minute)."""
+    import soak_drift
+    rng = np.random.default_rng(11)
+    s0 = gpsiq.reference_stats()
+    patches = sum(soak_drift.one(rng) for _ in range(1500))
+    s1 = gpsiq.reference_stats()
+    assert patches > 200 and s1[1] - s0[1] > 20000                         # decided without a walk, and checked against the walk
+    assert (s1[2] - s0[2]) + (s1[3] - s0[3]) >= (s1[0] - s0[0]) // 2       # the NO_DRIFT halves walked everything
