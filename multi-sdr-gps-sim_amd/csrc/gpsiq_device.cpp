@@ -50,6 +50,11 @@ struct gpsiq_ctx {
         gpsiq_patch_t *d_patch = nullptr;
         size_t         patch_cap = 0;
         int            npatch = 0;
+        gpsiq_patch_t *h_patch = nullptr;  size_t h_patch_cap = 0;   // page-locked staging of the list (asynchronous sets)
+        // a set staged without waiting (the pieces of a batch): the uploads are on up_stream, `uploaded` is recorded behind
+        // them, and every launch on the set waits for it on its own stream
+        hipEvent_t     uploaded = nullptr;
+        bool           upload_pending = false;
     } buf[2];
     hipStream_t    up_stream = nullptr;  // descriptor / patch uploads: never behind a running kernel
     int            cur = 0;             // buf[cur] holds the resident set
@@ -102,6 +107,10 @@ static double wall_ms()
 // Wait until no launch reads the buffer any more (every stream that used it), then forget the uses.
 static int wait_idle(gpsiq_ctx::DescBuf &b)
 {
+    if (b.upload_pending) {              // also when nothing was ever launched on the set: its staging is about to be rewritten
+        HIP_TRY(hipEventSynchronize(b.uploaded));
+        b.upload_pending = false;
+    }
     if (!b.in_use) return GPSIQ_OK;
     for (auto &u : b.use)
         if (u.active) { HIP_TRY(hipEventSynchronize(u.ev)); u.active = false; }
@@ -223,6 +232,8 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
         if (c->buf[i].d) (void) hipFree(c->buf[i].d);
         if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
         if (c->buf[i].d_patch) (void) hipFree(c->buf[i].d_patch);
+        if (c->buf[i].h_patch) (void) hipHostFree(c->buf[i].h_patch);
+        if (c->buf[i].uploaded) (void) hipEventDestroy(c->buf[i].uploaded);
         for (auto &u : c->buf[i].use)
             if (u.ev) (void) hipEventDestroy(u.ev);
         if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
@@ -248,7 +259,26 @@ void gpsiq_host_free(void *p)
     if (p) (void) hipHostFree(p);
 }
 
-int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan)
+}  // extern "C"
+
+// patch list against the set it belongs to: slot counts the block's ACTIVE channels (device order), sorted by (block, sample)
+static int check_patches(const gpsiq_ctx::DescBuf &b, int nblocks, const gpsiq_patch_t *patches, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        const gpsiq_patch_t &p = patches[i];
+        if ((int64_t) p.block >= nblocks || p.slot >= b.active_per_block[p.block] || p.lut > 511 || p.neg > 1)
+            return fail(GPSIQ_E_RANGE, "patch %d (block %u, slot %u, lut %u) outside the resident descriptors", i, p.block, p.slot, p.lut);
+        if (i && (patches[i - 1].block > p.block || (patches[i - 1].block == p.block && patches[i - 1].sample > p.sample)))
+            return fail(GPSIQ_E_ARG, "patches not sorted by (block, sample) at %d", i);
+    }
+    return GPSIQ_OK;
+}
+
+// gpsiq_set_descriptors (+ the set's patches in the same step).  no_wait: the uploads are queued on the context's upload
+// stream and the call returns; launches on the set wait for them on the device (the pieces of a batch: the render thread
+// queues piece after piece without a round trip to the device in between).
+static int set_descriptors_impl(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan, const gpsiq_patch_t *patches, int npatch,
+                                bool no_wait)
 {
     if (!c || !q) return fail(GPSIQ_E_ARG, "null argument");
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
@@ -311,22 +341,56 @@ int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, i
         HIP_TRY(hipMalloc((void **) &nb.d, need * sizeof(gpsiq_qchan_t)));
         nb.cap = need;
     }
+    if (npatch > 0) {                                   // before anything resident is touched, like the descriptors
+        const int prc = check_patches(nb, nblocks, patches, npatch);
+        if (prc) return prc;
+        if ((size_t) npatch > nb.patch_cap) {
+            if (nb.d_patch) HIP_TRY(hipFree(nb.d_patch));
+            nb.d_patch = nullptr; nb.patch_cap = 0;
+            const size_t cap = (size_t) npatch < 256 ? 256 : (size_t) npatch;
+            HIP_TRY(hipMalloc((void **) &nb.d_patch, cap * sizeof(gpsiq_patch_t)));
+            nb.patch_cap = cap;
+        }
+        if ((size_t) npatch > nb.h_patch_cap) {
+            if (nb.h_patch) HIP_TRY(hipHostFree(nb.h_patch));
+            nb.h_patch = nullptr; nb.h_patch_cap = 0;
+            const size_t cap = (size_t) npatch < 256 ? 256 : (size_t) npatch;
+            HIP_TRY(hipHostMalloc((void **) &nb.h_patch, cap * sizeof(gpsiq_patch_t), hipHostMallocDefault));
+            nb.h_patch_cap = cap;
+        }
+        std::memcpy(nb.h_patch, patches, (size_t) npatch * sizeof(gpsiq_patch_t));
+    }
     if (n) {
         const double t1 = trace ? wall_ms() : 0.0;
         // on the context's upload stream (non-blocking, nothing else ever queued on it): overlaps whatever the caller's
         // streams and the context's own kernels are doing
         hipError_t e = hipMemcpyAsync(nb.d, nb.h, n * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->up_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->up_stream);
+        if (e == hipSuccess && npatch > 0)
+            e = hipMemcpyAsync(nb.d_patch, nb.h_patch, (size_t) npatch * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice, c->up_stream);
+        if (e == hipSuccess && no_wait) {
+            if (!nb.uploaded) e = hipEventCreateWithFlags(&nb.uploaded, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(nb.uploaded, c->up_stream);
+            if (e == hipSuccess) nb.upload_pending = true;
+        } else if (e == hipSuccess) {
+            e = hipStreamSynchronize(c->up_stream);
+        }
         if (e != hipSuccess) return fail(GPSIQ_E_DEVICE, "descriptor upload: %s", hipGetErrorString(e));
         if (trace)
-            std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %.2f ms\n",
-                         nblocks, t1 - t0, wall_ms() - t1);
+            std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %s %.2f ms\n",
+                         nblocks, t1 - t0, no_wait ? "queued" : "done", wall_ms() - t1);
     }
     c->cur ^= 1;
     c->d_desc = nb.d;
     c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = pj.mx; c->max_active = pj.max_active; c->max_amplitude = pj.max_amp;
-    nb.npatch = 0;
+    nb.npatch = n ? npatch : 0;
     return GPSIQ_OK;
+}
+
+extern "C" {
+
+int gpsiq_set_descriptors(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblocks, int nchan)
+{
+    return set_descriptors_impl(c, q, nblocks, nchan, nullptr, 0, false);
 }
 
 int gpsiq_set_patches(gpsiq_ctx_t *c, const gpsiq_patch_t *patches, int n)
@@ -334,14 +398,7 @@ int gpsiq_set_patches(gpsiq_ctx_t *c, const gpsiq_patch_t *patches, int n)
     if (!c || (n > 0 && !patches) || n < 0) return fail(GPSIQ_E_ARG, "bad patch list");
     HIP_TRY(hipSetDevice(c->device));
     gpsiq_ctx::DescBuf &cb = c->buf[c->cur];
-    for (int i = 0; i < n; ++i) {
-        const gpsiq_patch_t &p = patches[i];
-        // slot counts the block's ACTIVE channels (device order), not the caller's channel index
-        if ((int64_t) p.block >= c->nblocks || p.slot >= cb.active_per_block[p.block] || p.lut > 511 || p.neg > 1)
-            return fail(GPSIQ_E_RANGE, "patch %d (block %u, slot %u, lut %u) outside the resident descriptors", i, p.block, p.slot, p.lut);
-        if (i && (patches[i - 1].block > p.block || (patches[i - 1].block == p.block && patches[i - 1].sample > p.sample)))
-            return fail(GPSIQ_E_ARG, "patches not sorted by (block, sample) at %d", i);
-    }
+    { const int prc = check_patches(cb, c->nblocks, patches, n); if (prc) return prc; }
     cb.npatch = 0;
     if (n == 0) return GPSIQ_OK;                      // launches in flight took their count with them
     // launches of THIS set may still be applying the list that is replaced (the other buffer's launches have their own)
@@ -381,6 +438,7 @@ static int launch_on(gpsiq_ctx *c, int v, int block0, int nblocks, int nsamp, in
         HIP_TRY(hipMalloc(&c->d_scratch, need));
         c->scratch_cap = need;
     }
+    if (c->buf[c->cur].upload_pending) HIP_TRY(hipStreamWaitEvent(s, c->buf[c->cur].uploaded, 0));    // a set staged without waiting
     hipError_t e = launch_variant(v, c->d_desc, c->nchan, nsamp, sample_size, dst, stride, block0, nblocks, c->d_tab, s,
                                   c->max_active, c->max_amplitude, need ? c->d_scratch : nullptr);
     if (e == hipSuccess && c->buf[c->cur].npatch)
@@ -587,12 +645,8 @@ struct RefRender {
     // blocks [b0, b0 + nb) of the range: q and patches (block indices relative to b0) belong to this piece
     int piece(const gpsiq_qchan_t *q, int b0, int nb, const std::vector<gpsiq_patch_t> &patches)
     {
-        int rc = gpsiq_set_descriptors(c, q, nb, nchan);
+        int rc = set_descriptors_impl(c, q, nb, nchan, patches.data(), (int) patches.size(), true);   // queued, not waited for
         if (rc) return rc;
-        if (!patches.empty()) {
-            rc = gpsiq_set_patches(c, patches.data(), (int) patches.size());
-            if (rc) return rc;
-        }
         if (!nb || !nsamp) return GPSIQ_OK;
         uint8_t *dev = direct ? dst + (size_t) b0 * blk_bytes : static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
         rc = gpsiq_launch(c, 0, nb, nsamp, ss, dev, stride, c->stream, kAuto);
@@ -624,10 +678,26 @@ struct RefRender {
 };
 
 // piece boundaries of a range of `n` blocks starting at block `first` of the walk, `chunk` blocks each
+// The first piece is half a chunk (nothing renders before it is through all channels), the next one a chunk, the rest two
+// chunks each: a launch of twice the samples runs closer to the rate of one big launch (a 26-block piece at 25 Msps is one
+// round of workgroups over the chip: 215 us measured against 183 us of its share of a whole-timeline launch), and once the
+// device is busy the host side has the time.  GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
 static void piece_ends(int first, int n, int chunk, std::vector<int> *ends)
 {
-    for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
-    ends->push_back(first + n);
+    static const bool ramp = [] { const char *e = std::getenv("GPSIQ_REF_CHUNK_RAMP"); return !e || std::atoi(e) != 0; }();
+    if (!ramp || n <= 2 * chunk) {
+        for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
+        ends->push_back(first + n);
+        return;
+    }
+    int b = chunk > 1 ? chunk / 2 : 1;
+    ends->push_back(first + b);
+    b += chunk;
+    while (b < n) {
+        ends->push_back(first + b);
+        b += 2 * chunk;
+    }
+    if (ends->back() != first + n) ends->push_back(first + n);
 }
 
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
@@ -847,7 +917,7 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
             const int nb = nblocks - b0 < piece ? nblocks - b0 : piece;
             gpsiq_qchan_t *qp = q.data();
             rc = quantize_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, cont, seed, qp, carry, prev_prn);
-            if (rc == GPSIQ_OK) rc = gpsiq_set_descriptors(c, qp, nb, nchan);
+            if (rc == GPSIQ_OK) rc = set_descriptors_impl(c, qp, nb, nchan, nullptr, 0, true);
             if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, c->stream, kAuto);
             for (int i = 0; i < nchan; ++i) {
                 // the next piece continues a slot while it keeps its PRN and re-seeds it otherwise, as inside one timeline

@@ -1004,7 +1004,7 @@ void RefWalk::work()
             }
         }
         if (best_i < 0) {
-            if (!pending) break;                                                      // everything is taken (running tasks finish on their threads)
+            if (!pending) { pthread_cond_broadcast(&task_cv); break; }                // everything is taken: the sleepers may leave too
             pthread_cond_wait(&task_cv, &mu);                                         // a chain in flight will make more runnable
             continue;
         }
@@ -1018,7 +1018,10 @@ void RefWalk::work()
             pthread_mutex_lock(&mu);
             chain_busy[i] = false;
             ++chain_next[i];
-            pthread_cond_broadcast(&task_cv);                                         // EVAL(i, k) and CHAIN(i, k+1) are runnable now
+            // EVAL(i, k) and CHAIN(i, k+1) are runnable now: this thread takes one of them, one sleeper the other (a thread only
+            // sleeps after it has found nothing runnable under the lock, and tasks only become runnable here: nothing is missed,
+            // and nobody is woken to find nothing -- with 16 threads and tasks of ~50 us a broadcast is most of the work)
+            pthread_cond_signal(&task_cv);
         } else {
             eval_task(i, k, &codes);
             finish_piece(k);
@@ -1109,8 +1112,9 @@ extern "C" int gpsiq_reference_chain(const gpsiq_chain_in_t *in, int nblocks, in
     if ((!in || !carr_start) && nblocks) return fail(GPSIQ_E_ARG, "null pointer");
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     if (nsamp < 0 || !(fs > 0.0) || (!carr_in != !prn_in)) return fail(GPSIQ_E_ARG, "bad nsamp %d / fs %g / continuation state", nsamp, fs);
+    // one task per channel when there is a thread for every channel; else pieces, so that the channels share the threads evenly
     std::vector<int> ends;
-    const int chunk = nblocks > 64 ? (nblocks + 15) / 16 : nblocks;
+    const int chunk = host_threads() >= nchan || nblocks <= 64 ? nblocks : (nblocks + 7) / 8;
     for (int b = chunk; b < nblocks; b += chunk) ends.push_back(b);
     RefWalk w(nullptr, nblocks, nchan, 1.0 / fs, nsamp, nullptr, carr_in, prn_in, ends);
     w.in = in; w.chain_only = true; w.start_out = carr_start;

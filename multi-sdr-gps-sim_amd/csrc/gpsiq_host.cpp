@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 #include <vector>
 
@@ -83,13 +84,38 @@ void pool_after_fork_in_child()          // the child has none of the parent's t
 }
 }  // namespace
 
-int host_threads()
+// CPUs this process may really use: the online count, cut to the scheduler affinity mask and to the container's CPU
+// bandwidth limit (cgroup v2 cpu.max, cgroup v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- a box with 256 hardware threads and
+// a 16-CPU quota runs 16 threads' worth of work, and 64 runnable threads there only take turns.
+static int granted_cpus()
 {
-    static const int cap = [] { const char *e = std::getenv("GPSIQ_THREADS"); return e ? std::atoi(e) : 0; }();
     long c = sysconf(_SC_NPROCESSORS_ONLN);
     int n = c > 0 ? (int) c : 1;
-    if (cap > 0 && n > cap) n = cap;
-    if (n > kMaxWorkers + 1) n = kMaxWorkers + 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < n) n = a; }
+    long long quota = -1, period = -1;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = "";
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+        std::fclose(f);
+    } else {
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &quota) != 1) quota = -1; std::fclose(g); }
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = -1; std::fclose(g); }
+    }
+    if (quota > 0 && period > 0) { const int lim = (int) ((quota + period - 1) / period); if (lim >= 1 && lim < n) n = lim; }
+    return n;
+}
+
+int host_threads()
+{
+    static const int n = [] {
+        const char *e = std::getenv("GPSIQ_THREADS");
+        const int cap = e ? std::atoi(e) : 0;
+        int g = granted_cpus();
+        if (cap > 0 && g > cap) g = cap;
+        if (g > kMaxWorkers + 1) g = kMaxWorkers + 1;
+        return g < 1 ? 1 : g;
+    }();
     return n;
 }
 

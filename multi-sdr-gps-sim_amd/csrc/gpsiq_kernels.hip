@@ -810,39 +810,49 @@ size_t variant_scratch_bytes(int variant, int nsamp, int nblocks)
 // GPSIQ_NCO_REFERENCE fix-up (csrc/gpsiq_exact.cpp): the few samples per 10^7 where the reference's
 // double accumulators pick another LUT entry or sign than the closed form are recomputed whole --
 // every channel from the closed form, the patched channels from the patch -- and stored over what
-// the synthesis kernel wrote (same stream, after it).  One thread per patch; the first patch of a
-// (block, sample) group does the sample.
+// the synthesis kernel wrote (same stream, after it).  Sixteen lanes per patch, one channel each (the
+// closed form of one channel is a chain of 128-bit products and a division: sixteen of them one
+// after the other in one thread were 13-18 us of a 200 us piece), summed with cross-lane
+// shuffles inside each group of sixteen; the first patch of a (block, sample) group does the sample, lane 0 stores it.
 template <int FMT>
 __global__ __launch_bounds__(64) void apply_patches(
     const gpsiq_qchan_t *__restrict__ desc, int nchan, int nsamp, uint8_t *__restrict__ dst, size_t block_stride,
     int block0, int nblocks, const DeviceTables *__restrict__ tab, const gpsiq_patch_t *__restrict__ pt, int npatch)
 {
-    const int i = (int) (blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= npatch) return;
-    const gpsiq_patch_t p = pt[i];
-    if (i > 0 && pt[i - 1].block == p.block && pt[i - 1].sample == p.sample) return;
-    if (p.block < (uint32_t) block0 || p.block >= (uint32_t) (block0 + nblocks) || p.sample >= (uint32_t) nsamp) return;
-    const gpsiq_qchan_t *q = desc + (size_t) p.block * nchan;
-    const uint64_t n = p.sample;
+    const int i = (int) (blockIdx.x * 4u + (threadIdx.x >> 4));      // four patches per wave
+    const int c = (int) (threadIdx.x & 15u);                          // this lane's channel slot (GPSIQ_MAX_CHAN = 16)
+    const bool have = i < npatch;
+    const gpsiq_patch_t p = pt[have ? i : npatch - 1];
+    bool lead = have && !(i > 0 && pt[i - 1].block == p.block && pt[i - 1].sample == p.sample);
+    lead = lead && p.block >= (uint32_t) block0 && p.block < (uint32_t) (block0 + nblocks) && p.sample < (uint32_t) nsamp;
     int i_acc = 0, q_acc = 0;
-    for (int c = 0; c < nchan; ++c) {
-        if (q[c].prn == 0) continue;
-        const uint64_t P = q[c].carr_phase + (uint64_t) q[c].carr_step * n;
-        uint32_t idx = (uint32_t) (P >> (GPSIQ_CARR_FRAC_BITS - 9)) & 511u;
-        const unsigned __int128 T = (unsigned __int128) q[c].code_frac + (unsigned __int128) q[c].code_step * (unsigned __int128) n;
-        const uint64_t A = (uint64_t) q[c].chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
-        const uint32_t chip = (uint32_t) (A % GPSIQ_CA_SEQ_LEN);
-        const uint32_t bit = (uint32_t) ((q[c].icode + A / GPSIQ_CA_SEQ_LEN) / 20);
-        uint32_t neg = ((tab->prn_ext[q[c].prn - 1][chip >> 5] >> (chip & 31)) ^ (q[c].nav_bits >> (bit & 31))) & 1u;
-        for (int j = i; j < npatch && pt[j].block == p.block && pt[j].sample == p.sample; ++j)
-            if (pt[j].slot == c) { idx = pt[j].lut & 511u; neg = pt[j].neg & 1u; }
-        const int ts = (int) ((double) dev_sin512(tab->quarter_wave, (int) idx) * q[c].gain);        // gps.c:2782
-        const int tc = (int) ((double) dev_sin512(tab->quarter_wave, (int) idx + 128) * q[c].gain);  // gps.c:2781
-        i_acc += neg ? -tc : tc;
-        q_acc += neg ? -ts : ts;
+    if (lead && c < nchan) {
+        const gpsiq_qchan_t qc = desc[(size_t) p.block * nchan + c];
+        if (qc.prn != 0) {
+            const uint64_t n = p.sample;
+            const uint64_t P = qc.carr_phase + (uint64_t) qc.carr_step * n;
+            uint32_t idx = (uint32_t) (P >> (GPSIQ_CARR_FRAC_BITS - 9)) & 511u;
+            const unsigned __int128 T = (unsigned __int128) qc.code_frac + (unsigned __int128) qc.code_step * (unsigned __int128) n;
+            const uint64_t A = (uint64_t) qc.chip0 + (uint64_t) (T >> GPSIQ_CODE_FRAC_BITS);
+            const uint32_t chip = (uint32_t) (A % GPSIQ_CA_SEQ_LEN);
+            const uint32_t bit = (uint32_t) ((qc.icode + A / GPSIQ_CA_SEQ_LEN) / 20);
+            uint32_t neg = ((tab->prn_ext[qc.prn - 1][chip >> 5] >> (chip & 31)) ^ (qc.nav_bits >> (bit & 31))) & 1u;
+            for (int j = i; j < npatch && pt[j].block == p.block && pt[j].sample == p.sample; ++j)
+                if (pt[j].slot == c) { idx = pt[j].lut & 511u; neg = pt[j].neg & 1u; }
+            const int ts = (int) ((double) dev_sin512(tab->quarter_wave, (int) idx) * qc.gain);        // gps.c:2782
+            const int tc = (int) ((double) dev_sin512(tab->quarter_wave, (int) idx + 128) * qc.gain);  // gps.c:2781
+            i_acc = neg ? -tc : tc;
+            q_acc = neg ? -ts : ts;
+        }
     }
-    store_sample<FMT>(dst + (size_t) (p.block - (uint32_t) block0) * block_stride, (uint32_t) n,
-                      ((uint32_t) i_acc & 0xffffu) | ((uint32_t) q_acc << 16));
+    // sum over the sixteen lanes of the patch (all 64 lanes take part: no divergence around the cross-lane moves)
+    for (int off = 8; off >= 1; off >>= 1) {
+        i_acc += __shfl_xor(i_acc, off, 16);
+        q_acc += __shfl_xor(q_acc, off, 16);
+    }
+    if (lead && c == 0)
+        store_sample<FMT>(dst + (size_t) (p.block - (uint32_t) block0) * block_stride, p.sample,
+                          ((uint32_t) i_acc & 0xffffu) | ((uint32_t) q_acc << 16));
 }
 
 hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size, void *dst, size_t block_stride,
@@ -850,7 +860,7 @@ hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int s
                           hipStream_t stream)
 {
     if (npatch <= 0 || nblocks <= 0 || nsamp <= 0) return hipSuccess;
-    dim3 grid((unsigned) ((npatch + 63) / 64)), block(64);
+    dim3 grid((unsigned) ((npatch + 3) / 4)), block(64);
     uint8_t *d = static_cast<uint8_t *>(dst);
     if (sample_size == GPSIQ_SC16)
         hipLaunchKernelGGL(apply_patches<GPSIQ_SC16>, grid, block, 0, stream, desc, nchan, nsamp, d, block_stride, block0, nblocks, tab, patches, npatch);
