@@ -693,11 +693,11 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends)
     int b = chunk > 1 ? chunk / 2 : 1;
     ends->push_back(first + b);
     b += chunk;
-    while (b < n) {
+    while (b < n && n - b >= chunk) {                 // a remainder shorter than a chunk joins the piece before it
         ends->push_back(first + b);
         b += 2 * chunk;
     }
-    if (ends->back() != first + n) ends->push_back(first + n);
+    ends->push_back(first + n);
 }
 
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
@@ -909,6 +909,24 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     if (dst_is_device && !(blk_bytes & 15) && !((uintptr_t) dst & 3) && piece < nblocks && nsamp > 0) {
         // A long batch into device memory: quantise, validate and upload piece k+1 (host threads) under the kernel of
         // piece k.  The carrier prefix goes from piece to piece exactly as it goes from call to call.
+        // Every descriptor of the timeline is range-checked BEFORE the first piece is launched (the quantiser's own checks, run
+        // once more without keeping the result: ~3 % of the call): a bad descriptor in a late block fails the call with the
+        // caller's buffer, the resident set and the carried phases untouched, as when the batch is rendered in one piece.
+        {
+            struct VJob { const gpsiq_chan_t *ch; int nchan, nsamp; double delt; int rc; char err[320]; };
+            VJob vj = {ch, nchan, nsamp, 1.0 / fs, GPSIQ_OK, ""};
+            parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
+                VJob &j = *static_cast<VJob *>(p);
+                gpsiq_qchan_t scratch;
+                for (int b = b0; b < b1 && __atomic_load_n(&j.rc, __ATOMIC_RELAXED) == GPSIQ_OK; ++b)
+                    for (int i = 0; i < j.nchan; ++i) {
+                        const int qrc = quantize_one(j.ch[(size_t) b * j.nchan + i], j.delt, j.nsamp, nullptr, &scratch, nullptr);
+                        if (qrc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, qrc))
+                            std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error());
+                    }
+            }, &vj);
+            if (vj.rc != GPSIQ_OK) return fail(vj.rc, "%s", vj.err);
+        }
         bool cont[GPSIQ_MAX_CHAN];
         uint64_t seed[GPSIQ_MAX_CHAN];
         for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }

@@ -1082,6 +1082,34 @@ int reference_timeline(const gpsiq_chan_t *ch, int nblocks, int nchan, double de
                        gpsiq_qchan_t *q, std::vector<gpsiq_patch_t> *patches, double *carr_end, int *last_prn,
                        const double *carr_in, const int *prn_in)
 {
+    if (nblocks == 1) {
+        // the drop-in block call (one 0.1 s block per call, ~100 us all told): chain and evaluation of the sixteen channels right
+        // here, without the scheduler's mutexes, condition variables and task state
+        CodeCache codes;
+        patches->clear();
+        int slot = 0;
+        for (int i = 0; i < nchan; ++i) {
+            const gpsiq_chan_t &d = ch[i];
+            if (d.prn <= 0) {
+                (void) quantize_one(d, delt, nsamp, nullptr, &q[i], nullptr);
+                if (carr_end) carr_end[i] = 0.0;
+                if (last_prn) last_prn[i] = 0;
+                continue;
+            }
+            const double start = carr_in && prn_in && prn_in[i] == d.prn ? carr_in[i] : d.carr_phase;
+            if (!(start >= 0.0 && start <= 1.0) || !(std::fabs(d.f_carr * delt) < 0.5))
+                return fail(GPSIQ_E_RANGE, "block 0: carrier phase or Doppler outside the NCO format");
+            const int erc = eval_block(d, start, delt, nsamp, 0, slot++, &codes, &q[i], patches, std::getenv("GPSIQ_NO_DRIFT") != nullptr);
+            if (erc != GPSIQ_OK) { char msg[300]; std::snprintf(msg, sizeof msg, "%s", gpsiq_last_error()); return fail(erc, "block 0: %.280s", msg); }
+            if (carr_end) carr_end[i] = chain_block(d.f_carr, delt, nsamp, start);
+            if (last_prn) last_prn[i] = d.prn;
+        }
+        std::sort(patches->begin(), patches->end(), [](const gpsiq_patch_t &a, const gpsiq_patch_t &b) {
+            if (a.sample != b.sample) return a.sample < b.sample;
+            return a.slot < b.slot;
+        });
+        return GPSIQ_OK;
+    }
     // a handful of pieces so that a thread-starved host still overlaps chains and evaluations; a short timeline is one piece
     std::vector<int> ends;
     const int chunk = nblocks > 64 ? (nblocks + 15) / 16 : nblocks;
