@@ -312,6 +312,13 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
                                int nsamp, double fs, int sample_size, void *host_dst, void *const *dev_dst,
                                double *carr_phase_out);
 
+/* One shard of a time-sharded run in GPSIQ_NCO_REFERENCE, whatever the context's mode: render nblocks blocks whose start
+ * states are known (carr_start[nblocks][nchan], this range's rows of gpsiq_reference_chain; ch[b][i].carr_phase is not
+ * read) into dst, host or device as above -- evaluated and rendered in pieces like gpsiq_generate_batch, with no reference
+ * to the blocks before the range.  Synchronous.  Does not touch the carrier continuation state. */
+int gpsiq_generate_seeded(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
+                          int sample_size, const double *carr_start, void *dst, int dst_is_device);
+
 /* One shard of a time-sharded run: synthesise nblocks already-quantised blocks
  * (a contiguous slice of gpsiq_quantize_batch's output, which carries the exact carrier
  * phase of every block) into dst, host or device as above.  Synchronous.  Does not touch

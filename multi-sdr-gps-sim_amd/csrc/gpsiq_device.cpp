@@ -678,25 +678,28 @@ struct RefRender {
 };
 
 // piece boundaries of a range of `n` blocks starting at block `first` of the walk, `chunk` blocks each
-// The first piece is half a chunk (nothing renders before it is through all channels), the next one a chunk, the rest two
-// chunks each: a launch of twice the samples runs closer to the rate of one big launch (a 26-block piece at 25 Msps is one
-// round of workgroups over the chip: 215 us measured against 183 us of its share of a whole-timeline launch), and once the
-// device is busy the host side has the time.  GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
+// Piece sizes: half a chunk, a chunk, then two chunks each, and a chunk and half a chunk again at the end.  Nothing renders
+// before the first piece is through all channels, and when the host is the slower side the last piece's kernel is all that
+// is left after the host has finished: both want a small piece.  In between a launch of twice the samples runs closer to the
+// rate of one big launch (a 26-block piece at 25 Msps is one round of workgroups over the chip: 215 us measured against
+// 183 us for its share of a whole-timeline launch).  GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
 static void piece_ends(int first, int n, int chunk, std::vector<int> *ends)
 {
     static const bool ramp = [] { const char *e = std::getenv("GPSIQ_REF_CHUNK_RAMP"); return !e || std::atoi(e) != 0; }();
-    if (!ramp || n <= 2 * chunk) {
+    const int half = chunk > 1 ? chunk / 2 : 1;
+    if (!ramp || n <= 4 * chunk) {
         for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
         ends->push_back(first + n);
         return;
     }
-    int b = chunk > 1 ? chunk / 2 : 1;
+    const int tail0 = n - chunk - half;               // the last two pieces: a chunk, half a chunk
+    int b = half;
     ends->push_back(first + b);
     b += chunk;
-    while (b < n && n - b >= chunk) {                 // a remainder shorter than a chunk joins the piece before it
-        ends->push_back(first + b);
-        b += 2 * chunk;
-    }
+    ends->push_back(first + b);
+    while (tail0 - b >= 3 * chunk) { b += 2 * chunk; ends->push_back(first + b); }     // what is left (chunk .. 3 chunks) is one piece
+    if (tail0 > b) ends->push_back(first + tail0);
+    ends->push_back(first + n - half);
     ends->push_back(first + n);
 }
 
@@ -704,7 +707,7 @@ static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullpt
 
 // GPSIQ_NCO_REFERENCE form of both drop-in calls: the carrier is the caller's double, walked exactly
 static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
-                              int sample_size, void *dst, int dst_is_device, double *carr_phase_out)
+                              int sample_size, void *dst, int dst_is_device, double *carr_phase_out, const double *seeds = nullptr)
 {
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     const double t0 = trace ? wall_ms() : 0.0;
@@ -719,6 +722,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     std::vector<int> ends;
     piece_ends(0, nblocks, chunk, &ends);
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
+    w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
     // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
     // thread, and this thread renders every piece as soon as all channels are through it
     pthread_t th;
@@ -968,6 +972,18 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         if (carr_phase_out) carr_phase_out[i] = c->handed[i];
     }
     return GPSIQ_OK;
+}
+
+int gpsiq_generate_seeded(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs, int sample_size,
+                          const double *carr_start, void *dst, int dst_is_device)
+{
+    int rc = check_gen_args(c, ch, dst, nblocks, nchan, nsamp, fs, sample_size);
+    if (rc) return rc;
+    if (!carr_start && nblocks) return fail(GPSIQ_E_ARG, "null start states");
+    if (nblocks == 0) return GPSIQ_OK;
+    for (size_t k = 0; k < (size_t) nblocks * (size_t) nchan; ++k)
+        if (ch[k].prn > 0 && !(carr_start[k] >= 0.0 && carr_start[k] <= 1.0)) return fail(GPSIQ_E_RANGE, "start phase %zu outside [0, 1]", k);
+    return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, nullptr, carr_start);
 }
 
 int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_chan_t *ch, int nblocks, int nchan,

@@ -75,6 +75,7 @@ _generate_block_async = _sig("gpsiq_generate_block_async", _i, _vp, _vp, _i, _i,
 _wait = _sig("gpsiq_wait", _i, _vp)
 _generate_batch = _sig("gpsiq_generate_batch", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _i, _vp)
 _generate_quantized = _sig("gpsiq_generate_quantized", _i, _vp, _vp, _i, _i, _i, _i, _vp, _i)
+_generate_seeded = _sig("gpsiq_generate_seeded", _i, _vp, _vp, _i, _i, _i, _d, _i, _vp, _vp, _i)
 _quantize_batch = _sig("gpsiq_quantize_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp)
 _reference_batch = _sig("gpsiq_reference_batch", _i, _vp, _i, _i, _d, _i, _vp, _vp, _i, C.POINTER(C.c_int), _vp)
 _reference_chain = _sig("gpsiq_reference_chain", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp)
@@ -551,6 +552,22 @@ class Context:
         return out
 
     # -- resident-descriptor path (device buffers) --
+    def generate_seeded(self, desc, nsamp, fs, sample_size, carr_start, device_ptr=None, host_ptr=None):
+        """gpsiq_generate_seeded: GPSIQ_NCO_REFERENCE render of blocks whose start states are known (rows of reference_chain)."""
+        desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+        nb, nc = desc.shape
+        st = np.ascontiguousarray(carr_start, dtype=np.float64)
+        assert st.shape == (nb, nc)
+        if device_ptr is not None:
+            _check(_generate_seeded(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(st), _vp(device_ptr), 1))
+            return None
+        out = None
+        if host_ptr is None:
+            out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
+            host_ptr = out.ctypes.data
+        _check(_generate_seeded(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(st), _vp(host_ptr), 0))
+        return out
+
     def set_descriptors(self, q):
         q = np.ascontiguousarray(q, dtype=QCHAN_DTYPE)
         nb, nc = q.shape

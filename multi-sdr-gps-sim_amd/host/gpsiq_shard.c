@@ -7,12 +7,18 @@
  * model, so the timeline splits into contiguous block ranges, one per GPU, with no traffic
  * between them.  Every rank runs this program:
  *
- *   gpsiq_shard <descriptors.bin> <out.part> <rank> <world> [device]
+ *   gpsiq_shard <descriptors.bin> <out.part> <rank> <world> [device [reference]]
  *
  * It quantises the WHOLE timeline on the host (cheap: threaded, ~1 us per block), takes its
  * own range, renders it on its GPU and writes that part of the iqfile stream (the iqfile
  * sink is one block per buffer, reference sdr_iqfile.c:59, so parts concatenate to the
  * file the single-thread run would have written).  descriptors.bin as for gpsiq_play.
+ *
+ * With "reference" the rank renders its range in GPSIQ_NCO_REFERENCE (the reference's own double accumulators: the bytes the
+ * reference program writes).  The only thing serial in time there is the carrier chain (gps.c:2821-2826): the rank walks it over
+ * the whole timeline on the host (gpsiq_reference_chain, ~2.5 us per block and channel, a thread per channel; ranks that can
+ * talk walk a few channels each and exchange 8 bytes per channel and block instead, gpsiq/shard.py) and hands its own
+ * blocks' start states to gpsiq_generate_seeded, which evaluates and renders them with no reference to the blocks before.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -40,6 +46,7 @@ int main(int argc, char **argv)
     if (argc < 5) { fprintf(stderr, "usage: %s descriptors.bin out.part rank world [device]\n", argv[0]); return 2; }
     const int rank = atoi(argv[3]), world = atoi(argv[4]);
     const int device = argc > 5 ? atoi(argv[5]) : rank;
+    const int reference = argc > 6 && !strcmp(argv[6], "reference");
     FILE *fd = fopen(argv[1], "rb");
     struct play_header h;
     if (!fd || fread(&h, sizeof h, 1, fd) != 1 || memcmp(h.magic, "GPSIQD1", 8)) { fprintf(stderr, "bad descriptor file\n"); return 2; }
@@ -50,9 +57,20 @@ int main(int argc, char **argv)
     if (!desc || !q || fread(desc, sizeof *desc, n, fd) != n) { fprintf(stderr, "short descriptor file\n"); return 2; }
     fclose(fd);
 
-    /* the whole timeline, so that this shard starts from the exact carried carrier phase */
-    if (gpsiq_quantize_batch(desc, (int) h.nblocks, (int) h.nchan, h.fs, (int) h.nsamp, q, NULL, NULL) != GPSIQ_OK)
+    double *start = NULL;
+    if (reference) {
+        /* the chain over the whole timeline: the double every channel's accumulator holds at the start of every block */
+        gpsiq_chain_in_t *cin = malloc(sizeof *cin * (n ? n : 1));
+        start = malloc(sizeof *start * (n ? n : 1));
+        if (!cin || !start) { fprintf(stderr, "out of memory\n"); return 1; }
+        gpsiq_chain_inputs(desc, (int) n, cin);
+        if (gpsiq_reference_chain(cin, (int) h.nblocks, (int) h.nchan, h.fs, (int) h.nsamp, NULL, NULL, start, NULL, NULL) != GPSIQ_OK)
+            return die("chain");
+        free(cin);
+    } else if (gpsiq_quantize_batch(desc, (int) h.nblocks, (int) h.nchan, h.fs, (int) h.nsamp, q, NULL, NULL) != GPSIQ_OK) {
+        /* the whole timeline, so that this shard starts from the exact carried carrier phase */
         return die("quantise");
+    }
     int b0, b1;
     if (gpsiq_shard_range((int) h.nblocks, rank, world, &b0, &b1) != GPSIQ_OK) return die("shard");
 
@@ -65,12 +83,16 @@ int main(int argc, char **argv)
     int failed = 0;
     for (int b = b0; b < b1 && !failed; b += BLOCKS_PER_CALL) {
         const int nb = b1 - b < BLOCKS_PER_CALL ? b1 - b : BLOCKS_PER_CALL;
-        if (gpsiq_generate_quantized(gq, q + (size_t) b * h.nchan, nb, (int) h.nchan, (int) h.nsamp,
-                                     (int) h.sample_size, buf, 0) != GPSIQ_OK) { failed = die("generate"); break; }
+        const int rc = reference
+            ? gpsiq_generate_seeded(gq, desc + (size_t) b * h.nchan, nb, (int) h.nchan, (int) h.nsamp, h.fs, (int) h.sample_size,
+                                    start + (size_t) b * h.nchan, buf, 0)
+            : gpsiq_generate_quantized(gq, q + (size_t) b * h.nchan, nb, (int) h.nchan, (int) h.nsamp, (int) h.sample_size, buf, 0);
+        if (rc != GPSIQ_OK) { failed = die("generate"); break; }
         if (fwrite(buf, blk_bytes, (size_t) nb, fo) != (size_t) nb) failed = 1;
     }
     fclose(fo);
-    printf("rank %d/%d: blocks [%d, %d) of %u on device %d\n", rank, world, b0, b1, h.nblocks, device);
+    printf("rank %d/%d: blocks [%d, %d) of %u on device %d%s\n", rank, world, b0, b1, h.nblocks, device, reference ? ", GPSIQ_NCO_REFERENCE" : "");
+    free(start);
     gpsiq_host_free(buf);
     gpsiq_destroy(gq);
     free(q);

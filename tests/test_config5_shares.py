@@ -140,6 +140,10 @@ def test_the_second_share_alone(gold, desc):
         ctx.launch(0, NB - CUT, NS, SC16, buf.data_ptr(), BLK)
         ctx.synchronize()
         sha = _digests(buf, NB - CUT)
+        # the same as ONE call (what a C rank makes, host/gpsiq_shard.c): evaluated and rendered in pieces from the start states
+        buf.zero_()
+        ctx.generate_seeded(desc[CUT:CUT + 700], NS, float(FS), SC16, starts[CUT:CUT + 700], device_ptr=buf.data_ptr())
+        assert _digests(buf, 700) == gold["sha"][CUT:CUT + 700]
     finally:
         ctx.close()
     bad = [CUT + b for b in range(NB - CUT) if sha[b] != gold["sha"][CUT + b]]

@@ -209,6 +209,36 @@ def test_gpsiq_shard_parts_concatenate_to_the_single_run(host_built, oracle, tmp
 
 
 @pytest.mark.gpu
+def test_gpsiq_shard_in_the_reference_nco_model(host_built, oracle, tmp_path):
+    """C host, time-sharded, GPSIQ_NCO_REFERENCE: every rank walks the carrier chain (gpsiq_reference_chain) and renders ONLY its
+    own block range from the start states (gpsiq_generate_seeded); the three parts concatenate to the float loop's stream."""
+    fs, ns, nb, nc, ss = 10.0e6, 200000, 13, 9, SC16
+    d = synth_blocks(nb, nc, seed=29)
+    rng = np.random.default_rng(3)
+    d["carr_phase"][:] = (rng.integers(0, 512, (nb, nc)) + 1e-12) / 512.0          # candidates and patches at the block starts
+    d["code_phase"][:] = rng.integers(0, 1023, (nb, nc)) + 1e-9
+    d["prn"][4:, 5] = 0
+    d["prn"][9:, 5] = 29
+    dpath = str(tmp_path / "desc.bin")
+    write_descriptors(dpath, d, fs, ns, ss)
+    parts = []
+    for r in range(3):
+        out = str(tmp_path / f"part{r}.bin")
+        p = subprocess.run([os.path.join(host_built, "gpsiq_shard"), dpath, out, str(r), "3", "0", "reference"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "GPSIQ_NCO_REFERENCE" in p.stdout, p.stdout + p.stderr
+        parts.append(np.fromfile(out, dtype=np.int16))
+    got = np.concatenate(parts).reshape(nb, 2 * ns)
+    carr, prev = None, None
+    for b in range(nb):
+        db = d[b].copy()
+        if b:
+            db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+        want, carr = oracle.block_float(db, ns, fs, ss)
+        prev = db["prn"].copy()
+        assert np.array_equal(got[b], want), b
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("contexts,mode", [(0, "fixed"), (3, "fixed"), (2, "reference")])
 def test_gpsiq_render_one_process_all_devices(host_built, oracle, tmp_path, contexts, mode):
     """C host, one process: gpsiq_generate_batch_multi over `contexts` contexts (0 = one per visible GPU), the
