@@ -469,7 +469,10 @@ struct NcoWalk {
     // one load and an add per cycle, no search: the states are as good as random, a binary search would mispredict at every
     // level); the few buckets that straddle an edge fall back to a scan of the entries.
     struct Entry { int64_t first, last, inc; long steps; };
-    static constexpr int kMaxEntries = 64, kBuckets = 1024;
+#ifndef GPSIQ_WALK_BUCKETS
+#define GPSIQ_WALK_BUCKETS 1024
+#endif
+    static constexpr int kMaxEntries = 64, kBuckets = GPSIQ_WALK_BUCKETS;     // scripts/ubench_walk.cpp A/Bs the bucket count
     // The buckets live per thread and are never cleared: a bucket belongs to the table of the run (= block) whose stamp it
     // carries (clearing 1024 of them per block cost as much as a hundred look-ups).  Increment and sample count sit in two
     // arrays, so that the chain state -> shift -> load -> add that every cycle waits for is those three instructions and

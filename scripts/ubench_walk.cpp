@@ -1,9 +1,12 @@
 // ubench_walk.cpp -- cost of the wrap-to-wrap carrier walk (csrc/gpsiq_exact.cpp, NcoWalk) per block and channel on this host,
 // one thread: blocks of 26 000 .. 1 040 000 samples at +-2750 Hz (28 .. 1100 carrier cycles), best of 5 passes over 20 000
 // addends.  Build:  g++ -O3 -std=c++17 -ffp-contract=off [-DKLOW=n] -I multi-sdr-gps-sim_amd/csrc scripts/ubench_walk.cpp
-//                   multi-sdr-gps-sim_amd/csrc/gpsiq_host.cpp -lpthread   (KLOW: binades walked by plain additions, A/B)
+//                   multi-sdr-gps-sim_amd/csrc/gpsiq_host.cpp -lpthread   (KLOW: binades walked by plain additions, BUCKETS: buckets of the wrap-to-wrap table, A/B)
 #ifdef KLOW
 #define GPSIQ_WALK_KLOW KLOW
+#endif
+#ifdef BUCKETS
+#define GPSIQ_WALK_BUCKETS BUCKETS
 #endif
 #include "gpsiq_exact.cpp"
 #include <chrono>

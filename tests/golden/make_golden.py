@@ -326,20 +326,20 @@ def make_config35_golden(which=("cfg3", "cfg5")):
     """BASELINE configs 3 and 5 as the reference itself renders them: the reference program rebuilt at TX_SAMPLERATE
     10 000 000 / 25 000 000 and MAX_CHAN 16 (oracle/_ref/gps-sim-ref-10M / -25M), static BASELINE position, 16 satellites in
     view (tests/golden/synth_static16.21n), --iq16.  Config 3: -d 300 = 2 999 blocks of 10^6 samples (12 GB).  Config 5 is
-    8 GPUs x 450 s; the capture is the first GPU's share, -d 450 = 4 499 blocks of 2.5 * 10^6 samples (45 GB) -- a later
-    share starts from a carrier state only the reference's own run up to there could supply.  SHA-256 of every block and
+    8 GPUs x 450 s; the capture is the WHOLE run, -d 3600 = 35 999 blocks of 2.5 * 10^6 samples (360 GB, about three hours of
+    the reference on one core) -- a later share starts from a carrier state only the reference's own run up to there supplies.  SHA-256 of every block and
     the first 4096 elements of a few; the streams go through a pipe and are never stored."""
     import tempfile
     from _program import program, program_block_digests
     out = {}
-    for name, suffix, fs, seconds, nblocks in (("cfg3", "10M", 10000000, 300, 2999), ("cfg5", "25M", 25000000, 900, 8999)):
+    for name, suffix, fs, seconds, nblocks in (("cfg3", "10M", 10000000, 300, 2999), ("cfg5", "25M", 25000000, 3600, 35999)):
         if name not in which:
             continue
         ref = program("gps-sim-ref-" + suffix)
         assert ref, f"oracle/_ref/gps-sim-ref-{suffix} missing (make -C oracle progs)"
-        keep = (0, 1, 299, 300, 301, nblocks - 1) if name == "cfg3" else (0, 1, 299, 300, 301, 4498, 4499, 4500, 4501, nblocks - 1)
+        keep = (0, 1, 299, 300, 301, nblocks - 1) if name == "cfg3" else (0, 1, 299, 300, 301, 4498, 4499, 4500, 4501, 8998, 8999, 9000, 17999, 18000, 31499, 31500, nblocks - 1)
         with tempfile.TemporaryDirectory() as td:
-            sha, heads = program_block_digests(ref, td, None, seconds, nblocks, fs=fs, keep=keep, timeout=7200)
+            sha, heads = program_block_digests(ref, td, None, seconds, nblocks, fs=fs, keep=keep, timeout=18000)
         out[name + "_sha16"] = np.array(sha)
         out[name + "_head_blocks"] = np.array(sorted(heads))
         out[name + "_heads"] = np.stack([heads[k] for k in sorted(heads)])
