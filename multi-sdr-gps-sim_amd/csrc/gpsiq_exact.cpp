@@ -35,6 +35,9 @@
 #include <cstring>
 #include <ctime>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace gpsiq {
 
@@ -457,6 +460,170 @@ struct NcoWalk {
 
     inline bool cycle(double &x, long &n, long ns) const { return neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr); }
 
+#if defined(__x86_64__)
+    // ---- eight carrier cycles walked at once (AVX-512) -------------------------------------------------------------------
+    // A walked cycle is ~10 dependent binade steps, and a block needs a dozen of them before its wrap-to-wrap table is
+    // complete.  Discovered one at a time as the chain reaches them they are a third of the chain's time; but a cycle depends
+    // only on its start state, every lane goes through the same binades in the same order, and the per-binade piece
+    // (step, run length) is the same for all of them: eight start states take the vector form of climb<true> / descend<true>
+    // -- the same additions, the same slack notes, lane for lane -- in about the time of one.  Anything that is not the plain
+    // case in some lane (a run that needs the division, a state of exactly 1.0, a tie on the wrap, a lane that leaves the
+    // binade sequence) marks that lane not-ok; such a start state is walked by the scalar code when the chain gets there.
+    struct Batch { int64_t m[8], lo[8], hi[8], m2[8], steps[8]; bool ok[8]; };
+
+#define GPSIQ_AVX512 __attribute__((target("avx512f,avx512dq")))
+#define GPSIQ_NOTE(v, act)                                                                                               \
+    do {                                                                                                                 \
+        const __m512i b_ = _mm512_castpd_si512(v);                                                                       \
+        const __m512i e_ = _mm512_srli_epi64(b_, 52);                                                                    \
+        const __m512i sh_ = _mm512_sub_epi64(uexp_v, e_);                                                                \
+        const __mmask8 bad_ = _mm512_cmplt_epi64_mask(sh_, zero) | _mm512_cmpgt_epi64_mask(sh_, sixty2) | _mm512_cmpeq_epi64_mask(e_, zero); \
+        okm &= (__mmask8) ~(bad_ & (act));                                                                               \
+        const __m512i mx_ = _mm512_or_si512(_mm512_and_si512(b_, mant), one52);                                          \
+        const __m512i l_ = _mm512_sub_epi64(two, _mm512_srlv_epi64(_mm512_sub_epi64(mx_, one52), sh_));                  \
+        const __m512i h_ = _mm512_sub_epi64(_mm512_srlv_epi64(_mm512_sub_epi64(one53, mx_), sh_), two);                  \
+        lo = _mm512_mask_max_epi64(lo, (act), lo, l_);                                                                   \
+        hi = _mm512_mask_min_epi64(hi, (act), hi, h_);                                                                   \
+    } while (0)
+
+    // One table binade for all lanes (run + the addition that leaves it): x in binade ec + s on entry.  kDown: negative addend.
+    // Returns with x = the last value inside the binade (after the run), n advanced by the run; the caller adds c.
+    template <bool kDown>
+    GPSIQ_AVX512 inline void batch_level(int s, __m512d &x, __m512i &n, __m512i &lo, __m512i &hi, __mmask8 &okm, const __m512i uexp_v) const
+    {
+        const __m512i zero = _mm512_setzero_si512(), two = _mm512_set1_epi64(2), sixty2 = _mm512_set1_epi64(62);
+        const __m512i mant = _mm512_set1_epi64((int64_t) kMant), one52 = _mm512_set1_epi64((int64_t) 1 << 52), one53 = _mm512_set1_epi64((int64_t) 1 << 53);
+        const Piece &p = T[s];
+        const __m512d cv = _mm512_set1_pd(c);
+        __m512i b = _mm512_castpd_si512(x);
+        okm &= _mm512_cmpeq_epi64_mask(_mm512_srli_epi64(b, 52), _mm512_set1_epi64(ec + s));          // still on the common path
+        __m512i mx = _mm512_or_si512(_mm512_and_si512(b, mant), one52);
+        if (p.tie) {                                                   // an odd mantissa in a tie binade: one real addition first
+            const __mmask8 odd = _mm512_test_epi64_mask(mx, _mm512_set1_epi64(1));
+            if (odd) {
+                x = _mm512_mask_add_pd(x, odd, x, cv);
+                n = _mm512_mask_add_epi64(n, odd, n, _mm512_set1_epi64(1));
+                GPSIQ_NOTE(x, odd);
+                b = _mm512_castpd_si512(x);
+                okm &= _mm512_cmpeq_epi64_mask(_mm512_srli_epi64(b, 52), _mm512_set1_epi64(ec + s));
+                mx = _mm512_or_si512(_mm512_and_si512(b, mant), one52);
+            }
+        }
+        const __m512i off = kDown ? _mm512_sub_epi64(_mm512_set1_epi64(((int64_t) 1 << 53) - 1), mx) : _mm512_sub_epi64(mx, one52);
+        const __mmask8 c1 = _mm512_cmple_epi64_mask(off, _mm512_set1_epi64(p.rem));
+        const __mmask8 c2 = (__mmask8) (~c1 & _mm512_cmple_epi64_mask(off, _mm512_set1_epi64(p.rem + p.dm)));
+        const __mmask8 c3 = _mm512_cmpgt_epi64_mask(off, _mm512_set1_epi64(p.span));
+        okm &= (__mmask8) (c1 | c2 | c3);                              // the run that needs a division: scalar code
+        __m512i run = _mm512_maskz_mov_epi64(c1, _mm512_set1_epi64(p.k));
+        run = _mm512_mask_mov_epi64(run, c2, _mm512_set1_epi64(p.k - 1));
+        __m512i moved = _mm512_maskz_mov_epi64(c1, _mm512_set1_epi64(p.kdm));
+        moved = _mm512_mask_mov_epi64(moved, c2, _mm512_set1_epi64(p.kdm - p.dm));
+        const __m512i mx2 = kDown ? _mm512_sub_epi64(mx, moved) : _mm512_add_epi64(mx, moved);
+        x = _mm512_castsi512_pd(_mm512_or_si512(_mm512_andnot_si512(mant, b), _mm512_and_si512(mx2, mant)));
+        n = _mm512_add_epi64(n, run);
+        const __mmask8 ran = _mm512_cmpgt_epi64_mask(run, zero);
+        GPSIQ_NOTE(x, ran);
+    }
+
+    // positive addend: climb<true> for eight post-wrap states m (units of 2^-52)
+    GPSIQ_AVX512 void walk8_up(int64_t m_max, Batch *io) const
+    {
+        const __m512i zero = _mm512_setzero_si512(), two = _mm512_set1_epi64(2), sixty2 = _mm512_set1_epi64(62);
+        const __m512i mant = _mm512_set1_epi64((int64_t) kMant), one52 = _mm512_set1_epi64((int64_t) 1 << 52), one53 = _mm512_set1_epi64((int64_t) 1 << 53);
+        const __m512i uexp_v = _mm512_set1_epi64(1023);
+        const __m512d cv = _mm512_set1_pd(c), thr_v = _mm512_set1_pd(thr), one = _mm512_set1_pd(1.0);
+        const __m512i m = _mm512_loadu_si512(io->m);
+        __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(m), _mm512_set1_pd(0x1p-52));
+        __m512i n = zero, lo = _mm512_sub_epi64(zero, m), hi = _mm512_sub_epi64(_mm512_set1_epi64(m_max), m);
+        __mmask8 okm = 0xff;
+        // the binades below the table: plain additions (at most 2^(kLow + 1) + 1 of them)
+        for (int it = 0; it < (2 << kLow) + 2; ++it) {
+            const __mmask8 act = _mm512_cmp_pd_mask(x, thr_v, _CMP_LT_OQ);
+            if (!act) break;
+            x = _mm512_mask_add_pd(x, act, x, cv);
+            n = _mm512_mask_add_epi64(n, act, n, _mm512_set1_epi64(1));
+            GPSIQ_NOTE(x, act);
+        }
+        okm &= (__mmask8) ~_mm512_cmp_pd_mask(x, thr_v, _CMP_LT_OQ);
+        const int top = (int) (top_exp - ec);
+        for (int s = kLow + 1; s <= top; ++s) {
+            batch_level<false>(s, x, n, lo, hi, okm, uexp_v);
+            const __m512d y = _mm512_add_pd(x, cv);                        // leaves the binade; at the top: wraps
+            n = _mm512_add_epi64(n, _mm512_set1_epi64(1));
+            if (s < top) { x = y; GPSIQ_NOTE(x, (__mmask8) 0xff); continue; }
+            okm &= _mm512_cmp_pd_mask(y, one, _CMP_GE_OQ);
+            GPSIQ_NOTE(y, (__mmask8) 0xff);
+            const __m512d bb = _mm512_sub_pd(y, x);
+            const __m512d err = _mm512_add_pd(_mm512_sub_pd(x, _mm512_sub_pd(y, bb)), _mm512_sub_pd(cv, bb));    // the rounding error of x + c, exactly
+            okm &= (__mmask8) ~_mm512_cmp_pd_mask(_mm512_abs_pd(err), _mm512_set1_pd(0x1p-53), _CMP_EQ_OQ);      // a tie on the grid the wrap is taken on
+            x = _mm512_sub_pd(y, one);
+        }
+        okm &= _mm512_cmp_pd_mask(x, one, _CMP_LT_OQ);
+        const __m512i m2 = _mm512_cvttpd_epi64(_mm512_mul_pd(x, _mm512_set1_pd(0x1p52)));
+        _mm512_storeu_si512(io->lo, lo); _mm512_storeu_si512(io->hi, hi); _mm512_storeu_si512(io->m2, m2); _mm512_storeu_si512(io->steps, n);
+        for (int q = 0; q < 8; ++q) io->ok[q] = (okm >> q) & 1;
+    }
+
+    // negative addend: descend<true> for eight post-wrap states m (units of 2^-53)
+    GPSIQ_AVX512 void walk8_down(int64_t m_max, Batch *io) const
+    {
+        const __m512i zero = _mm512_setzero_si512(), two = _mm512_set1_epi64(2), sixty2 = _mm512_set1_epi64(62);
+        const __m512i mant = _mm512_set1_epi64((int64_t) kMant), one52 = _mm512_set1_epi64((int64_t) 1 << 52), one53 = _mm512_set1_epi64((int64_t) 1 << 53);
+        const __m512i uexp_v = _mm512_set1_epi64(1022);
+        const __m512d cv = _mm512_set1_pd(c), thr_v = _mm512_set1_pd(thr), one = _mm512_set1_pd(1.0), zd = _mm512_setzero_pd();
+        const __m512i m = _mm512_loadu_si512(io->m);
+        __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(m), _mm512_set1_pd(0x1p-53));
+        __m512i n = zero, lo = _mm512_sub_epi64(zero, m), hi = _mm512_sub_epi64(_mm512_set1_epi64(m_max), m);
+        __mmask8 okm = (__mmask8) (0xff & _mm512_cmp_pd_mask(x, one, _CMP_LT_OQ));        // a state of exactly 1.0: scalar code
+        const int top = (int) (top_exp - ec);
+        for (int s = top; s > kLow; --s) {
+            batch_level<true>(s, x, n, lo, hi, okm, uexp_v);
+            x = _mm512_add_pd(x, cv);                                      // into the binade underneath
+            n = _mm512_add_epi64(n, _mm512_set1_epi64(1));
+            GPSIQ_NOTE(x, (__mmask8) 0xff);
+        }
+        okm &= _mm512_cmp_pd_mask(x, thr_v, _CMP_LT_OQ);
+        // below the table: plain additions until the sum turns negative, then + 1.0
+        const __m512d c2 = _mm512_mul_pd(cv, _mm512_set1_pd(-2.0));
+        __mmask8 open = 0xff;
+        __m512d r_end = zd;
+        for (int it = 0; it < (4 << kLow) + 4 && open; ++it) {
+            const __m512d y = _mm512_add_pd(x, cv);
+            n = _mm512_mask_add_epi64(n, open, n, _mm512_set1_epi64(1));
+            const __mmask8 ng = (__mmask8) (open & _mm512_cmp_pd_mask(y, zd, _CMP_LT_OQ)), ps = (__mmask8) (open & ~ng);
+            if (ng) {
+                const __m512d r = _mm512_add_pd(y, one);
+                // y's own rounding: exact when x lies in the addend's binade (only its sign has to hold), else noted
+                const __mmask8 same = (__mmask8) (ng & _mm512_cmpeq_epi64_mask(_mm512_srli_epi64(_mm512_castpd_si512(x), 52), _mm512_set1_epi64(ec)));
+                const __m512i h = _mm512_sub_epi64(_mm512_cvttpd_epi64(_mm512_mul_pd(_mm512_sub_pd(zd, y), _mm512_set1_pd(0x1p53))), two);
+                hi = _mm512_mask_min_epi64(hi, same, hi, h);
+                const __m512d ny = _mm512_sub_pd(zd, y);
+                GPSIQ_NOTE(ny, (__mmask8) (ng & ~same));
+                const __m512d bb = _mm512_sub_pd(r, y);
+                const __m512d err = _mm512_add_pd(_mm512_sub_pd(y, _mm512_sub_pd(r, bb)), _mm512_sub_pd(one, bb));
+                const __mmask8 badr = (__mmask8) (_mm512_cmp_pd_mask(r, one, _CMP_GE_OQ) | _mm512_cmp_pd_mask(_mm512_abs_pd(err), _mm512_set1_pd(0x1p-54), _CMP_EQ_OQ));
+                okm &= (__mmask8) ~(badr & ng);
+                GPSIQ_NOTE(r, (__mmask8) (ng & ~badr));
+                r_end = _mm512_mask_mov_pd(r_end, ng, r);
+                open &= (__mmask8) ~ng;
+            }
+            if (ps) {
+                // x <= 2|c|: x + c is exact (Sterbenz) for this x and every translated one; it only has to stay non-negative
+                const __mmask8 st = (__mmask8) (ps & _mm512_cmp_pd_mask(x, c2, _CMP_LE_OQ));
+                const __m512i l = _mm512_sub_epi64(two, _mm512_cvttpd_epi64(_mm512_mul_pd(y, _mm512_set1_pd(0x1p53))));
+                lo = _mm512_mask_max_epi64(lo, st, lo, l);
+                GPSIQ_NOTE(y, (__mmask8) (ps & ~st));
+                x = _mm512_mask_mov_pd(x, ps, y);
+            }
+        }
+        okm &= (__mmask8) ~open;
+        const __m512i m2 = _mm512_cvttpd_epi64(_mm512_mul_pd(r_end, _mm512_set1_pd(0x1p53)));
+        _mm512_storeu_si512(io->lo, lo); _mm512_storeu_si512(io->hi, hi); _mm512_storeu_si512(io->m2, m2); _mm512_storeu_si512(io->steps, n);
+        for (int q = 0; q < 8; ++q) io->ok[q] = (okm >> q) & 1;
+    }
+#undef GPSIQ_NOTE
+#endif   // __x86_64__
+
     // the state at sample `target` (>= n) of a walk that is at sample n in state x; counts the wraps on the way
     inline double state_at(double x, long n, long target, long *wraps) const
     {
@@ -560,6 +727,74 @@ struct NcoWalk {
         int ntab = 0;
         long min_steps = ns;                                          // shortest cycle seen
         int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
+        // an entry for the cycle walked from state ms to state m2 in ne samples, valid for start states ms + [lo, hi]
+        auto add_entry = [&](int64_t ms, int64_t m2, long ne, int64_t elo, int64_t ehi) {
+            Entry &t = tab[ntab++];
+            t.first = ms + elo; t.last = ms + ehi; t.inc = m2 - ms; t.steps = ne;
+            if (ne < min_steps) min_steps = ne;
+            // buckets wholly inside [first, last]
+            const int64_t f = t.first - base, l = t.last - base;
+            int64_t k0 = f <= 0 ? 0 : ((f - 1) >> bshift) + 1;        // first bucket starting at or after `first`
+            int64_t k1 = l >= W ? kBuckets - 1 : ((l + 1) >> bshift) - 1;  // last bucket ending at or before `last`
+            if (k1 > kBuckets - 1) k1 = kBuckets - 1;
+            if (ne <= 0xffffffffL) {
+                const uint64_t tag = ((uint64_t) stamp << 32) | (uint64_t) ne;
+                for (int64_t k = k0; k <= k1; ++k) { bkt.inc[k] = t.inc; bkt.tag[k] = tag; }
+            }
+        };
+#if defined(__x86_64__)
+        // The table built ahead of the chain, eight cycles at a time (walk8_up / walk8_down).  The post-wrap states of a block
+        // fill their range [base, base + W) evenly (a rotation by an irrational step), so with enough cycles in the block every
+        // entry will be needed -- and which start states to walk is known without the chain: first eight states spread over the
+        // range, then the first uncovered state of every gap those eight entries leave, then once more.  What is still
+        // uncovered after that (slivers; cycles that are not the plain case) is found on demand below, as before.
+        static const bool batched = __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512f") && !std::getenv("GPSIQ_WALK_NOBATCH");
+        if (batched && kind == 1 && std::fabs(c) * (double) ns > 64.0 * span) {
+            const int64_t d_lo = base < 0 ? 0 : base, d_hi = base + W - 1 > m_max ? m_max : base + W - 1;      // the range, inside the accumulator's
+            Batch bt;
+            for (int q = 0; q < 8; ++q) bt.m[q] = d_lo + ((d_hi - d_lo) * (2 * q + 1)) / 16;
+            for (int round = 0; round < 3 && ntab <= kMaxEntries - 8; ++round) {
+                if (neg) walk8_down(m_max, &bt); else walk8_up(m_max, &bt);
+                for (int q = 0; q < 8; ++q)
+                    if (bt.ok[q] && bt.lo[q] <= 0 && bt.hi[q] >= 0 && bt.m2[q] >= 0 && bt.m2[q] <= m_max && bt.steps[q] > 0) {
+                        bool dup = false;                              // lanes that repeat a start state, or fell into an entry of this round
+                        for (int i = 0; i < ntab && !dup; ++i) dup = tab[i].first <= bt.m[q] && bt.m[q] <= tab[i].last;
+                        if (!dup) add_entry(bt.m[q], bt.m2[q], (long) bt.steps[q], bt.lo[q], bt.hi[q]);
+                    }
+                // the gaps the entries leave in [d_lo, d_hi], widest first
+                int order[kMaxEntries];
+                for (int i = 0; i < ntab; ++i) {                       // insertion sort by `first`
+                    int j = i;
+                    for (; j > 0 && tab[order[j - 1]].first > tab[i].first; --j) order[j] = order[j - 1];
+                    order[j] = i;
+                }
+                int64_t gs[kMaxEntries + 1], gl[kMaxEntries + 1];
+                int ng = 0;
+                int64_t at = d_lo, open = 0;
+                for (int i = 0; i < ntab; ++i) {
+                    const Entry &e = tab[order[i]];
+                    if (e.first > at) { gs[ng] = at; gl[ng] = e.first - at; open += gl[ng]; ++ng; }
+                    if (e.last + 1 > at) at = e.last + 1;
+                }
+                if (at <= d_hi) { gs[ng] = at; gl[ng] = d_hi - at + 1; open += gl[ng]; ++ng; }
+                if (ng == 0 || open * 64 < (d_hi - d_lo)) break;        // covered but for slivers
+                // the eight lanes of the next round over the gaps, by width: a gap's first uncovered state, and states spread over
+                // its inside when it gets more than one lane (an entry reaches down from its start state as well as up)
+                int q = 0;
+                while (q < 8) {
+                    int w = -1;
+                    for (int g = 0; g < ng; ++g) if (gl[g] > 0 && (w < 0 || gl[g] > gl[w])) w = g;
+                    if (w < 0) break;
+                    int k = (int) ((8 * gl[w] + open / 2) / open);
+                    if (k < 1) k = 1;
+                    if (k > 8 - q) k = 8 - q;
+                    for (int i = 0; i < k; ++i) bt.m[q++] = gs[w] + (gl[w] * i) / k;
+                    gl[w] = 0;
+                }
+                for (; q < 8; ++q) bt.m[q] = bt.m[0];                    // fewer gaps than lanes: repeats (dropped as duplicates)
+            }
+        }
+#endif
         for (;;) {
             // the common case, cycle after cycle: the state's bucket lies wholly inside one entry and names its increment.
             // Stops before a cycle that would pass the end of the block or hold the next target.
@@ -597,20 +832,7 @@ struct NcoWalk {
             if (!wrapped) return x;                                   // the block ended inside this cycle
             ++wraps;
             const int64_t m2 = (int64_t) (x * scale);
-            if (sl.ok && sl.lo <= 0 && sl.hi >= 0 && x < wrap && m2 <= m_max) {
-                Entry &t = tab[ntab++];
-                t.first = m + sl.lo; t.last = m + sl.hi; t.inc = m2 - m; t.steps = ne;
-                if (ne < min_steps) min_steps = ne;
-                // buckets wholly inside [first, last]
-                const int64_t f = t.first - base, l = t.last - base;
-                int64_t k0 = f <= 0 ? 0 : ((f - 1) >> bshift) + 1;    // first bucket starting at or after `first`
-                int64_t k1 = l >= W ? kBuckets - 1 : ((l + 1) >> bshift) - 1;  // last bucket ending at or before `last`
-                if (k1 > kBuckets - 1) k1 = kBuckets - 1;
-                if (ne <= 0xffffffffL) {
-                    const uint64_t tag = ((uint64_t) stamp << 32) | (uint64_t) ne;
-                    for (int64_t k = k0; k <= k1; ++k) { bkt.inc[k] = t.inc; bkt.tag[k] = tag; }
-                }
-            }
+            if (sl.ok && sl.lo <= 0 && sl.hi >= 0 && x < wrap && m2 <= m_max) add_entry(m, m2, ne, sl.lo, sl.hi);
             m = m2;
         }
         // the last, partial cycle
