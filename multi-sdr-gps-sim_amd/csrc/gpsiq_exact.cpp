@@ -751,47 +751,70 @@ struct NcoWalk {
         static const bool batched = __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512f") && !std::getenv("GPSIQ_WALK_NOBATCH");
         if (batched && kind == 1 && std::fabs(c) * (double) ns > 64.0 * span) {
             const int64_t d_lo = base < 0 ? 0 : base, d_hi = base + W - 1 > m_max ? m_max : base + W - 1;      // the range, inside the accumulator's
+            const double range = (double) (d_hi - d_lo);
             Batch bt;
-            for (int q = 0; q < 8; ++q) bt.m[q] = d_lo + ((d_hi - d_lo) * (2 * q + 1)) / 16;
-            for (int round = 0; round < 3 && ntab <= kMaxEntries - 8; ++round) {
+            auto take = [&]() {                                        // the lanes of a round that are new, valid entries
                 if (neg) walk8_down(m_max, &bt); else walk8_up(m_max, &bt);
-                for (int q = 0; q < 8; ++q)
-                    if (bt.ok[q] && bt.lo[q] <= 0 && bt.hi[q] >= 0 && bt.m2[q] >= 0 && bt.m2[q] <= m_max && bt.steps[q] > 0) {
-                        bool dup = false;                              // lanes that repeat a start state, or fell into an entry of this round
-                        for (int i = 0; i < ntab && !dup; ++i) dup = tab[i].first <= bt.m[q] && bt.m[q] <= tab[i].last;
-                        if (!dup) add_entry(bt.m[q], bt.m2[q], (long) bt.steps[q], bt.lo[q], bt.hi[q]);
+                for (int q = 0; q < 8 && ntab < kMaxEntries; ++q) {
+                    if (!(bt.ok[q] && bt.lo[q] <= 0 && bt.hi[q] >= 0 && bt.m2[q] >= 0 && bt.m2[q] <= m_max && bt.steps[q] > 0)) continue;
+                    bool dup = false;                                  // a lane that repeats a start state, or fell into an entry already there
+                    for (int i = 0; i < ntab && !dup; ++i) dup = tab[i].first <= bt.m[q] && bt.m[q] <= tab[i].last;
+                    if (!dup) add_entry(bt.m[q], bt.m2[q], (long) bt.steps[q], bt.lo[q], bt.hi[q]);
+                }
+            };
+            // Where the entries of the table this thread built last lay, if that was for nearly the same addend (a thread walks the
+            // blocks of one channel one after the other; the Doppler moves by a fraction of a hertz per block, and the entries with
+            // it): one lane per entry, two rounds, no search.  Else: eight states spread over the range, then twice the gaps the
+            // entries leave, lanes by gap width (a gap's first uncovered state, and states spread over its inside when it gets
+            // more than one lane: an entry reaches down from its start state as well as up).
+            struct Hint { double c; int n; double at[16]; };
+            static thread_local Hint hint = {0.0, 0, {}};
+            if (hint.n >= 6 && (hint.c < 0.0) == neg && std::fabs(c - hint.c) <= std::fabs(c) * 0x1p-10) {
+                for (int r0 = 0; r0 < hint.n; r0 += 8) {
+                    for (int q = 0; q < 8; ++q) bt.m[q] = d_lo + (int64_t) (range * hint.at[r0 + q < hint.n ? r0 + q : r0]);
+                    take();
+                }
+            } else {
+                for (int q = 0; q < 8; ++q) bt.m[q] = d_lo + ((d_hi - d_lo) * (2 * q + 1)) / 16;
+                for (int round = 0; round < 3 && ntab <= kMaxEntries - 8; ++round) {
+                    take();
+                    int order[kMaxEntries];
+                    for (int i = 0; i < ntab; ++i) {                   // insertion sort by `first`
+                        int j = i;
+                        for (; j > 0 && tab[order[j - 1]].first > tab[i].first; --j) order[j] = order[j - 1];
+                        order[j] = i;
                     }
-                // the gaps the entries leave in [d_lo, d_hi], widest first
-                int order[kMaxEntries];
-                for (int i = 0; i < ntab; ++i) {                       // insertion sort by `first`
-                    int j = i;
-                    for (; j > 0 && tab[order[j - 1]].first > tab[i].first; --j) order[j] = order[j - 1];
-                    order[j] = i;
+                    int64_t gs[kMaxEntries + 1], gl[kMaxEntries + 1];
+                    int ng = 0;
+                    int64_t at = d_lo, open = 0;
+                    for (int i = 0; i < ntab; ++i) {
+                        const Entry &e = tab[order[i]];
+                        if (e.first > at) { gs[ng] = at; gl[ng] = e.first - at; open += gl[ng]; ++ng; }
+                        if (e.last + 1 > at) at = e.last + 1;
+                    }
+                    if (at <= d_hi) { gs[ng] = at; gl[ng] = d_hi - at + 1; open += gl[ng]; ++ng; }
+                    if (ng == 0 || open * 64 < (d_hi - d_lo)) break;    // covered but for slivers
+                    int q = 0;
+                    while (q < 8) {
+                        int w = -1;
+                        for (int g = 0; g < ng; ++g) if (gl[g] > 0 && (w < 0 || gl[g] > gl[w])) w = g;
+                        if (w < 0) break;
+                        int k = (int) ((8 * gl[w] + open / 2) / open);
+                        if (k < 1) k = 1;
+                        if (k > 8 - q) k = 8 - q;
+                        for (int i = 0; i < k; ++i) bt.m[q++] = gs[w] + (gl[w] * i) / k;
+                        gl[w] = 0;
+                    }
+                    for (; q < 8; ++q) bt.m[q] = bt.m[0];                // fewer gaps than lanes: repeats (dropped as duplicates)
                 }
-                int64_t gs[kMaxEntries + 1], gl[kMaxEntries + 1];
-                int ng = 0;
-                int64_t at = d_lo, open = 0;
-                for (int i = 0; i < ntab; ++i) {
-                    const Entry &e = tab[order[i]];
-                    if (e.first > at) { gs[ng] = at; gl[ng] = e.first - at; open += gl[ng]; ++ng; }
-                    if (e.last + 1 > at) at = e.last + 1;
-                }
-                if (at <= d_hi) { gs[ng] = at; gl[ng] = d_hi - at + 1; open += gl[ng]; ++ng; }
-                if (ng == 0 || open * 64 < (d_hi - d_lo)) break;        // covered but for slivers
-                // the eight lanes of the next round over the gaps, by width: a gap's first uncovered state, and states spread over
-                // its inside when it gets more than one lane (an entry reaches down from its start state as well as up)
-                int q = 0;
-                while (q < 8) {
-                    int w = -1;
-                    for (int g = 0; g < ng; ++g) if (gl[g] > 0 && (w < 0 || gl[g] > gl[w])) w = g;
-                    if (w < 0) break;
-                    int k = (int) ((8 * gl[w] + open / 2) / open);
-                    if (k < 1) k = 1;
-                    if (k > 8 - q) k = 8 - q;
-                    for (int i = 0; i < k; ++i) bt.m[q++] = gs[w] + (gl[w] * i) / k;
-                    gl[w] = 0;
-                }
-                for (; q < 8; ++q) bt.m[q] = bt.m[0];                    // fewer gaps than lanes: repeats (dropped as duplicates)
+            }
+            // for the next block of this thread: the middle of every entry, as a fraction of the range
+            hint.n = ntab < 16 ? ntab : 16;
+            hint.c = c;
+            const double inv = 1.0 / range;
+            for (int i = 0; i < hint.n; ++i) {
+                const int64_t lo_i = tab[i].first < d_lo ? d_lo : tab[i].first, hi_i = tab[i].last > d_hi ? d_hi : tab[i].last;
+                hint.at[i] = ((double) (lo_i - d_lo) + (double) (hi_i - lo_i) * 0.5) * inv;
             }
         }
 #endif

@@ -264,3 +264,26 @@ def test_candidates_decided_from_the_start_state_equal_the_walked_ones():
     s1 = gpsiq.reference_stats()
     assert patches > 200 and s1[1] - s0[1] > 20000                         # decided without a walk, and checked against the walk
     assert (s1[2] - s0[2]) + (s1[3] - s0[3]) >= (s1[0] - s0[0]) // 2       # the NO_DRIFT halves walked everything
+
+
+@pytest.mark.parametrize("fs", [2.6e6, 25e6])
+def test_table_built_from_the_previous_blocks_layout(oracle, fs):
+    """On hosts with AVX-512 the wrap-to-wrap table of a block is built eight cycles at a time, and from the second block of a
+    channel on the start states walked are where the previous block's entries lay (the Doppler moves by a fraction of a hertz
+    per block).  Forty blocks per channel with a slow Doppler drift, a jump (no usable hint), a sign change and a slot that
+    is re-allocated: the carried phase after every block == the plain loop of gps.c:2821-2826."""
+    ns = int(fs) // 10
+    nb, nc = 40, 16
+    d = synth_blocks(nb, nc, seed=404, doppler_hz=6000.0, drift_hz=0.3)
+    d["f_carr"][20:, 3] += 700.0                        # a jump: the hint does not apply to block 20
+    d["f_carr"][10:, 5] *= -1.0                         # the other direction from block 10 on
+    d["f_carr"][:, 7] = 30.0                            # three cycles per block: never tabled
+    d["prn"][25:, 9] = 17                               # re-allocated: the chain restarts from its carr_phase
+    d["f_code"] = 1.023e6 + d["f_carr"] / 1540.0
+    x = d["carr_phase"][0].copy()
+    for b in range(nb):
+        x = np.where(b == 25, np.where(np.arange(nc) == 9, d["carr_phase"][b], x), x)
+        _, _, got = gpsiq.reference_blocks(d[:b + 1], fs, ns) if b in (0, 1, 19, 20, 21, 39) else (None, None, None)
+        x = np.array([oracle.carrier_chain(x[i], d["f_carr"][b, i] * (1.0 / fs), ns) for i in range(nc)])
+        if got is not None:
+            assert got.tobytes() == x.tobytes(), b
