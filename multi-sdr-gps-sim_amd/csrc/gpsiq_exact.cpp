@@ -187,10 +187,13 @@ struct Nco {
     }
 };
 
-// Smallest x >= 0 with L <= (A*x mod M) <= R, for 0 <= L <= R < M and 0 <= A < M; kNone if there is none.
+// Smallest x in [0, bound) with L <= (A*x mod M) <= R, for 0 <= L <= R < M and 0 <= A < M; kNone if there is none.
+// The bound goes down the descent with the problem (x < bound needs y <= (A*(bound-1) - L) / M wraps of M), so a search
+// that cannot succeed inside the block stops after ~log2(bound) levels instead of ~log(M).
 constexpr u128 kNone = ~(u128) 0;
-u128 first_in_range(uint64_t A, uint64_t M, uint64_t L, uint64_t R)
+u128 first_in_range(uint64_t A, uint64_t M, uint64_t L, uint64_t R, u128 bound)
 {
+    if (bound == 0) return kNone;
     if (L == 0) return 0;
     if (A == 0) return kNone;
     if (A > M - A) {                 // 2A > M: count downwards instead
@@ -198,13 +201,20 @@ u128 first_in_range(uint64_t A, uint64_t M, uint64_t L, uint64_t R)
         const uint64_t l = M - R, r = M - L;
         L = l; R = r;
     }
-    const uint64_t k = (L + A - 1) / A;
-    if ((u128) k * A <= R) return k;
+    const uint64_t lq = L / A, lr = L - lq * A;                   // one division serves the first multiple and L mod A
+    const uint64_t k = lq + (lr != 0);
+    if ((u128) k * A <= R) return k < bound ? (u128) k : kNone;
     // no multiple of A inside [L, R]: after y wraps of M the window is at M*y + [L, R]; it holds a
     // multiple of A iff ((-M mod A) * y) mod A lies in [L mod A, R mod A]
-    const u128 y = first_in_range((A - M % A) % A, A, L % A, R % A);
+    const u128 reach = (u128) A * (bound - 1);                    // A * x for the largest x allowed
+    if (reach < L) return kNone;
+    // the wraps that can matter, a little generously (a double quotient instead of a 128-bit division; the result is checked)
+    const u128 ybound = (u128) ((double) (reach - L) / (double) M * (1.0 + 0x1p-40)) + 2;
+    const uint64_t mr = M % A;
+    const u128 y = first_in_range(mr ? A - mr : 0, A, lr, R % A, ybound);
     if (y == kNone) return kNone;
-    return ((u128) M * y + L + A - 1) / A;
+    const u128 x = ((u128) M * y + L + A - 1) / A;
+    return x < bound ? x : kNone;
 }
 
 // All n in [0, nsamp) with (a + n*b) mod 2^k within w of 0 (either side), ascending; false if there
@@ -221,8 +231,8 @@ bool candidates(uint64_t a, uint64_t b, int k, uint64_t w, long nsamp, size_t ca
         long hit;
         if (cur < W) hit = base;
         else {
-            const u128 x = first_in_range(b, M, M - cur, M - cur + W - 1);
-            if (x == kNone || x >= (u128) (nsamp - base)) break;
+            const u128 x = first_in_range(b, M, M - cur, M - cur + W - 1, (u128) (nsamp - base));
+            if (x == kNone) break;
             hit = base + (long) x;
         }
         if (out->size() >= cap) return false;
@@ -621,6 +631,14 @@ struct NcoWalk {
         _mm512_storeu_si512(io->lo, lo); _mm512_storeu_si512(io->hi, hi); _mm512_storeu_si512(io->m2, m2); _mm512_storeu_si512(io->steps, n);
         for (int q = 0; q < 8; ++q) io->ok[q] = (okm >> q) & 1;
     }
+    // the buckets [k0, k1] of one entry, eight per store
+    GPSIQ_AVX512 static void fill8(int64_t *inc, uint64_t *tag, int64_t k0, int64_t k1, int64_t vinc, uint64_t vtag)
+    {
+        const __m512i vi = _mm512_set1_epi64(vinc), vt = _mm512_set1_epi64((int64_t) vtag);
+        int64_t k = k0;
+        for (; k + 7 <= k1; k += 8) { _mm512_storeu_si512(inc + k, vi); _mm512_storeu_si512(tag + k, vt); }
+        for (; k <= k1; ++k) { inc[k] = vinc; tag[k] = vtag; }
+    }
 #undef GPSIQ_NOTE
 #endif   // __x86_64__
 
@@ -727,6 +745,9 @@ struct NcoWalk {
         int ntab = 0;
         long min_steps = ns;                                          // shortest cycle seen
         int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
+#if defined(__x86_64__)
+        static const bool wide = __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512f") && !std::getenv("GPSIQ_WALK_NOBATCH");
+#endif
         // an entry for the cycle walked from state ms to state m2 in ne samples, valid for start states ms + [lo, hi]
         auto add_entry = [&](int64_t ms, int64_t m2, long ne, int64_t elo, int64_t ehi) {
             Entry &t = tab[ntab++];
@@ -739,6 +760,9 @@ struct NcoWalk {
             if (k1 > kBuckets - 1) k1 = kBuckets - 1;
             if (ne <= 0xffffffffL) {
                 const uint64_t tag = ((uint64_t) stamp << 32) | (uint64_t) ne;
+#if defined(__x86_64__)
+                if (wide) { fill8(bkt.inc, bkt.tag, k0, k1, t.inc, tag); return; }
+#endif
                 for (int64_t k = k0; k <= k1; ++k) { bkt.inc[k] = t.inc; bkt.tag[k] = tag; }
             }
         };
@@ -748,8 +772,7 @@ struct NcoWalk {
         // entry will be needed -- and which start states to walk is known without the chain: first eight states spread over the
         // range, then the first uncovered state of every gap those eight entries leave, then once more.  What is still
         // uncovered after that (slivers; cycles that are not the plain case) is found on demand below, as before.
-        static const bool batched = __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512f") && !std::getenv("GPSIQ_WALK_NOBATCH");
-        if (batched && kind == 1 && std::fabs(c) * (double) ns > 64.0 * span) {
+        if (wide && kind == 1 && std::fabs(c) * (double) ns > 64.0 * span) {
             const int64_t d_lo = base < 0 ? 0 : base, d_hi = base + W - 1 > m_max ? m_max : base + W - 1;      // the range, inside the accumulator's
             const double range = (double) (d_hi - d_lo);
             Batch bt;
