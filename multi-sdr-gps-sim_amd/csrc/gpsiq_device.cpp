@@ -911,42 +911,20 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size;
     const int piece = batch_piece_blocks(nblocks, nsamp);
     if (dst_is_device && !(blk_bytes & 15) && !((uintptr_t) dst & 3) && piece < nblocks && nsamp > 0) {
-        // A long batch into device memory: quantise, validate and upload piece k+1 (host threads) under the kernel of
-        // piece k.  The carrier prefix goes from piece to piece exactly as it goes from call to call.
-        // Every descriptor of the timeline is range-checked BEFORE the first piece is launched (the quantiser's own checks, run
-        // once more without keeping the result: ~3 % of the call): a bad descriptor in a late block fails the call with the
-        // caller's buffer, the resident set and the carried phases untouched, as when the batch is rendered in one piece.
-        {
-            struct VJob { const gpsiq_chan_t *ch; int nchan, nsamp; double delt; int rc; char err[320]; };
-            VJob vj = {ch, nchan, nsamp, 1.0 / fs, GPSIQ_OK, ""};
-            parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
-                VJob &j = *static_cast<VJob *>(p);
-                gpsiq_qchan_t scratch;
-                for (int b = b0; b < b1 && __atomic_load_n(&j.rc, __ATOMIC_RELAXED) == GPSIQ_OK; ++b)
-                    for (int i = 0; i < j.nchan; ++i) {
-                        const int qrc = quantize_one(j.ch[(size_t) b * j.nchan + i], j.delt, j.nsamp, nullptr, &scratch, nullptr);
-                        if (qrc != GPSIQ_OK && __sync_bool_compare_and_swap(&j.rc, GPSIQ_OK, qrc))
-                            std::snprintf(j.err, sizeof j.err, "block %d: %.280s", b, gpsiq_last_error());
-                    }
-            }, &vj);
-            if (vj.rc != GPSIQ_OK) return fail(vj.rc, "%s", vj.err);
-        }
-        bool cont[GPSIQ_MAX_CHAN];
-        uint64_t seed[GPSIQ_MAX_CHAN];
-        for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }
-        std::vector<gpsiq_qchan_t> q((size_t) piece * (size_t) nchan);          // one piece's worth, reused (gpsiq_set_descriptors copies it out)
-        for (int b0 = 0; b0 < nblocks && rc == GPSIQ_OK; b0 += piece) {
-            const int nb = nblocks - b0 < piece ? nblocks - b0 : piece;
-            gpsiq_qchan_t *qp = q.data();
-            rc = quantize_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, cont, seed, qp, carry, prev_prn);
-            if (rc == GPSIQ_OK) rc = set_descriptors_impl(c, qp, nb, nchan, nullptr, 0, true);
+        // A long batch into device memory.  The whole timeline is quantised first (host threads; the exact carrier prefix down
+        // every slot) -- which is also every range check there is, so a bad descriptor in a late block fails the call with the
+        // caller's buffer, the resident set and the carried phases untouched -- and then rendered in pieces: compaction + upload
+        // of piece k+1 are queued under the kernel of piece k, small pieces at both ends (piece_ends: nothing renders before
+        // the first upload has landed, and the last kernel is all that is left when the host is through).
+        std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+        rc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
+        if (rc) return rc;
+        std::vector<int> ends;
+        piece_ends(0, nblocks, piece / 2 > 0 ? piece / 2 : 1, &ends);
+        for (size_t k = 0; k < ends.size() && rc == GPSIQ_OK; ++k) {
+            const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+            rc = set_descriptors_impl(c, q.data() + (size_t) b0 * nchan, nb, nchan, nullptr, 0, true);
             if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, c->stream, kAuto);
-            for (int i = 0; i < nchan; ++i) {
-                // the next piece continues a slot while it keeps its PRN and re-seeds it otherwise, as inside one timeline
-                const gpsiq_chan_t *next = b0 + nb < nblocks ? &ch[(size_t) (b0 + nb) * nchan + i] : nullptr;
-                cont[i] = next && next->prn > 0 && prev_prn[i] == next->prn;
-                seed[i] = carry[i];
-            }
         }
         char err[400] = "";
         if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());

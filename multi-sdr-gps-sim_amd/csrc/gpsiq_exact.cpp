@@ -1028,14 +1028,25 @@ static inline double chain_block(double f_carr, double delt, int nsamp, double s
 // entry or sign than the closed form.  The candidates are found without visiting samples (candidates()); each is decided by
 // the drift enclosure from the block's start state, and only where a boundary lies inside the enclosure are the accumulators
 // walked (from the block's start, to the last undecided sample).
+// slot_of: the block's descriptors up to this channel (blk[0 .. i]), or null with `slot` given: the device order counts the
+// active channels before this one (gpsiq_set_descriptors), which is only looked up when a patch is written.
 static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int nsamp, int block, int slot,
-                      CodeCache *codes, gpsiq_qchan_t *qq, std::vector<gpsiq_patch_t> *out, bool no_drift = false)
+                      CodeCache *codes, gpsiq_qchan_t *qq, std::vector<gpsiq_patch_t> *out, bool no_drift = false,
+                      const gpsiq_chan_t *blk = nullptr, int i_in_blk = 0)
 {
-    gpsiq_chan_t ch = ch_in;
+    const gpsiq_chan_t &ch = ch_in;
     // a start of exactly 1.0 (a wrap of the block before that rounded up to one) is phase 0 of the closed form (mod 1); the
-    // reference goes on from 1.0, and sample 0, where it indexes its table at 512, is patched
-    ch.carr_phase = start == 1.0 ? 0.0 : start;
-    const int qrc = quantize_one(ch, delt, nsamp, nullptr, qq, nullptr);
+    // reference goes on from 1.0, and sample 0, where it indexes its table at 512, is patched.  The start state replaces the
+    // descriptor's own carr_phase (handed to the quantiser as the carried phase: the 296-byte descriptor is not copied)
+    if (!(start >= 0.0 && start <= 1.0)) return fail(GPSIQ_E_RANGE, "prn %d: start phase %g outside [0, 1]", ch.prn, start);
+    const uint64_t seeded = carr_phase_to_fixed(start == 1.0 ? 0.0 : start);
+    int qrc;
+    if (ch.carr_phase >= 0.0 && ch.carr_phase < 1.0) qrc = quantize_one(ch, delt, nsamp, &seeded, qq, nullptr);
+    else {                         // the descriptor's own phase is the 1.0 the reference handed back (or garbage): not the quantiser's business here
+        gpsiq_chan_t tmp = ch;
+        tmp.carr_phase = 0.0;
+        qrc = quantize_one(tmp, delt, nsamp, &seeded, qq, nullptr);
+    }
     if (qrc != GPSIQ_OK) return qrc;
     const gpsiq_qchan_t &q = *qq;
     const long ns = nsamp;
@@ -1136,6 +1147,7 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
             ++ik;
         }
         if (idx != idx_f || neg_d != neg_f) {
+            if (blk) { slot = 0; for (int j = 0; j < i_in_blk; ++j) slot += blk[j].prn > 0; blk = nullptr; }
             gpsiq_patch_t p;
             p.block = (uint32_t) block; p.sample = (uint32_t) n;
             p.slot = (uint8_t) slot; p.neg = (uint8_t) neg_d; p.lut = (uint16_t) idx;
@@ -1236,9 +1248,7 @@ void RefWalk::eval_task(int i, size_t k, CodeCache *codes)
             (void) quantize_one(none, delt, nsamp, nullptr, &q[at], nullptr);           // an unused slot: zeroes
             continue;
         }
-        int slot = 0;                                            // device order: active channels first (gpsiq_set_descriptors)
-        for (int j = 0; j < i; ++j) slot += ch[(size_t) b * nchan + j].prn > 0;
-        const int erc = eval_block(d, start[at], delt, nsamp, b, slot, codes, &q[at], mine, no_drift);
+        const int erc = eval_block(d, start[at], delt, nsamp, b, 0, codes, &q[at], mine, no_drift, &ch[(size_t) b * nchan], i);
         if (erc != GPSIQ_OK) set_error(erc, gpsiq_last_error(), b);
     }
 }
