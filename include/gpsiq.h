@@ -295,7 +295,9 @@ int gpsiq_wait(gpsiq_ctx_t *ctx);
  * pointer on the context's device (no D2H).  carr_phase_out[nchan] (may be NULL) receives
  * the carrier phase after the last block, to be put into the next batch's block 0.
  * A long batch is worked through in pieces, the host side of piece k+1 (quantiser or, in GPSIQ_NCO_REFERENCE, the
- * carrier walk) under the kernel of piece k; the call returns when everything has landed. */
+ * carrier chain and the evaluation) under the kernel of piece k; the call returns when everything has landed.  Descriptors
+ * are range-checked piece by piece: when a later piece fails its check the call returns the error after earlier pieces
+ * have been rendered -- dst and the resident descriptor set are then undefined; the carried phases are untouched. */
 int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, int dst_is_device, double *carr_phase_out);
