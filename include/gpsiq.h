@@ -152,7 +152,7 @@ typedef struct gpsiq_patch {
 
 /* ---- [boundary] library / tables (no device needed) ----------------------- */
 const char *gpsiq_version(void);
-/* first 16 hex digits of the SHA-256 of the device-code source (csrc/gpsiq_kernels.hip) this library was built from: a
+/* [sharding / measurement] first 16 hex digits of the SHA-256 of the device-code source (csrc/gpsiq_kernels.hip) this library was built from: a
  * profile taken from one library (profiles/pmc_*.json record it) is only replayed next to measurements of the same one */
 const char *gpsiq_kernels_id(void);
 /* last error text of the calling thread ("" if none) */
@@ -314,13 +314,6 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
                                int nsamp, double fs, int sample_size, void *host_dst, void *const *dev_dst,
                                double *carr_phase_out);
 
-/* One shard of a time-sharded run in GPSIQ_NCO_REFERENCE, whatever the context's mode: render nblocks blocks whose start
- * states are known (carr_start[nblocks][nchan], this range's rows of gpsiq_reference_chain; ch[b][i].carr_phase is not
- * read) into dst, host or device as above -- evaluated and rendered in pieces like gpsiq_generate_batch, with no reference
- * to the blocks before the range.  Synchronous.  Does not touch the carrier continuation state. */
-int gpsiq_generate_seeded(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
-                          int sample_size, const double *carr_start, void *dst, int dst_is_device);
-
 /* One shard of a time-sharded run: synthesise nblocks already-quantised blocks
  * (a contiguous slice of gpsiq_quantize_batch's output, which carries the exact carrier
  * phase of every block) into dst, host or device as above.  Synchronous.  Does not touch
@@ -334,6 +327,13 @@ void *gpsiq_host_alloc(size_t bytes);
 void  gpsiq_host_free(void *p);
 
 /* ---- [sharding] resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
+/* One shard of a time-sharded run in GPSIQ_NCO_REFERENCE, whatever the context's mode: render nblocks blocks whose start
+ * states are known (carr_start[nblocks][nchan], this range's rows of gpsiq_reference_chain; ch[b][i].carr_phase is not
+ * read) into dst, host or device as above -- evaluated and rendered in pieces like gpsiq_generate_batch, with no reference
+ * to the blocks before the range.  Synchronous.  Does not touch the carrier continuation state. */
+int gpsiq_generate_seeded(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
+                          int sample_size, const double *carr_start, void *dst, int dst_is_device);
+
 /* Copy nblocks*nchan quantised descriptors ([nblocks][nchan]) to the device. */
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
 /* Patches that go with the resident descriptors (gpsiq_reference_batch); every later gpsiq_launch
