@@ -132,11 +132,13 @@ typedef struct gpsiq_ctx gpsiq_ctx_t;
  * an independent function of its descriptor, so the time axis shards freely.  GPSIQ_NCO_REFERENCE: the
  * reference's own double accumulators (gps.c:2789-2792, 2821-2826), reproduced exactly: a whole run
  * equals the reference element for element and carr_phase is handed out as the reference's accumulator
- * leaves it.  Costs a serial walk of the carrier per channel on the host (a table look-up per carrier cycle
- * once the cycles of a block have been seen, a dozen integer steps for those that have not, see
- * csrc/gpsiq_exact.cpp); the device runs the same kernels plus a fix-up of the few samples per 10^7 where
- * the two models differ.  A batch is walked and rendered in pieces (GPSIQ_REF_CHUNK_BLOCKS, default 256 blocks):
- * the device renders piece k under the walk of piece k+1. */
+ * leaves it.  Costs a carrier chain per channel on the host that is serial in time (~2 us per block: a table look-up per
+ * carrier cycle, the table of a block's dozen distinct cycles built eight at a time where the host has AVX-512, see
+ * csrc/gpsiq_exact.cpp) -- everything else about a block follows from its start state and runs on any thread, device or
+ * process (gpsiq_reference_chain / gpsiq_reference_seeded / gpsiq_generate_seeded below); the device runs the same kernels
+ * plus a fix-up of the few samples per 10^7 where the two models differ.  A batch is worked through in pieces
+ * (GPSIQ_REF_CHUNK_BLOCKS, default 256 blocks at 2.6 Msps; half a piece first, doubled ones in the middle): the device
+ * renders piece k under the host side of the pieces behind it. */
 #define GPSIQ_NCO_FIXED      0
 #define GPSIQ_NCO_REFERENCE  1
 
