@@ -87,6 +87,10 @@ struct gpsiq_ctx {
     uint64_t carry[GPSIQ_MAX_CHAN] = {};
     double   handed[GPSIQ_MAX_CHAN] = {};
     int      carry_prn[GPSIQ_MAX_CHAN] = {};
+    // GPSIQ_NCO_REFERENCE batch calls: quantised descriptors and start states of the timeline being worked through, kept
+    // between calls (a fresh 1.5 MB per call is four hundred page faults on the thread everything else waits for)
+    std::vector<gpsiq_qchan_t> ref_q;
+    std::vector<double>        ref_start;
 };
 
 #define HIP_TRY(expr)                                                                        \
@@ -713,7 +717,9 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     const double t0 = trace ? wall_ms() : 0.0;
     double t_wait = 0.0, t_queue = 0.0;
     size_t npatch = 0;
-    std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+    std::vector<gpsiq_qchan_t> &q = c->ref_q;                // every element is written by its evaluation task before it is read
+    if (q.size() < (size_t) nblocks * (size_t) nchan) q.resize((size_t) nblocks * (size_t) nchan);
+    if (!seeds && c->ref_start.size() < (size_t) nblocks * (size_t) nchan) c->ref_start.resize((size_t) nblocks * (size_t) nchan);
     std::vector<gpsiq_patch_t> patches;
     RefRender r;
     int rc = r.begin(c, nblocks, nchan, nsamp, sample_size, dst, dst_is_device);
@@ -723,6 +729,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     piece_ends(0, nblocks, chunk, &ends);
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
+    if (!seeds) w.start_out = c->ref_start.data();
     // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
     // thread, and this thread renders every piece as soon as all channels are through it
     pthread_t th;

@@ -1214,6 +1214,8 @@ void RefWalk::chain_task(int i, size_t k)
     int pv = prev[i];
     for (int b = b0; b < b1; ++b) {
         const size_t at = (size_t) b * nchan + i;
+        // a channel's descriptors lie nchan * 296 bytes apart: every block is a cache miss unless it is asked for early
+        if (b + 6 < b1) { if (in) __builtin_prefetch(&in[at + (size_t) 6 * nchan]); else __builtin_prefetch(&ch[at + (size_t) 6 * nchan]); }
         const double f_carr = in ? in[at].f_carr : ch[at].f_carr, phase0 = in ? in[at].carr_phase : ch[at].carr_phase;
         const int prn = in ? in[at].prn : ch[at].prn;
         if (prn <= 0) { pv = 0; c = 0.0; start_out[at] = 0.0; continue; }
@@ -1241,6 +1243,10 @@ void RefWalk::eval_task(int i, size_t k, CodeCache *codes)
     std::vector<gpsiq_patch_t> *mine = &patches[(size_t) i * ends.size() + k];
     for (int b = b0; b < b1; ++b) {
         const size_t at = (size_t) b * nchan + i;
+        if (b + 3 < b1) {                                        // the next descriptors of this channel (five cache lines each, all misses)
+            const char *nx = reinterpret_cast<const char *>(&ch[at + (size_t) 3 * nchan]);
+            __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128); __builtin_prefetch(nx + 192); __builtin_prefetch(nx + 256);
+        }
         const gpsiq_chan_t &d = ch[at];
         if (d.prn <= 0 || abort_flag.load(std::memory_order_acquire)) {
             gpsiq_chan_t none = d;
