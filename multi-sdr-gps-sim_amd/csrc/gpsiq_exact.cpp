@@ -535,18 +535,17 @@ struct NcoWalk {
         GPSIQ_NOTE(x, ran);
     }
 
-    // positive addend: climb<true> for eight post-wrap states m (units of 2^-52)
-    GPSIQ_AVX512 void walk8_up(int64_t m_max, Batch *io) const
+#define GPSIQ_VCONSTS(UEXP)                                                                                               \
+    const __m512i zero = _mm512_setzero_si512(), two = _mm512_set1_epi64(2), sixty2 = _mm512_set1_epi64(62);              \
+    const __m512i mant = _mm512_set1_epi64((int64_t) kMant), one52 = _mm512_set1_epi64((int64_t) 1 << 52), one53 = _mm512_set1_epi64((int64_t) 1 << 53); \
+    const __m512i uexp_v = _mm512_set1_epi64(UEXP);                                                                       \
+    const __m512d cv = _mm512_set1_pd(c), thr_v = _mm512_set1_pd(thr), one = _mm512_set1_pd(1.0);                         \
+    (void) zero; (void) two; (void) sixty2; (void) mant; (void) one52; (void) one53; (void) uexp_v; (void) cv; (void) thr_v; (void) one
+
+    // positive addend, the binades below the table: plain additions (at most 2^(kLow + 1) + 1 of them)
+    GPSIQ_AVX512 inline void batch_low_up(__m512d &x, __m512i &n, __m512i &lo, __m512i &hi, __mmask8 &okm) const
     {
-        const __m512i zero = _mm512_setzero_si512(), two = _mm512_set1_epi64(2), sixty2 = _mm512_set1_epi64(62);
-        const __m512i mant = _mm512_set1_epi64((int64_t) kMant), one52 = _mm512_set1_epi64((int64_t) 1 << 52), one53 = _mm512_set1_epi64((int64_t) 1 << 53);
-        const __m512i uexp_v = _mm512_set1_epi64(1023);
-        const __m512d cv = _mm512_set1_pd(c), thr_v = _mm512_set1_pd(thr), one = _mm512_set1_pd(1.0);
-        const __m512i m = _mm512_loadu_si512(io->m);
-        __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(m), _mm512_set1_pd(0x1p-52));
-        __m512i n = zero, lo = _mm512_sub_epi64(zero, m), hi = _mm512_sub_epi64(_mm512_set1_epi64(m_max), m);
-        __mmask8 okm = 0xff;
-        // the binades below the table: plain additions (at most 2^(kLow + 1) + 1 of them)
+        GPSIQ_VCONSTS(1023);
         for (int it = 0; it < (2 << kLow) + 2; ++it) {
             const __mmask8 act = _mm512_cmp_pd_mask(x, thr_v, _CMP_LT_OQ);
             if (!act) break;
@@ -555,45 +554,42 @@ struct NcoWalk {
             GPSIQ_NOTE(x, act);
         }
         okm &= (__mmask8) ~_mm512_cmp_pd_mask(x, thr_v, _CMP_LT_OQ);
-        const int top = (int) (top_exp - ec);
-        for (int s = kLow + 1; s <= top; ++s) {
-            batch_level<false>(s, x, n, lo, hi, okm, uexp_v);
-            const __m512d y = _mm512_add_pd(x, cv);                        // leaves the binade; at the top: wraps
-            n = _mm512_add_epi64(n, _mm512_set1_epi64(1));
-            if (s < top) { x = y; GPSIQ_NOTE(x, (__mmask8) 0xff); continue; }
-            okm &= _mm512_cmp_pd_mask(y, one, _CMP_GE_OQ);
-            GPSIQ_NOTE(y, (__mmask8) 0xff);
-            const __m512d bb = _mm512_sub_pd(y, x);
-            const __m512d err = _mm512_add_pd(_mm512_sub_pd(x, _mm512_sub_pd(y, bb)), _mm512_sub_pd(cv, bb));    // the rounding error of x + c, exactly
-            okm &= (__mmask8) ~_mm512_cmp_pd_mask(_mm512_abs_pd(err), _mm512_set1_pd(0x1p-53), _CMP_EQ_OQ);      // a tie on the grid the wrap is taken on
-            x = _mm512_sub_pd(y, one);
-        }
-        okm &= _mm512_cmp_pd_mask(x, one, _CMP_LT_OQ);
-        const __m512i m2 = _mm512_cvttpd_epi64(_mm512_mul_pd(x, _mm512_set1_pd(0x1p52)));
-        _mm512_storeu_si512(io->lo, lo); _mm512_storeu_si512(io->hi, hi); _mm512_storeu_si512(io->m2, m2); _mm512_storeu_si512(io->steps, n);
-        for (int q = 0; q < 8; ++q) io->ok[q] = (okm >> q) & 1;
     }
 
-    // negative addend: descend<true> for eight post-wrap states m (units of 2^-53)
-    GPSIQ_AVX512 void walk8_down(int64_t m_max, Batch *io) const
+    // positive addend, table binade ec + s: the run and the addition that leaves it.  true: that was the wrap (s == top), x is
+    // the state after it
+    GPSIQ_AVX512 inline bool batch_level_up(int s, int top, __m512d &x, __m512i &n, __m512i &lo, __m512i &hi, __mmask8 &okm) const
     {
-        const __m512i zero = _mm512_setzero_si512(), two = _mm512_set1_epi64(2), sixty2 = _mm512_set1_epi64(62);
-        const __m512i mant = _mm512_set1_epi64((int64_t) kMant), one52 = _mm512_set1_epi64((int64_t) 1 << 52), one53 = _mm512_set1_epi64((int64_t) 1 << 53);
-        const __m512i uexp_v = _mm512_set1_epi64(1022);
-        const __m512d cv = _mm512_set1_pd(c), thr_v = _mm512_set1_pd(thr), one = _mm512_set1_pd(1.0), zd = _mm512_setzero_pd();
-        const __m512i m = _mm512_loadu_si512(io->m);
-        __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(m), _mm512_set1_pd(0x1p-53));
-        __m512i n = zero, lo = _mm512_sub_epi64(zero, m), hi = _mm512_sub_epi64(_mm512_set1_epi64(m_max), m);
-        __mmask8 okm = (__mmask8) (0xff & _mm512_cmp_pd_mask(x, one, _CMP_LT_OQ));        // a state of exactly 1.0: scalar code
-        const int top = (int) (top_exp - ec);
-        for (int s = top; s > kLow; --s) {
-            batch_level<true>(s, x, n, lo, hi, okm, uexp_v);
-            x = _mm512_add_pd(x, cv);                                      // into the binade underneath
-            n = _mm512_add_epi64(n, _mm512_set1_epi64(1));
-            GPSIQ_NOTE(x, (__mmask8) 0xff);
-        }
+        GPSIQ_VCONSTS(1023);
+        batch_level<false>(s, x, n, lo, hi, okm, uexp_v);
+        const __m512d y = _mm512_add_pd(x, cv);                        // leaves the binade; at the top: wraps
+        n = _mm512_add_epi64(n, _mm512_set1_epi64(1));
+        if (s < top) { x = y; GPSIQ_NOTE(x, (__mmask8) 0xff); return false; }
+        okm &= _mm512_cmp_pd_mask(y, one, _CMP_GE_OQ);
+        GPSIQ_NOTE(y, (__mmask8) 0xff);
+        const __m512d bb = _mm512_sub_pd(y, x);
+        const __m512d err = _mm512_add_pd(_mm512_sub_pd(x, _mm512_sub_pd(y, bb)), _mm512_sub_pd(cv, bb));    // the rounding error of x + c, exactly
+        okm &= (__mmask8) ~_mm512_cmp_pd_mask(_mm512_abs_pd(err), _mm512_set1_pd(0x1p-53), _CMP_EQ_OQ);      // a tie on the grid the wrap is taken on
+        x = _mm512_sub_pd(y, one);
+        return true;
+    }
+
+    // negative addend, table binade ec + s: the run and the addition into the binade underneath
+    GPSIQ_AVX512 inline void batch_level_down(int s, __m512d &x, __m512i &n, __m512i &lo, __m512i &hi, __mmask8 &okm) const
+    {
+        GPSIQ_VCONSTS(1022);
+        batch_level<true>(s, x, n, lo, hi, okm, uexp_v);
+        x = _mm512_add_pd(x, cv);
+        n = _mm512_add_epi64(n, _mm512_set1_epi64(1));
+        GPSIQ_NOTE(x, (__mmask8) 0xff);
+    }
+
+    // negative addend, below the table: plain additions until the sum turns negative, then + 1.0; x: the state after the wrap
+    GPSIQ_AVX512 inline void batch_tail_down(__m512d &x, __m512i &n, __m512i &lo, __m512i &hi, __mmask8 &okm) const
+    {
+        GPSIQ_VCONSTS(1022);
+        const __m512d zd = _mm512_setzero_pd();
         okm &= _mm512_cmp_pd_mask(x, thr_v, _CMP_LT_OQ);
-        // below the table: plain additions until the sum turns negative, then + 1.0
         const __m512d c2 = _mm512_mul_pd(cv, _mm512_set1_pd(-2.0));
         __mmask8 open = 0xff;
         __m512d r_end = zd;
@@ -627,7 +623,37 @@ struct NcoWalk {
             }
         }
         okm &= (__mmask8) ~open;
-        const __m512i m2 = _mm512_cvttpd_epi64(_mm512_mul_pd(r_end, _mm512_set1_pd(0x1p53)));
+        x = r_end;
+    }
+
+    // positive addend: climb<true> for eight post-wrap states m (units of 2^-52)
+    GPSIQ_AVX512 void walk8_up(int64_t m_max, Batch *io) const
+    {
+        const __m512i m = _mm512_loadu_si512(io->m);
+        __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(m), _mm512_set1_pd(0x1p-52));
+        __m512i n = _mm512_setzero_si512(), lo = _mm512_sub_epi64(_mm512_setzero_si512(), m), hi = _mm512_sub_epi64(_mm512_set1_epi64(m_max), m);
+        __mmask8 okm = 0xff;
+        batch_low_up(x, n, lo, hi, okm);
+        const int top = (int) (top_exp - ec);
+        for (int s = kLow + 1; s <= top; ++s)
+            if (batch_level_up(s, top, x, n, lo, hi, okm)) break;
+        okm &= _mm512_cmp_pd_mask(x, _mm512_set1_pd(1.0), _CMP_LT_OQ);
+        const __m512i m2 = _mm512_cvttpd_epi64(_mm512_mul_pd(x, _mm512_set1_pd(0x1p52)));
+        _mm512_storeu_si512(io->lo, lo); _mm512_storeu_si512(io->hi, hi); _mm512_storeu_si512(io->m2, m2); _mm512_storeu_si512(io->steps, n);
+        for (int q = 0; q < 8; ++q) io->ok[q] = (okm >> q) & 1;
+    }
+
+    // negative addend: descend<true> for eight post-wrap states m (units of 2^-53)
+    GPSIQ_AVX512 void walk8_down(int64_t m_max, Batch *io) const
+    {
+        const __m512i m = _mm512_loadu_si512(io->m);
+        __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(m), _mm512_set1_pd(0x1p-53));
+        __m512i n = _mm512_setzero_si512(), lo = _mm512_sub_epi64(_mm512_setzero_si512(), m), hi = _mm512_sub_epi64(_mm512_set1_epi64(m_max), m);
+        __mmask8 okm = (__mmask8) (0xff & _mm512_cmp_pd_mask(x, _mm512_set1_pd(1.0), _CMP_LT_OQ));        // a state of exactly 1.0: scalar code
+        const int top = (int) (top_exp - ec);
+        for (int s = top; s > kLow; --s) batch_level_down(s, x, n, lo, hi, okm);
+        batch_tail_down(x, n, lo, hi, okm);
+        const __m512i m2 = _mm512_cvttpd_epi64(_mm512_mul_pd(x, _mm512_set1_pd(0x1p53)));
         _mm512_storeu_si512(io->lo, lo); _mm512_storeu_si512(io->hi, hi); _mm512_storeu_si512(io->m2, m2); _mm512_storeu_si512(io->steps, n);
         for (int q = 0; q < 8; ++q) io->ok[q] = (okm >> q) & 1;
     }
@@ -640,6 +666,7 @@ struct NcoWalk {
         for (; k <= k1; ++k) { inc[k] = vinc; tag[k] = vtag; }
     }
 #undef GPSIQ_NOTE
+#undef GPSIQ_VCONSTS
 #endif   // __x86_64__
 
     // the state at sample `target` (>= n) of a walk that is at sample n in state x; counts the wraps on the way
