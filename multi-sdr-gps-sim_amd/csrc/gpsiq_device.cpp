@@ -682,17 +682,30 @@ struct RefRender {
 };
 
 // piece boundaries of a range of `n` blocks starting at block `first` of the walk, `chunk` blocks each
-// Piece sizes: half a chunk, a chunk, then two chunks each, and a chunk and half a chunk again at the end.  Nothing renders
-// before the first piece is through all channels, and when the host is the slower side the last piece's kernel is all that
-// is left after the host has finished: both want a small piece.  In between a launch of twice the samples runs closer to the
-// rate of one big launch (a 26-block piece at 25 Msps is one round of workgroups over the chip: 215 us measured against
-// 183 us for its share of a whole-timeline launch).  GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
-static void piece_ends(int first, int n, int chunk, std::vector<int> *ends)
+// Piece sizes.  Nothing renders before the first piece is through all channels: half a chunk.  After that it depends on which
+// side is the slower one.  HOST-bound (the rule at 2.6 - 10 Msps): a chunk, then two chunks each, and a chunk and half a chunk
+// again at the end -- the last piece's kernel is all that is left after the host has finished.  KERNEL-bound (25 Msps: a block
+// is 6.7 us of device work against ~3 us of host work per thread): every launch costs ~30 us beyond its share of one big
+// launch (a 26-block piece is a single round of workgroups: 215 us measured against 183 us), so as few pieces as the host can
+// keep ahead of -- each 2.2 x the one before (the host has piece k+1 ready before the kernel of piece k ends), no small tail.
+// GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
+static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool kernel_bound = false)
 {
     static const bool ramp = [] { const char *e = std::getenv("GPSIQ_REF_CHUNK_RAMP"); return !e || std::atoi(e) != 0; }();
     const int half = chunk > 1 ? chunk / 2 : 1;
     if (!ramp || n <= 4 * chunk) {
         for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
+        ends->push_back(first + n);
+        return;
+    }
+    if (kernel_bound) {
+        int b = 0, size = half;
+        while (n - b > size + half) {                // what is left after this piece is worth a piece of its own
+            b += size;
+            ends->push_back(first + b);
+            size = (size * 11 + 4) / 5;
+            if (size > 16 * chunk) size = 16 * chunk;
+        }
         ends->push_back(first + n);
         return;
     }
@@ -705,6 +718,15 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends)
     if (tail0 > b) ends->push_back(first + tail0);
     ends->push_back(first + n - half);
     ends->push_back(first + n);
+}
+
+// Which side a GPSIQ_NCO_REFERENCE batch is bound by, from the rates measured on MI355X + EPYC 9575F: the
+// kernel at 6.0e12 channel-samples/s, the host at ~2.7 us per block and channel on each of its threads.
+static bool ref_kernel_bound(int nsamp, int nchan)
+{
+    const int threads = host_threads() < nchan ? host_threads() : nchan;
+    const double t_kernel = (double) nsamp * (double) nchan / 6.0e12, t_host = (double) nchan * 2.7e-6 / (double) (threads > 0 ? threads : 1);
+    return t_kernel > 1.3 * t_host;
 }
 
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
@@ -726,7 +748,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     if (rc) return rc;
     const int chunk = ref_chunk_blocks(nblocks, nsamp);
     std::vector<int> ends;
-    piece_ends(0, nblocks, chunk, &ends);
+    piece_ends(0, nblocks, chunk, &ends, ref_kernel_bound(nsamp, nchan));
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
     if (!seeds) w.start_out = c->ref_start.data();
@@ -928,7 +950,7 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         uint64_t seed[GPSIQ_MAX_CHAN];
         for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }
         std::vector<int> ends;
-        piece_ends(0, nblocks, piece / 2 > 0 ? piece / 2 : 1, &ends);
+        piece_ends(0, nblocks, piece / 8 > 0 ? piece / 8 : 1, &ends, true);       // the quantiser is a fraction of the kernel's time: kernel-bound
         int longest = 0;
         for (size_t k = 0; k < ends.size(); ++k) { const int nb = ends[k] - (k ? ends[k - 1] : 0); if (nb > longest) longest = nb; }
         std::vector<gpsiq_qchan_t> q((size_t) longest * (size_t) nchan);        // one piece's worth, reused (the set is staged out of it at once)
@@ -1054,7 +1076,7 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
             (void) gpsiq_shard_range(nblocks, i, ndev, &r0, &r1);
             if (r1 == r0) continue;
             const size_t before = ends.size();
-            piece_ends(r0, r1 - r0, ref_chunk_blocks(r1 - r0, nsamp), &ends);
+            piece_ends(r0, r1 - r0, ref_chunk_blocks(r1 - r0, nsamp), &ends, ref_kernel_bound(nsamp, nchan));
             owner.insert(owner.end(), ends.size() - before, i);
         }
         RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
