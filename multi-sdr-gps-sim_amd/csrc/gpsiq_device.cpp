@@ -720,13 +720,17 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool
     ends->push_back(first + n);
 }
 
-// Which side a GPSIQ_NCO_REFERENCE batch is bound by, from the rates measured on MI355X + EPYC 9575F: the
-// kernel at 6.0e12 channel-samples/s, the host at ~2.7 us per block and channel on each of its threads.
+// Whether a GPSIQ_NCO_REFERENCE batch is clearly kernel-bound, from the rates measured on MI355X + EPYC 9575F (DESIGN.md section
+// 2): the kernel at 6.0e12 channel-samples/s, the host at 2.5 us + 0.8 us per 10^6 samples per block and channel on each of its
+// threads (2.7 us at 2.6 Msps, 4.5 us at 25 Msps, in the call).  At 25 Msps on sixteen threads the two sides are within 1.5 x of
+// each other and the symmetric ramp measured better (1.77 against 1.91 ms per 200 blocks): only a clear case takes the few
+// growing pieces.
 static bool ref_kernel_bound(int nsamp, int nchan)
 {
     const int threads = host_threads() < nchan ? host_threads() : nchan;
-    const double t_kernel = (double) nsamp * (double) nchan / 6.0e12, t_host = (double) nchan * 2.7e-6 / (double) (threads > 0 ? threads : 1);
-    return t_kernel > 1.3 * t_host;
+    const double t_kernel = (double) nsamp * (double) nchan / 6.0e12;
+    const double t_host = (double) nchan * (2.5e-6 + 0.8e-12 * (double) nsamp) / (double) (threads > 0 ? threads : 1);
+    return t_kernel > 2.0 * t_host;
 }
 
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
@@ -950,7 +954,9 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         uint64_t seed[GPSIQ_MAX_CHAN];
         for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }
         std::vector<int> ends;
-        piece_ends(0, nblocks, piece / 8 > 0 ? piece / 8 : 1, &ends, true);       // the quantiser is a fraction of the kernel's time: kernel-bound
+        // the quantiser is a fraction of the kernel's time (kernel-bound), but a piece costs the host ~0.1 ms whatever its size:
+        // the first piece is a quarter of the nominal one (256 blocks at 2.6 Msps: 0.18 ms of kernel to prepare the next under)
+        piece_ends(0, nblocks, piece / 2 > 0 ? piece / 2 : 1, &ends, true);
         int longest = 0;
         for (size_t k = 0; k < ends.size(); ++k) { const int nb = ends[k] - (k ? ends[k - 1] : 0); if (nb > longest) longest = nb; }
         std::vector<gpsiq_qchan_t> q((size_t) longest * (size_t) nchan);        // one piece's worth, reused (the set is staged out of it at once)
