@@ -21,11 +21,14 @@
 //     values < 1024), the fixed-point path is within (n/2 + 1) units of its last place of real arithmetic.
 //     Those candidates are the n with (a + n*b) mod 2^k inside a narrow window: found with a
 //     Euclid-style descent in O(log) per hit (first_in_window), typically none or one per channel and block.
-//   * At every candidate both paths are evaluated exactly; where (LUT index, sign) differ, a patch
-//     {block, sample, slot, index, sign} is emitted.  The device runs the fixed-point kernels unchanged
-//     and then recomputes the patched samples (apply_patches in gpsiq_kernels.hip).
-// The carrier chain is serial per channel (block k starts where the double accumulator left block k-1);
-// channels run on host threads, and everything but the carrier walk is parallel over blocks.
+//   * At every candidate the double path's LUT index / chip is decided from the block's START state by a rigorous enclosure of
+//     the accumulated rounding (Drift: 99.5+ % of the candidates), else by walking the accumulator (NcoWalk); where (LUT index,
+//     sign) differ from the closed form a patch {block, sample, slot, index, sign} is emitted.  The device runs the fixed-point
+//     kernels unchanged and then recomputes the patched samples (apply_patches in gpsiq_kernels.hip).
+// Only the carrier chain is serial (block k of a channel starts where the double accumulator left block k-1): NcoWalk walks it
+// from wrap to wrap through a per-block table of its dozen distinct cycles (built eight cycles at a time where the host has
+// AVX-512), and RefWalk runs chains and evaluations as tasks on the shared thread pool, piece by piece, so that devices render
+// behind them; gpsiq_reference_chain / gpsiq_reference_seeded export the two halves for sharding over processes.
 #include "gpsiq_internal.h"
 
 #include <algorithm>
