@@ -287,3 +287,31 @@ def test_table_built_from_the_previous_blocks_layout(oracle, fs):
         x = np.array([oracle.carrier_chain(x[i], d["f_carr"][b, i] * (1.0 / fs), ns) for i in range(nc)])
         if got is not None:
             assert got.tobytes() == x.tobytes(), b
+
+
+def test_chain_and_seeded_edge_cases():
+    """gpsiq_reference_chain / gpsiq_reference_seeded: empty timelines, error reporting (a start phase outside [0, 1], a NaN
+    Doppler names its block), and a chain continued from the state another call published (carr_in / prn_in) goes on exactly."""
+    from gpsiq.abi import CHAIN_IN_DTYPE, CHAN_DTYPE
+    st, e, last = gpsiq.reference_chain(np.zeros((0, 5), dtype=CHAIN_IN_DTYPE), 2.6e6, 260000)
+    assert st.shape == (0, 5) and not e.any() and not last.any()
+    q, p = gpsiq.reference_seeded(np.zeros((0, 5), dtype=CHAN_DTYPE), 2.6e6, 260000, np.zeros((0, 5)))
+    assert q.shape == (0, 5) and len(p) == 0
+    d = synth_blocks(3, 4, seed=1)
+    with pytest.raises(gpsiq.GpsiqError, match="start phase"):
+        gpsiq.reference_seeded(d, 2.6e6, 260000, np.full((3, 4), 1.5))
+    bad = d.copy()
+    bad["f_carr"][1, 2] = np.nan
+    for call in (lambda: gpsiq.reference_chain(gpsiq.chain_inputs(bad), 2.6e6, 260000), lambda: gpsiq.reference_blocks(bad, 2.6e6, 260000)):
+        with pytest.raises(gpsiq.GpsiqError, match="block 1"):
+            call()
+    d = synth_blocks(9, 4, seed=2)
+    d["prn"][6:, 1] = 23                                      # re-allocated in the second half
+    cin = gpsiq.chain_inputs(d)
+    s_all, e_all, l_all = gpsiq.reference_chain(cin, 10e6, 1000000)
+    s1, e1, l1 = gpsiq.reference_chain(cin[:4], 10e6, 1000000)
+    s2, e2, l2 = gpsiq.reference_chain(cin[4:], 10e6, 1000000, carr_in=e1, prn_in=l1)
+    assert np.array_equal(np.vstack([s1, s2]), s_all) and np.array_equal(e2, e_all) and np.array_equal(l2, l_all)
+    # columns are independent: a subset of the channels gives those channels' columns
+    s_sub, e_sub, _ = gpsiq.reference_chain(np.ascontiguousarray(cin[:, 1:3]), 10e6, 1000000)
+    assert np.array_equal(s_sub, s_all[:, 1:3]) and np.array_equal(e_sub, e_all[1:3])
