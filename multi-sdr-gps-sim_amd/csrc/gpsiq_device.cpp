@@ -739,7 +739,8 @@ static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullpt
 static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
                               int sample_size, void *dst, int dst_is_device, double *carr_phase_out, const double *seeds = nullptr)
 {
-    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    const char *trace_env = std::getenv("GPSIQ_TRACE");
+    const bool trace = trace_env != nullptr, trace_pieces = trace && std::atoi(trace_env) >= 2;      // GPSIQ_TRACE=2: every piece
     const double t0 = trace ? wall_ms() : 0.0;
     double t_wait = 0.0, t_queue = 0.0;
     size_t npatch = 0;
@@ -770,7 +771,13 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         npatch += patches.size();
         const int b0 = k ? w.ends[k - 1] : 0;
         rc = r.piece(q.data() + (size_t) b0 * nchan, b0, w.ends[k] - b0, patches);
-        if (trace) { t_wait += tp - tw; t_queue += wall_ms() - tp; }
+        if (trace) {
+            const double tq = wall_ms();
+            t_wait += tp - tw; t_queue += tq - tp;
+            if (trace_pieces)
+                std::fprintf(stderr, "[gpsiq trace]   piece %zu, blocks [%d, %d): ready at %.3f ms, queued at %.3f ms, %zu patches\n",
+                             k, b0, w.ends[k], tp - t0, tq - t0, patches.size());
+        }
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) { std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); w.abort(); }     // nothing further is walked for a call that has failed
