@@ -1,7 +1,7 @@
 """BASELINE config 5 beyond the first GPU's share, against the reference's bytes: "8xMI355X time-sharded, 25 Msps int16, 16
-channels, 3600 s" is eight shares of 450 s; tests/golden/program_config35_static.npz holds the SHA-256 of every block of the
-FIRST TWO (oracle/_ref/gps-sim-ref-25M -d 900: 8 999 blocks of 2.5 * 10^6 samples, 90 GB, tests/golden/make_golden.py
---config35-only cfg5).  A later share starts from the carrier state the reference's own run reaches at its start: in
+channels, 3600 s" is eight shares of 450 s; tests/golden/program_config35_static.npz holds the SHA-256 of every block of ALL
+EIGHT (oracle/_ref/gps-sim-ref-25M -d 3600: 35 999 blocks of 2.5 * 10^6 samples, 360 GB, 5.4 CPU-hours of the reference;
+tests/golden/make_golden.py --config35-only cfg5).  Tests (a)-(c) use the first two shares (8 999 blocks), (d) all of them.  A later share starts from the carrier state the reference's own run reaches at its start: in
 GPSIQ_NCO_REFERENCE that is what the carrier chain gives (gpsiq_reference_chain: host only, serial per channel, ~1 us per
 block and channel), after which the share is evaluated and rendered with no reference to the blocks before it.
 
@@ -10,7 +10,8 @@ block and channel), after which the share is evaluated and rendered with no refe
       gpsiq_set_descriptors / gpsiq_set_patches / gpsiq_launch for blocks 4 500 - 8 998 only == their digests;
   (c) the default fixed-point model: the second share, seeded with the exact carrier prefix, == the oracle on the blocks
       checked (it differs from the reference in a few elements per 10^7, tier T2 -- at 5 * 10^6 elements per block that is
-      every block of this share).
+      every block of this share);
+  (d) the whole hour: chain once, then each of the eight shares alone (gpsiq_generate_seeded) == the digests, all 35 999 blocks.
 The descriptors come from the library's own host chain (RINEX reader, allocation, nav words, batched refresh)."""
 import hashlib
 import os
