@@ -699,11 +699,13 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool
         return;
     }
     if (kernel_bound) {
+        int growth = 220;                                 // per cent; GPSIQ_PIECE_GROWTH (read per call) for A/B
+        if (const char *e = std::getenv("GPSIQ_PIECE_GROWTH")) { const int g = std::atoi(e); if (g >= 100 && g <= 1000) growth = g; }
         int b = 0, size = half;
         while (n - b > size + half) {                // what is left after this piece is worth a piece of its own
             b += size;
             ends->push_back(first + b);
-            size = (size * 11 + 4) / 5;
+            size = (int) (((long) size * growth + 50) / 100);
             if (size > 16 * chunk) size = 16 * chunk;
         }
         ends->push_back(first + n);
@@ -940,7 +942,8 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     if (nblocks == 0) return GPSIQ_OK;                    // an empty batch leaves the carried phases alone
     if (c->nco_mode == GPSIQ_NCO_REFERENCE)
         return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out);
-    const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
+    const char *trace_env = std::getenv("GPSIQ_TRACE");
+    const bool trace = trace_env != nullptr, trace_pieces = trace && std::atoi(trace_env) >= 2;
     const double t0 = trace ? wall_ms() : 0.0;
     // continue a previous call exactly where the caller hands back what it was given
     bool cont0[GPSIQ_MAX_CHAN];
@@ -961,17 +964,27 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         uint64_t seed[GPSIQ_MAX_CHAN];
         for (int i = 0; i < nchan; ++i) { cont[i] = cont0[i]; seed[i] = c->carry[i]; }
         std::vector<int> ends;
-        // the quantiser is a fraction of the kernel's time (kernel-bound), but a piece costs the host ~0.1 ms whatever its size:
-        // the first piece is a quarter of the nominal one (256 blocks at 2.6 Msps: 0.18 ms of kernel to prepare the next under)
-        piece_ends(0, nblocks, piece / 2 > 0 ? piece / 2 : 1, &ends, true);
+        // the quantiser is a fraction of the kernel's time (kernel-bound), but nothing renders before the first piece is through
+        // it: the first piece is a sixteenth of the nominal one (64 blocks at 2.6 Msps: on the device 0.1 ms into the call), each
+        // later one 2.2 x the one before (GPSIQ_TRACE=2 prints the timeline)
+        piece_ends(0, nblocks, piece / 8 > 0 ? piece / 8 : 1, &ends, true);
         int longest = 0;
         for (size_t k = 0; k < ends.size(); ++k) { const int nb = ends[k] - (k ? ends[k - 1] : 0); if (nb > longest) longest = nb; }
-        std::vector<gpsiq_qchan_t> q((size_t) longest * (size_t) nchan);        // one piece's worth, reused (the set is staged out of it at once)
+        // one piece's worth, the context's own (the set is staged out of it at once; a fresh 7 MB vector per call was 0.25 ms of
+        // zero-filling before the first descriptor was looked at); every element is written by the quantiser
+        std::vector<gpsiq_qchan_t> &q = c->ref_q;
+        if (q.size() < (size_t) longest * (size_t) nchan) q.resize((size_t) longest * (size_t) nchan);
         for (size_t k = 0; k < ends.size() && rc == GPSIQ_OK; ++k) {
             const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+            const double tq0 = trace_pieces ? wall_ms() : 0.0;
             rc = quantize_timeline(ch + (size_t) b0 * nchan, nb, nchan, 1.0 / fs, nsamp, cont, seed, q.data(), carry, prev_prn);
+            const double tq1 = trace_pieces ? wall_ms() : 0.0;
             if (rc == GPSIQ_OK) rc = set_descriptors_impl(c, q.data(), nb, nchan, nullptr, 0, true);
+            const double tq2 = trace_pieces ? wall_ms() : 0.0;
             if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, c->stream, kAuto);
+            if (trace_pieces)
+                std::fprintf(stderr, "[gpsiq trace]   piece %zu, blocks [%d, %d): quantise from %.3f to %.3f ms, descriptors queued at %.3f, launched at %.3f\n",
+                             k, b0, b0 + nb, tq0 - t0, tq1 - t0, tq2 - t0, wall_ms() - t0);
             for (int i = 0; i < nchan; ++i) {
                 // the next piece continues a slot while it keeps its PRN and re-seeds it otherwise, as inside one timeline
                 const gpsiq_chan_t *next = b0 + nb < nblocks ? &ch[(size_t) (b0 + nb) * nchan + i] : nullptr;
@@ -986,7 +999,8 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         if (src != GPSIQ_OK) return src;
         if (trace) std::fprintf(stderr, "[gpsiq trace] batch %d blocks in pieces of %d: whole call %.2f ms\n", nblocks, piece, wall_ms() - t0);
     } else {
-        std::vector<gpsiq_qchan_t> q((size_t) nblocks * (size_t) nchan);
+        std::vector<gpsiq_qchan_t> &q = c->ref_q;
+        if (q.size() < (size_t) nblocks * (size_t) nchan) q.resize((size_t) nblocks * (size_t) nchan);
         int qrc = quantize_timeline(ch, nblocks, nchan, 1.0 / fs, nsamp, cont0, c->carry, q.data(), carry, prev_prn);
         if (qrc) return qrc;
         const double t2 = trace ? wall_ms() : 0.0;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <pthread.h>
 #include <sched.h>
+#include <time.h>
 #include <unistd.h>
 #include <vector>
 
@@ -63,12 +64,12 @@ void *pool_worker(void *)
     for (;;) {
         while (!p.head) pthread_cond_wait(&p.go, &p.m);
         Job *j = p.head;
-        ++j->running;
+        __atomic_add_fetch(&j->running, 1, __ATOMIC_RELAXED);
         if (--j->tickets == 0) { p.head = j->next; if (!p.head) p.tail = nullptr; }
         pthread_mutex_unlock(&p.m);
         j->entry(j->ctx);
         pthread_mutex_lock(&p.m);
-        if (--j->running == 0 && j->tickets == 0) pthread_cond_broadcast(&p.done);
+        if (__atomic_sub_fetch(&j->running, 1, __ATOMIC_RELEASE) == 0 && j->tickets == 0) pthread_cond_broadcast(&p.done);
     }
     return nullptr;
 }
@@ -143,7 +144,10 @@ void run_job(void (*entry)(void *), void *ctx, int nthreads)
     if (job.tickets > 0) {
         if (p.tail) p.tail->next = &job; else p.head = &job;
         p.tail = &job;
-        if (job.tickets == 1) pthread_cond_signal(&p.go); else pthread_cond_broadcast(&p.go);
+        // one wake-up per helper wanted: a broadcast to fifteen sleepers for a job that wants two is ~60 us of futex calls on
+        // the submitting thread (GPSIQ_TRACE=2 inside gpsiq_generate_batch: a 141-block piece quantised in 0.12 ms instead of 0.03)
+        if (job.tickets >= p.nworkers) pthread_cond_broadcast(&p.go);
+        else for (int t = 0; t < job.tickets; ++t) pthread_cond_signal(&p.go);
     }
     pthread_mutex_unlock(&p.m);
     entry(ctx);
@@ -154,7 +158,18 @@ void run_job(void (*entry)(void *), void *ctx, int nthreads)
         while (*pp && *pp != &job) { prev = *pp; pp = &(*pp)->next; }
         if (*pp) { *pp = job.next; if (p.tail == &job) p.tail = prev; }
     }
-    while (job.running) pthread_cond_wait(&p.done, &p.m);
+    // helpers still inside entry() are microseconds from leaving it (the work is handed out in chunks and none is left): poll
+    // for them before sleeping -- a sleep here costs this thread a wake-up latency of its own
+    if (__atomic_load_n(&job.running, __ATOMIC_ACQUIRE)) {
+        pthread_mutex_unlock(&p.m);
+        for (int i = 0; i < 4000 && __atomic_load_n(&job.running, __ATOMIC_ACQUIRE); ++i) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        pthread_mutex_lock(&p.m);
+    }
+    while (__atomic_load_n(&job.running, __ATOMIC_ACQUIRE)) pthread_cond_wait(&p.done, &p.m);
     pthread_mutex_unlock(&p.m);
 }
 
