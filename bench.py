@@ -462,7 +462,7 @@ def main():
                 print(f"[bench] no gloo side group ({ex}); seed exchange of the streamed leg over RCCL", file=sys.stderr)
         best_s = None
         passes_s = []
-        for _ in range(2):
+        for _ in range(4):
             ra, hist = scen.runahead(), []
             gc.collect()                                   # as timeit does: a full collection takes 35 ms in this process and,
             gc.disable()                                   # left to itself, lands in the middle of the second pass
@@ -498,7 +498,7 @@ def main():
                            "x_realtime": None if dry else round(R * nb_e * world * 0.1 / best_s[0], 1),
                            "host_refresh_and_quantise_ms_per_round": round(best_s[1] / R * 1e3, 2), "seed_exchange": exchange,
                            "what": "the chain above over one continuous timeline in rounds, launches asynchronous: the host side of round "
-                                   "m+1 overlaps the kernel of round m (double-buffered descriptor sets); slowest rank, best of 2 passes"}
+                                   "m+1 overlaps the kernel of round m (double-buffered descriptor sets); slowest rank, best of 4 passes"}
         # what the rounds of a long run are bound by on the slowest rank (the serial batch above is host + kernel by construction)
         e2e["bound"] = e2e["streamed"]["bound"]
         ref_sharded = None
