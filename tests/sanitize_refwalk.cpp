@@ -109,6 +109,31 @@ int main()
         if (std::memcmp(qs.data(), q0.data(), qs.size() * sizeof(gpsiq_qchan_t)) != 0) { std::fprintf(stderr, "seeded: descriptors differ\n"); return 1; }
         if (all.size() != p0.size() || std::memcmp(all.data(), p0.data(), all.size() * sizeof(gpsiq_patch_t)) != 0) { std::fprintf(stderr, "seeded: patches differ: %zu vs %zu\n", all.size(), p0.size()); return 1; }
     }
+    // the pool itself: thousands of tiny jobs from two submitting threads at once (a job wakes only as many workers as it wants
+    // helpers and polls for the ones still inside before it sleeps; a job's record lives on its submitter's stack): every index
+    // of every job is visited exactly once
+    {
+        struct Sub { int jobs; long sum; bool ok; };
+        auto body = [](void *arg) -> void * {
+            Sub &s = *static_cast<Sub *>(arg);
+            std::vector<unsigned char> seen;
+            for (int j = 0; j < s.jobs; ++j) {
+                const int n = 1 + (j * 37) % 300, want = (j % 5) + 1, grain = 1 + j % 7;
+                seen.assign((size_t) n, 0);
+                gpsiq::parallel_for(n, want, grain, [](void *p, int b0, int b1) {
+                    unsigned char *v = static_cast<unsigned char *>(p);
+                    for (int b = b0; b < b1; ++b) __atomic_add_fetch(&v[b], 1, __ATOMIC_RELAXED);
+                }, seen.data());
+                for (int b = 0; b < n; ++b) { if (seen[(size_t) b] != 1) s.ok = false; s.sum += seen[(size_t) b]; }
+            }
+            return nullptr;
+        };
+        Sub a = {1500, 0, true}, b = {1500, 0, true};
+        pthread_t ta, tb;
+        if (pthread_create(&ta, nullptr, body, &a) != 0 || pthread_create(&tb, nullptr, body, &b) != 0) return 1;
+        pthread_join(ta, nullptr); pthread_join(tb, nullptr);
+        if (!a.ok || !b.ok || a.sum != b.sum || a.sum <= 0) { std::fprintf(stderr, "pool: an index was visited %s\n", a.ok && b.ok ? "a wrong number of times in total" : "not exactly once"); return 1; }
+    }
     if (p0.empty()) { std::fprintf(stderr, "the scenario should have patches\n"); return 1; }
     std::printf("ok\n");
     return 0;
