@@ -1501,11 +1501,13 @@ extern "C" int gpsiq_reference_seeded(const gpsiq_chan_t *ch, int nblocks, int n
 
 extern "C" void gpsiq_reference_stats(uint64_t out[4])
 {
+    if (!out) return;
     for (int k = 0; k < 4; ++k) out[k] = g_stats[k].load(std::memory_order_relaxed);
 }
 
 extern "C" void gpsiq_chain_inputs(const gpsiq_chan_t *ch, int n, gpsiq_chain_in_t *out)
 {
+    if (!ch || !out) return;
     for (int k = 0; k < n; ++k) { out[k].f_carr = ch[k].f_carr; out[k].carr_phase = ch[k].carr_phase; out[k].prn = ch[k].prn; out[k].reserved = 0; }
 }
 
