@@ -767,6 +767,19 @@ def extra_legs(ctx, ring, stream, args, first):
                      "value": round(nb_h * nsamp / dt / 1e6, 1), "unit": "Msamples/s", "pcie_GBps": round(nb_h * blk / dt / 1e9, 2),
                      "x_realtime": round(nb_h * 0.1 / dt, 1)}
     os.environ.pop("GPSIQ_D2H_CHUNK_BLOCKS", None)
+    # what "PCIe-bound" means on this box: the same bytes as ONE plain device-to-host copy into the same page-locked buffer
+    nbytes_h = nb_h * blk
+    raw = float("inf")
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pinned.copy_(ring[:nbytes_h], non_blocking=True)
+        torch.cuda.synchronize()
+        raw = min(raw, time.perf_counter() - t1)
+    ex["pcie_d2h_raw"] = {"what": f"one device-to-host copy of the same {nbytes_h} bytes into the same page-locked buffer (no kernel)",
+                          "GBps": round(nbytes_h / raw / 1e9, 2)}
+    for label in ("host_dst_batch", "host_dst_batch_unchunked"):
+        ex[label]["frac_of_raw_copy"] = round(ex[label]["pcie_GBps"] / ex["pcie_d2h_raw"]["GBps"], 3)
 
     for label, mode in (("block_call", NCO_FIXED), ("block_call_reference_nco", NCO_REFERENCE)):
         ctx.set_nco_mode(mode)
