@@ -214,7 +214,8 @@ u128 first_in_range(uint64_t A, uint64_t M, uint64_t L, uint64_t R, u128 bound)
     // the wraps that can matter, a little generously (a double quotient instead of a 128-bit division; the result is checked)
     const u128 ybound = (u128) ((double) (reach - L) / (double) M * (1.0 + 0x1p-40)) + 2;
     const uint64_t mr = M % A;
-    const u128 y = first_in_range(mr ? A - mr : 0, A, lr, R % A, ybound);
+    // no multiple of A lies in [L, R] here (k * A > R and lr != 0): L and R have the same quotient, so R mod A needs no division
+    const u128 y = first_in_range(mr ? A - mr : 0, A, lr, lr + (R - L), ybound);
     if (y == kNone) return kNone;
     const u128 x = ((u128) M * y + L + A - 1) / A;
     return x < bound ? x : kNone;
