@@ -232,6 +232,60 @@ int gpsiq_reference_chain(const gpsiq_chain_in_t *in, int nblocks, int nchan, do
 int gpsiq_reference_seeded(const gpsiq_chan_t *ch, int nblocks, int nchan, double fs, int nsamp, const double *carr_start,
                            gpsiq_qchan_t *out, gpsiq_patch_t *patches, int max_patches, int *npatches);
 
+/* The chain, parallel in time (csrc/gpsiq_lane.h has the method).  x += c in double is a TRANSLATION on a whole residue class
+ * of start states, so every block can be walked on its own from a representative start state near an estimate of the true
+ * one (exact real arithmetic + modelled rounding drift), which yields a certified map of the block
+ *     start xs + d*2^-53, lo <= d <= hi   ->   end e + (d + cum)*2^-53;
+ * the chain proper is then one exact subtraction, range check and addition per block (gpsiq_chain_link), with a true walk
+ * of the rare block whose map does not apply.  carr_start / carr_end / last_prn are gpsiq_reference_chain's, bit for bit.
+ *   gpsiq_chain_maps     level 1 of blocks [0, nblocks): every block independent of every other -- host threads here,
+ *                        gpsiq_chain_maps_device runs the same walk with one GPU lane per stretch of a block.  start[nchan]:
+ *                        the estimator state before block 0 (NULL: the timeline begins here, block 0 seeds every slot from its
+ *                        own carr_phase; a continued timeline passes the accumulator itself: GPSIQ_CHAIN_EXACT, carr, prn,
+ *                        f_carr of the block before).  max_stretches: pieces a block is cut into at most (<= 0: default).
+ *                        end[nchan] (may be NULL): the estimator state after the last block.
+ *   gpsiq_chain_link     level 2: the chain over these blocks from carr_in / prn_in (as gpsiq_reference_chain).
+ *   gpsiq_chain_summary  what a RANGE of blocks does to the estimator, for ranks that each hold their own blocks only:
+ *   gpsiq_chain_fold     first every rank summarises its range with start = NULL (the phase pass: exact phase advance, no
+ *                        drift) and all ranks gather the summaries; fold(summaries of the ranks before me) is where my range
+ *                        starts; summarising again from there adds the modelled drift (it needs the absolute phase), one more
+ *                        gather and fold give the start for gpsiq_chain_maps.  After the maps (the expensive part, fully
+ *                        parallel over ranks) the true states are relayed: rank r links its range from rank r-1's carr_end /
+ *                        last_prn (16 doubles per rank; gpsiq/shard.py::reference_chain_by_time). */
+typedef struct gpsiq_chain_est {
+    uint64_t r_hi, r_lo;  /* phase in 2^-128 cycle, exact real arithmetic (the wrap is the overflow) */
+    double   drift;       /* modelled rounding drift accumulated since the slot was seeded */
+    double   carr;        /* GPSIQ_CHAIN_EXACT: the accumulator itself.  In a summary with first_prn: block 0's carr_phase */
+    double   f_carr;      /* f_carr of the block before (the next block walks its tail) */
+    int32_t  prn;         /* satellite of the block before; 0: none (the next block seeds itself) */
+    int32_t  flags;       /* GPSIQ_CHAIN_* */
+    int32_t  first_prn;   /* summary of the phase pass: block 0's satellite where it was taken to continue the slot */
+    int32_t  reserved;
+} gpsiq_chain_est_t;
+#define GPSIQ_CHAIN_EXACT    1
+#define GPSIQ_CHAIN_RESEEDED 2   /* summary: the slot was (re-)seeded inside the range, the state is absolute */
+#define GPSIQ_CHAIN_EMPTY    4   /* summary of no blocks */
+typedef struct gpsiq_chain_map {
+    double  xs, e;        /* representative state at the block's first sample; state after the block */
+    int64_t cum, lo, hi;  /* units of 2^-53 */
+    int32_t ok, even;     /* ok 0: no map, the block is walked; even: d must be even (positive addend) */
+} gpsiq_chain_map_t;
+int gpsiq_chain_maps(const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
+                     const gpsiq_chain_est_t *start, int max_stretches, gpsiq_chain_map_t *maps, gpsiq_chain_est_t *end);
+int gpsiq_chain_link(const gpsiq_chain_in_t *in, const gpsiq_chain_map_t *maps, int nblocks, int nchan, double fs, int nsamp,
+                     const double *carr_in, const int32_t *prn_in, double *carr_start, double *carr_end, int32_t *last_prn);
+int gpsiq_chain_summary(const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
+                        const gpsiq_chain_est_t *start, gpsiq_chain_est_t *sum);
+int gpsiq_chain_fold(const gpsiq_chain_est_t *sums /* [nranges][nchan] */, int nranges, int nchan, gpsiq_chain_est_t *out);
+/* out[0] blocks linked through their map, out[1] blocks walked from their true start, since the process started */
+void gpsiq_chain_stats(uint64_t out[2]);
+/* gpsiq_chain_maps on the context's device: one lane per stretch of a block (max_stretches <= 0: 16), `in` and `maps` host
+ * memory; kernel_ms (may be NULL): device time of the two kernels.  Synchronous.  In GPSIQ_NCO_REFERENCE gpsiq_generate_batch
+ * walks the chain of a batch this way itself (48 blocks or more; GPSIQ_CHAIN=host keeps the serial walk on host threads). */
+int gpsiq_chain_maps_device(gpsiq_ctx_t *ctx, const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
+                            const gpsiq_chain_est_t *start, int max_stretches, gpsiq_chain_map_t *maps, gpsiq_chain_est_t *end,
+                            float *kernel_ms);
+
 /* Contiguous balanced split of a block timeline over `world` devices/processes:
  * rank r owns [*begin, *end); the first nblocks % world ranks own one block more. */
 int gpsiq_shard_range(int nblocks, int rank, int world, int *begin, int *end);

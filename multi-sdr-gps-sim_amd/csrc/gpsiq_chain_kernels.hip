@@ -1,0 +1,219 @@
+// gpsiq_chain_kernels.hip -- gfx950 kernels of the time-parallel carrier chain of GPSIQ_NCO_REFERENCE (csrc/gpsiq_lane.h has
+// the method, csrc/gpsiq_chain.cpp the host twin and level 2).  Reference lines: gps.c:2821-2826 (the accumulator),
+// gps.c:2208-2214 (re-seeding a slot).
+//
+//   chain_prepare   one workgroup per slot: two segmented scans down the timeline -- the exact phase R_b = x_0 + sum nsamp*c_j
+//                   (128-bit integers, the wrap is the overflow) and the modelled rounding drift -- give every block an
+//                   estimate of the accumulator at its first sample (Prep, 32 bytes per block and slot).
+//   chain_lanes     level 1.  One LANE per stretch of a block (up to kSeg stretches per block): the lane places the last wrap
+//                   before its stretch from the estimate, starts from a representative post-wrap state there and walks the
+//                   reference's double additions -- plain FP64 adds at the binade crossings and wraps, integer jumps over the
+//                   steady runs, exactly the host's walker (gpsiq_walk.h) -- noting how far its start may move.  A workgroup
+//                   holds 256 / kSeg consecutive blocks of ONE slot: their addends differ by parts per million, so the lanes of
+//                   a wave take the same binades in the same order and diverge only at the ends of runs.  The walkers'
+//                   per-binade tables (one 64-bit division per binade) are built once per block in LDS, the divisions spread
+//                   over the workgroup's threads; the stretches of a block are joined by its first lane.
+// No MFMA (no contraction), no LDS staging of anything big: 48 bytes out per block and slot; the kernel is latency-bound on
+// dependent FP64 / 64-bit integer VALU chains, which is why the work is cut into as many lanes as there are wraps to spare.
+#include <hip/hip_runtime.h>
+
+#include "gpsiq_internal.h"
+#include "gpsiq_lane.h"
+
+namespace gpsiq {
+
+using lane::Prep;
+using lane::Rec;
+using lane::Stretch;
+using lane::Walker;
+using lane::u128;
+
+constexpr int kPrepThreads = 256;
+constexpr int kLaneThreads = 256;
+
+struct ScanR { u128 v; int flag; };     // f(R) = flag ? v : R + v
+struct ScanD { double v; int flag; };
+
+// ---- prepare ---------------------------------------------------------------------------------------------------------
+// est layout as on the host: start[nchan] may be null (the timeline begins here).
+__global__ __launch_bounds__(kPrepThreads) void chain_prepare(const gpsiq_chain_in_t *__restrict__ in, int nblocks, int nchan, double delt, int nsamp,
+                                                              const gpsiq_chain_est_t *__restrict__ start, Prep *__restrict__ prep,
+                                                              double *__restrict__ c_before, gpsiq_chain_est_t *__restrict__ end)
+{
+    __shared__ ScanR sr[kPrepThreads];
+    __shared__ ScanD sd[kPrepThreads];
+    __shared__ int s_any_seed;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    // the estimator before block 0
+    u128 Rc = 0;
+    double Dc = 0.0, carr0 = 0.0, f_prev0 = 0.0;
+    int prn0 = 0;
+    bool exact0 = false;
+    if (start) {
+        const gpsiq_chain_est_t e = start[i];
+        Rc = ((u128) e.r_hi << 64) | e.r_lo; Dc = e.drift; carr0 = e.carr; f_prev0 = e.f_carr; prn0 = e.prn; exact0 = (e.flags & GPSIQ_CHAIN_EXACT) != 0;
+    }
+    if (tid == 0) { c_before[i] = prn0 > 0 ? f_prev0 * delt : 0.0; s_any_seed = 0; }
+    int last_prn = prn0;
+    double last_f = f_prev0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += kPrepThreads) {
+        const int b = base + tid;
+        const bool live = b < nblocks;
+        gpsiq_chain_in_t d = {0.0, 0.0, 0, 0};
+        int prev_prn = 0;
+        if (live) {
+            d = in[(size_t) b * nchan + i];
+            prev_prn = b > 0 ? in[(size_t) (b - 1) * nchan + i].prn : prn0;
+            if (prev_prn < 0) prev_prn = 0;
+        }
+        const bool active = live && d.prn > 0;
+        const bool cont = active && b == 0 && exact0 && prev_prn == d.prn;       // continues a walked timeline: the accumulator itself
+        const bool seed = active && (prev_prn != d.prn || cont);
+        const double c = active ? d.f_carr * delt : 0.0;
+        const double x_seed = cont ? carr0 : d.carr_phase;
+        const u128 adv = active ? lane::advance_units(c, nsamp) : (u128) 0;
+        // R after this block as a function of R before it
+        ScanR mine;
+        mine.flag = seed ? 1 : 0;
+        mine.v = seed ? lane::phase_units(x_seed) + adv : adv;
+        sr[tid] = mine;
+        __syncthreads();
+        for (int off = 1; off < kPrepThreads; off <<= 1) {
+            ScanR a = sr[tid], p;
+            const bool has = tid >= off;
+            if (has) p = sr[tid - off];
+            __syncthreads();
+            if (has && !a.flag) { a.v = p.v + a.v; a.flag = p.flag; sr[tid] = a; }
+            __syncthreads();
+        }
+        // R at this block's first sample
+        u128 R0;
+        if (seed) R0 = lane::phase_units(x_seed);
+        else if (tid == 0) R0 = Rc;
+        else { const ScanR p = sr[tid - 1]; R0 = p.flag ? p.v : Rc + p.v; }
+        const double r0 = lane::units_to_double(R0);
+        double core = 0.0;
+        if (active && __builtin_fabs(c) < 0.5) core = lane::drift_core(c, seed ? (x_seed < 1.0 ? x_seed : 0.0) : r0, nsamp);
+        ScanD md;
+        md.flag = seed ? 1 : 0;
+        md.v = core;
+        sd[tid] = md;
+        __syncthreads();
+        for (int off = 1; off < kPrepThreads; off <<= 1) {
+            ScanD a = sd[tid], p;
+            const bool has = tid >= off;
+            if (has) p = sd[tid - off];
+            __syncthreads();
+            if (has && !a.flag) { a.v = p.v + a.v; a.flag = p.flag; sd[tid] = a; }
+            __syncthreads();
+        }
+        double D0;
+        if (seed) D0 = 0.0;
+        else if (tid == 0) D0 = Dc;
+        else { const ScanD p = sd[tid - 1]; D0 = p.flag ? p.v : Dc + p.v; }
+        if (live) {
+            Prep p = {0.0, 0.0, 0.0, lane::kSkip, 0};
+            if (active) {
+                p.c = c;
+                p.est = seed ? x_seed : lane::wrap01(r0 + D0);
+                p.core = core;
+                p.flags = seed ? lane::kSeed : 0;
+            }
+            prep[(size_t) b * nchan + i] = p;
+        }
+        // the chunk's carry
+        const ScanR er = sr[kPrepThreads - 1];
+        const ScanD ed = sd[kPrepThreads - 1];
+        if (seed) atomicOr(&s_any_seed, 1);
+        const int n_here = nblocks - base < kPrepThreads ? nblocks - base : kPrepThreads;
+        __syncthreads();
+        Rc = er.flag ? er.v : Rc + er.v;
+        Dc = ed.flag ? ed.v : Dc + ed.v;
+        // the satellite and Doppler of the chunk's last block, for `end` (every thread reads them: two loads)
+        {
+            const gpsiq_chain_in_t l = in[(size_t) (base + n_here - 1) * nchan + i];
+            last_prn = l.prn > 0 ? l.prn : 0;
+            last_f = l.f_carr;
+        }
+        __syncthreads();
+    }
+    if (end && tid == 0) {
+        gpsiq_chain_est_t e;
+        e.r_hi = (uint64_t) (Rc >> 64); e.r_lo = (uint64_t) Rc; e.drift = Dc; e.carr = 0.0; e.f_carr = last_f; e.prn = last_prn;
+        e.flags = s_any_seed ? GPSIQ_CHAIN_RESEEDED : 0; e.first_prn = 0; e.reserved = 0;
+        end[i] = e;
+    }
+}
+
+// ---- lanes -----------------------------------------------------------------------------------------------------------
+template <int kSeg>
+__global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restrict__ prep, const double *__restrict__ c_before,
+                                                            int nblocks, int nchan, int nsamp, int max_seg, Rec *__restrict__ rec)
+{
+    constexpr int kBlocks = kLaneThreads / kSeg;               // blocks of one slot per workgroup
+    // walker[k]: the addend of block b0 - 1 + k (raw storage: a __shared__ object may not have initialisers; setup_head writes every scalar)
+    __shared__ __attribute__((aligned(16))) unsigned char walker_raw[sizeof(Walker) * (kBlocks + 1)];
+    Walker *walker = reinterpret_cast<Walker *>(walker_raw);
+    __shared__ Stretch stretch[kLaneThreads];
+    __shared__ int usable[kBlocks + 1];
+    const int groups = (nblocks + kBlocks - 1) / kBlocks;
+    const int i = blockIdx.x / groups, b0 = (blockIdx.x % groups) * kBlocks;
+    const int tid = threadIdx.x;
+    // the walkers' scalars: one thread per addend
+    if (tid <= kBlocks) {
+        const int b = b0 - 1 + tid;
+        double c = 0.0;
+        if (b < 0) c = c_before[i];
+        else if (b < nblocks) { const Prep p = prep[(size_t) b * nchan + i]; c = (p.flags & lane::kSkip) ? 0.0 : p.c; }
+        const bool ok = c != 0.0 && __builtin_fabs(c) < 0.5;
+        walker[tid].setup_head(ok ? c : 0.25, 1);              // an addend the walk does not take: general, never walked
+        usable[tid] = ok && !walker[tid].general;
+    }
+    __syncthreads();
+    // their tables: one (addend, binade) pair per thread and round -- a 64-bit division each
+    for (int q = tid; q < (kBlocks + 1) * lane::kTab; q += kLaneThreads) {
+        const int w = q / lane::kTab, s = q % lane::kTab;
+        if (usable[w] && s > Walker::kLow && s <= (int) (walker[w].top_exp - walker[w].ec)) walker[w].setup_piece(s);
+    }
+    __syncthreads();
+    const int blk = tid / kSeg, t = tid % kSeg, b = b0 + blk;
+    int nseg = 0;
+    if (b < nblocks && usable[blk + 1]) {
+        const Prep p = prep[(size_t) b * nchan + i];
+        nseg = lane::stretches(p.c, nsamp, max_seg < kSeg ? max_seg : kSeg);
+        if (t < nseg) {
+            const Walker *prev = (!(p.flags & lane::kSeed) && usable[blk]) ? &walker[blk] : nullptr;
+            Stretch st;
+            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, &st);
+            stretch[tid] = st;
+        }
+    }
+    __syncthreads();
+    if (b < nblocks && t == 0) {
+        Rec r;
+        r.xs = 0.0; r.e = 0.0; r.cum = 0; r.lo = 0; r.hi = 0; r.ok = 0; r.even = 0;
+        if (nseg > 0) lane::join_stretches(&stretch[blk * kSeg], nseg, walker[blk + 1].neg, &r);
+        rec[(size_t) b * nchan + i] = r;
+    }
+}
+
+hipError_t launch_chain(const gpsiq_chain_in_t *d_in, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
+                        int max_seg, void *d_prep_, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream)
+{
+    if (nblocks <= 0) return hipSuccess;
+    Prep *d_prep = static_cast<Prep *>(d_prep_);
+    Rec *d_rec = static_cast<Rec *>(d_maps);
+    hipLaunchKernelGGL(chain_prepare, dim3((unsigned) nchan), dim3(kPrepThreads), 0, stream, d_in, nblocks, nchan, delt, nsamp, d_start, d_prep, d_c_before, d_end);
+#define GPSIQ_LANES(S)                                                                                                    \
+    hipLaunchKernelGGL(chain_lanes<S>, dim3((unsigned) (nchan * ((nblocks + kLaneThreads / S - 1) / (kLaneThreads / S)))), dim3(kLaneThreads), 0, stream, \
+                       d_prep, d_c_before, nblocks, nchan, nsamp, max_seg, d_rec)
+    if (max_seg < 1) max_seg = 1;
+    if (max_seg > 8) GPSIQ_LANES(16);
+    else if (max_seg > 4) GPSIQ_LANES(8);
+    else GPSIQ_LANES(4);                                        // fewer stretches than lanes per block: the spare lanes idle
+#undef GPSIQ_LANES
+    return hipGetLastError();
+}
+
+}  // namespace gpsiq

@@ -22,6 +22,11 @@ size_t variant_scratch_bytes(int variant, int nsamp, int nblocks);
 hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size, void *dst, size_t block_stride,
                           int block0, int nblocks, const DeviceTables *tab, const gpsiq_patch_t *patches, int npatch,
                           hipStream_t stream);
+// the time-parallel carrier chain (gpsiq_chain_kernels.hip; the buffers are opaque here: 32-byte Prep, 48-byte maps)
+hipError_t launch_chain(const gpsiq_chain_in_t *d_in, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
+                        int max_seg, void *d_prep, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream);
+int chain_link(const gpsiq_chain_in_t *in, const void *maps, int nblocks, int nchan, double delt, int nsamp,
+               const double *carr_in, const int32_t *prn_in, double *carr_start, double *carr_end, int32_t *last_prn);
 }
 
 using namespace gpsiq;
@@ -91,6 +96,19 @@ struct gpsiq_ctx {
     // between calls (a fresh 1.5 MB per call is four hundred page faults on the thread everything else waits for)
     std::vector<gpsiq_qchan_t> ref_q;
     std::vector<double>        ref_start;
+    // the carrier chain of GPSIQ_NCO_REFERENCE on the device (gpsiq_chain_maps_device): inputs, estimates and maps of the
+    // timeline being worked through, device side and page-locked staging, kept between calls
+    struct Chain {
+        size_t             cap = 0;                    // blocks x channels all of these hold
+        gpsiq_chain_in_t  *d_in = nullptr, *h_in = nullptr;
+        void              *d_prep = nullptr;           // lane::Prep, 32 bytes each
+        gpsiq_chain_map_t *d_maps = nullptr, *h_maps = nullptr;
+        gpsiq_chain_est_t *d_est = nullptr, *h_est = nullptr;       // [2][GPSIQ_MAX_CHAN]: start, end
+        double            *d_c_before = nullptr;
+        hipStream_t        stream = nullptr;
+        hipEvent_t         t0 = nullptr, t1 = nullptr;
+        float              last_ms = 0.0f;             // device time of the last call's two kernels
+    } chain;
 };
 
 #define HIP_TRY(expr)                                                                        \
@@ -243,6 +261,17 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
         if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
         if (c->copy_stream[i]) (void) hipStreamDestroy(c->copy_stream[i]);
     }
+    if (c->chain.d_in) (void) hipFree(c->chain.d_in);
+    if (c->chain.h_in) (void) hipHostFree(c->chain.h_in);
+    if (c->chain.d_prep) (void) hipFree(c->chain.d_prep);
+    if (c->chain.d_maps) (void) hipFree(c->chain.d_maps);
+    if (c->chain.h_maps) (void) hipHostFree(c->chain.h_maps);
+    if (c->chain.d_est) (void) hipFree(c->chain.d_est);
+    if (c->chain.h_est) (void) hipHostFree(c->chain.h_est);
+    if (c->chain.d_c_before) (void) hipFree(c->chain.d_c_before);
+    if (c->chain.t0) (void) hipEventDestroy(c->chain.t0);
+    if (c->chain.t1) (void) hipEventDestroy(c->chain.t1);
+    if (c->chain.stream) (void) hipStreamDestroy(c->chain.stream);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->up_stream) (void) hipStreamDestroy(c->up_stream);
     delete c;
@@ -735,6 +764,115 @@ static bool ref_kernel_bound(int nsamp, int nchan)
     return t_kernel > 2.0 * t_host;
 }
 
+// ---- the carrier chain on the device -------------------------------------------------------------------------------
+static int chain_reserve(gpsiq_ctx *c, size_t n)
+{
+    gpsiq_ctx::Chain &k = c->chain;
+    if (!k.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&k.t0));
+        HIP_TRY(hipEventCreate(&k.t1));
+        HIP_TRY(hipMalloc((void **) &k.d_est, 2 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t)));
+        HIP_TRY(hipHostMalloc((void **) &k.h_est, 2 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &k.d_c_before, GPSIQ_MAX_CHAN * sizeof(double)));
+    }
+    if (n <= k.cap) return GPSIQ_OK;
+    if (k.d_in) (void) hipFree(k.d_in);
+    if (k.h_in) (void) hipHostFree(k.h_in);
+    if (k.d_prep) (void) hipFree(k.d_prep);
+    if (k.d_maps) (void) hipFree(k.d_maps);
+    if (k.h_maps) (void) hipHostFree(k.h_maps);
+    k.d_in = nullptr; k.h_in = nullptr; k.d_prep = nullptr; k.d_maps = nullptr; k.h_maps = nullptr; k.cap = 0;
+    const size_t cap = n + n / 4 + 256;
+    HIP_TRY(hipMalloc((void **) &k.d_in, cap * sizeof(gpsiq_chain_in_t)));
+    HIP_TRY(hipHostMalloc((void **) &k.h_in, cap * sizeof(gpsiq_chain_in_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&k.d_prep, cap * 32));
+    HIP_TRY(hipMalloc((void **) &k.d_maps, cap * sizeof(gpsiq_chain_map_t)));
+    HIP_TRY(hipHostMalloc((void **) &k.h_maps, cap * sizeof(gpsiq_chain_map_t), hipHostMallocDefault));
+    k.cap = cap;
+    return GPSIQ_OK;
+}
+
+// level 1 of the chain for the inputs staged in c->chain.h_in: upload, two kernels, the maps back in c->chain.h_maps
+static int chain_maps_staged(gpsiq_ctx *c, int nblocks, int nchan, double fs, int nsamp, const gpsiq_chain_est_t *start, int max_stretches,
+                             gpsiq_chain_est_t *end)
+{
+    gpsiq_ctx::Chain &k = c->chain;
+    const size_t n = (size_t) nblocks * (size_t) nchan;
+    if (max_stretches <= 0) {
+        max_stretches = 16;
+        if (const char *e = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) max_stretches = v; }
+    }
+    HIP_TRY(hipMemcpyAsync(k.d_in, k.h_in, n * sizeof(gpsiq_chain_in_t), hipMemcpyHostToDevice, k.stream));
+    if (start) {
+        std::memcpy(k.h_est, start, (size_t) nchan * sizeof(gpsiq_chain_est_t));
+        HIP_TRY(hipMemcpyAsync(k.d_est, k.h_est, (size_t) nchan * sizeof(gpsiq_chain_est_t), hipMemcpyHostToDevice, k.stream));
+    }
+    HIP_TRY(hipEventRecord(k.t0, k.stream));
+    HIP_TRY(launch_chain(k.d_in, nblocks, nchan, 1.0 / fs, nsamp, start ? k.d_est : nullptr, max_stretches, k.d_prep, k.d_c_before,
+                         k.d_est + GPSIQ_MAX_CHAN, k.d_maps, k.stream));
+    HIP_TRY(hipEventRecord(k.t1, k.stream));
+    HIP_TRY(hipMemcpyAsync(k.h_maps, k.d_maps, n * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(hipMemcpyAsync(k.h_est + GPSIQ_MAX_CHAN, k.d_est + GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(hipStreamSynchronize(k.stream));
+    (void) hipEventElapsedTime(&k.last_ms, k.t0, k.t1);
+    if (end) std::memcpy(end, k.h_est + GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t));
+    return GPSIQ_OK;
+}
+
+extern "C" int gpsiq_chain_maps_device(gpsiq_ctx_t *c, const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
+                                       const gpsiq_chain_est_t *start, int max_stretches, gpsiq_chain_map_t *maps, gpsiq_chain_est_t *end,
+                                       float *kernel_ms)
+{
+    if (!c || ((!in || !maps) && nblocks)) return fail(GPSIQ_E_ARG, "null argument");
+    if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN || nsamp < 0 || !(fs > 0.0)) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d / nsamp %d / fs %g", nblocks, nchan, nsamp, fs);
+    if (kernel_ms) *kernel_ms = 0.0f;
+    if (nblocks == 0) return GPSIQ_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t) nblocks * (size_t) nchan;
+    int rc = chain_reserve(c, n);
+    if (rc) return rc;
+    std::memcpy(c->chain.h_in, in, n * sizeof(gpsiq_chain_in_t));
+    rc = chain_maps_staged(c, nblocks, nchan, fs, nsamp, start, max_stretches, end);
+    if (rc) return rc;
+    std::memcpy(maps, c->chain.h_maps, n * sizeof(gpsiq_chain_map_t));
+    if (kernel_ms) *kernel_ms = c->chain.last_ms;
+    return GPSIQ_OK;
+}
+
+// The start state of every block of a batch (-> start[nblocks][nchan]) and the state after it: chain inputs cut out of the
+// descriptors on host threads, level 1 on the device, level 2 here.  Timelines too short to fill a launch stay with the host's
+// serial walk (RefWalk's chain tasks), as does everything when GPSIQ_CHAIN=host.
+static bool chain_on_device(int nblocks)
+{
+    const char *e = std::getenv("GPSIQ_CHAIN");               // read per call: A/B in one process
+    if (e && !std::strcmp(e, "host")) return false;
+    if (e && !std::strcmp(e, "device")) return nblocks > 0;
+    return nblocks >= 48;
+}
+
+static int chain_starts_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
+                               double *start, double *carr_end, int32_t *last_prn, double *t_ms /* [3] or null: inputs, level 1, level 2 */)
+{
+    const size_t n = (size_t) nblocks * (size_t) nchan;
+    const double t0 = t_ms ? wall_ms() : 0.0;
+    int rc = chain_reserve(c, n);
+    if (rc) return rc;
+    struct Job { const gpsiq_chan_t *ch; gpsiq_chain_in_t *out; } job = {ch, c->chain.h_in};
+    // 296-byte descriptors, 24 bytes wanted of each: memory-bound, so spread over the pool
+    parallel_for((int) n, 0, 2048, [](void *p, int k0, int k1) {
+        const Job &j = *static_cast<Job *>(p);
+        gpsiq_chain_inputs(j.ch + k0, k1 - k0, j.out + k0);
+    }, &job);
+    const double t1 = t_ms ? wall_ms() : 0.0;
+    rc = chain_maps_staged(c, nblocks, nchan, fs, nsamp, nullptr, 0, nullptr);
+    if (rc) return rc;
+    const double t2 = t_ms ? wall_ms() : 0.0;
+    rc = chain_link(c->chain.h_in, c->chain.h_maps, nblocks, nchan, 1.0 / fs, nsamp, nullptr, nullptr, start, carr_end, last_prn);
+    if (t_ms) { t_ms[0] = t1 - t0; t_ms[1] = t2 - t1; t_ms[2] = wall_ms() - t2; }
+    return rc;
+}
+
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
 
 // GPSIQ_NCO_REFERENCE form of both drop-in calls: the carrier is the caller's double, walked exactly
@@ -756,6 +894,19 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     const int chunk = ref_chunk_blocks(nblocks, nsamp);
     std::vector<int> ends;
     piece_ends(0, nblocks, chunk, &ends, ref_kernel_bound(nsamp, nchan));
+    // the carrier chain: on the device, parallel in time (gpsiq_chain_kernels.hip), when the timeline is long enough to be
+    // worth two launches; its result is what gpsiq_generate_seeded is handed by a caller that walked the chain elsewhere
+    double chain_end[GPSIQ_MAX_CHAN] = {}, t_chain[3] = {};
+    int32_t chain_prn[GPSIQ_MAX_CHAN] = {};
+    const bool dev_chain = !seeds && chain_on_device(nblocks);
+    if (dev_chain) {
+        rc = chain_starts_device(c, ch, nblocks, nchan, nsamp, fs, c->ref_start.data(), chain_end, chain_prn, trace ? t_chain : nullptr);
+        if (rc) return rc;
+        seeds = c->ref_start.data();
+        if (trace)
+            std::fprintf(stderr, "[gpsiq trace] carrier chain on the device: inputs %.3f ms, upload + level 1 (kernels %.3f ms) + maps back %.3f ms, level 2 %.3f ms\n",
+                         t_chain[0], (double) c->chain.last_ms, t_chain[1], t_chain[2]);
+    }
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
     if (!seeds) w.start_out = c->ref_start.data();
@@ -794,8 +945,10 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
                              "validate + upload + launch %.2f ms, final wait %.2f ms, whole call %.2f ms\n",
                      nblocks, w.npieces(), chunk, t_wait, npatch, t_queue, wall_ms() - tf, wall_ms() - t0);
     if (carr_phase_out)
-        for (int i = 0; i < nchan; ++i)
-            carr_phase_out[i] = w.last_prn[i] ? w.carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+        for (int i = 0; i < nchan; ++i) {
+            const bool held = dev_chain ? chain_prn[i] != 0 : w.last_prn[i] != 0;
+            carr_phase_out[i] = held ? (dev_chain ? chain_end[i] : w.carr_end[i]) : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+        }
     return GPSIQ_OK;
 }
 

@@ -1,0 +1,291 @@
+// gpsiq_lane.h -- the reference's carrier chain (gps.c:2821-2826) made parallel in time.  Shared by the host
+// (gpsiq_chain.cpp) and the device (gpsiq_chain_kernels.hip): same source, same IEEE double additions.
+//
+// The chain x_{b+1} = F_b(x_b) (F_b: the block's nsamp double additions of c_b = f_carr*delt with the wrap rule) is serial
+// because every rounding depends on the low bits the one before left.  But F_b is a TRANSLATION on a whole residue class of
+// start states (gpsiq_walk.h / NcoWalk: a walk started d*U higher makes the same roundings as long as every result stays in
+// the binade it had; U = 2^-53, the coarsest ulp below 1).  So, per block and independently of every other block:
+//   1. an ESTIMATE of the accumulator at the block's start (exact real arithmetic R_b = x_0 + sum nsamp*c_j mod 1 in 128-bit
+//      integers + the modelled rounding drift, drift_core) places the last wrap before the block; right after a wrap the
+//      state is a multiple of U, so a REPRESENTATIVE post-wrap state there (the estimate rounded to the grid) differs from
+//      the true one by d*U with an integer d nobody knows yet;
+//   2. the block is walked from the representative (the previous block's tail first: that gives the residue class of the
+//      state at the block's first sample), noting how far the start may move (Slack): a certified map
+//          start xs + d*U, lo <= d <= hi   ->   end e + (d + cum)*U.
+//      A block is cut into up to kMaxSeg stretches walked by separate lanes, each from its own representative wrap; the
+//      stretches are joined at the wraps they share (same sample index, difference of the two representatives = an integer).
+//   3. what is left of the chain is one exact subtraction, one range check and one exact addition per block (link_block):
+//      d_b = (x_b - xs_b)/U, x_{b+1} = e_b + (d_b + cum_b)*U.  A block whose map does not apply (a start outside [lo, hi] or
+//      in another residue class: the estimate put the wrap one sample off; a slow or irregular addend; a phase of exactly
+//      1.0) is walked from its true start state as before (chain_block) -- rare by construction: the estimate is good to
+//      ~1e-13 cycle and the ranges are ~1e-4 cycle wide.
+// Correctness rests on the walk (exact), the slack (sufficient conditions, gpsiq_walk.h) and the two exactness checks in
+// link_block; a bad estimate can only cost a fallback, never a wrong state.
+#ifndef GPSIQ_LANE_H
+#define GPSIQ_LANE_H
+
+#include "gpsiq_walk.h"
+
+namespace gpsiq {
+namespace lane {
+
+typedef unsigned __int128 u128;
+
+constexpr int kTab = 28;                 // table binades of a lane's walker: |c| >= 2^-27 cycle per sample
+constexpr int kMaxSeg = 16;              // stretches per block at most
+typedef WalkCore<kTab> Walker;
+constexpr double kU = 0x1p-53;           // the unit of every offset here
+
+// what a block needs besides its own addend: 32 bytes per channel and block, written by prepare (scan over the timeline)
+struct Prep {
+    double  c;           // addend f_carr*delt of this block (0: unused slot, or a block the lanes leave to the true walk)
+    double  est;         // estimate of the accumulator at the block's first sample, [0, 1)
+    double  core;        // modelled drift over this block (interpolated inside it)
+    int32_t flags;       // kSeed, kSkip
+    int32_t reserved;
+};
+enum : int32_t {
+    kSeed = 1,           // the block's start state is known exactly (first block of a slot's satellite): est IS the state
+    kSkip = 2,           // no map for this block (unused slot, an addend the fast walk does not take): true walk, or nothing
+};
+
+// the certified map of one block (level 1 result), 48 bytes
+struct Rec {
+    double  xs;          // representative state at the block's first sample
+    double  e;           // state after the block when the last stretch starts from its own representative
+    int64_t cum;         // the true end is e + (d + cum)*U for a true start xs + d*U
+    int64_t lo, hi;      // ... if lo <= d <= hi (units of U = 2^-53; positive addends need an even d)
+    int32_t ok;          // 0: no map (level 2 walks the block from its true start)
+    int32_t even;        // d must be even (positive addend: the wrap rounds on the grid of [1, 2))
+};
+
+// ---- exact real arithmetic of the phase: 2^-128 cycle units, the wrap is the overflow -----------------------------------
+GPSIQ_HD inline u128 phase_units(double x)             // x in [0, 1]; bits below 2^-128 are cut (an estimate does not care)
+{
+    const uint64_t b = bits_of(x);
+    const int e = (int) (b >> 52) & 0x7ff;
+    if (e == 0) return 0;
+    const u128 m = (u128) ((b & kMant) | (kMant + 1));
+    const int sh = e - 947;                              // m * 2^(e - 1075) / 2^-128
+    return sh >= 0 ? (sh < 128 ? m << sh : (u128) 0) : (sh > -64 ? m >> -sh : (u128) 0);
+}
+GPSIQ_HD inline u128 advance_units(double c, long nsamp)   // nsamp * c mod 1, exact for |c| >= 2^-75
+{
+    const uint64_t b = bits_of(c);
+    const int e = (int) (b >> 52) & 0x7ff;
+    if (e == 0 || nsamp <= 0) return 0;
+    const u128 p = (u128) ((b & kMant) | (kMant + 1)) * (u128) (uint64_t) nsamp;
+    const int sh = e - 947;
+    const u128 v = sh >= 0 ? (sh < 128 ? p << sh : (u128) 0) : (sh > -64 ? p >> -sh : (u128) 0);
+    return (b >> 63) ? (u128) 0 - v : v;
+}
+GPSIQ_HD inline double units_to_double(u128 r) { return (double) (uint64_t) (r >> 64) * 0x1p-64; }
+
+GPSIQ_HD inline double wrap01(double x)                 // into [0, 1)
+{
+    x -= __builtin_floor(x);
+    return x < 1.0 ? x : 0.0;
+}
+
+// ---- the modelled rounding drift of one block (Drift in gpsiq_exact.cpp, its centre only) --------------------------------
+// While state and sum share binade b the addition adds S_b = rnd(|c|/u_b)*u_b instead of |c|: with G piecewise linear of
+// slope (S_b - |c|)/S_b in binade b, continued over the wraps, the accumulator after n additions is x0 + n*c + G^(end) -
+// G(x0) up to a dozen irregular roundings per cycle.  x0: where the block starts (an estimate does).
+GPSIQ_HD inline double drift_core(double c, double x0, long nsamp)
+{
+    const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
+    const int64_t ec = (int64_t) (bc >> 52), mc = (int64_t) ((bc & kMant) | (kMant + 1));
+    if (ec > 1022 - 6 || ec < 1022 - 40) return 0.0;
+    const double end = x0 + (double) nsamp * c, q = __builtin_floor(end), r = end - q;
+    double GL = 0.0, Gr = 0.0, G0 = 0.0;
+    for (int b = (int) ec + 3; b <= 1022; ++b) {
+        const int s = b - (int) ec;
+        int64_t dm = mc >> s;
+        const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
+        if (rem > half) ++dm;
+        else if (rem == half) dm += dm & 1;
+        const double delta = (double) ((dm << s) - mc), Sb = (double) dm * (double) ((int64_t) 1 << s);
+        const double gb = delta / Sb, lo = from_bits((uint64_t) b << 52);        // binade [lo, 2 lo)
+        GL += gb * lo;
+        const double ar = r - lo, a0 = x0 - lo;
+        Gr += gb * (ar < 0.0 ? 0.0 : ar > lo ? lo : ar);
+        G0 += gb * (a0 < 0.0 ? 0.0 : a0 > lo ? lo : a0);
+    }
+    return q * GL + Gr - G0;
+}
+
+// ---- placing the last wrap at or before a sample -----------------------------------------------------------------------
+// s: estimate of the accumulator at some sample, c: the addend in force before it.  The accumulator was last wrapped k
+// additions earlier; *r = the estimate of that post-wrap state on its grid (a multiple of 2^-52 in [0, c] for a positive
+// addend, of 2^-53 in [1 + c, 1) for a negative one).  false: no usable answer.
+GPSIQ_HD inline bool last_wrap(double s, double c, long *k, double *r)
+{
+    if (!(s >= 0.0 && s < 1.0)) return false;
+    if (c > 0.0) {
+        double kk = __builtin_floor(s / c);
+        double w = __builtin_fma(-kk, c, s);
+        if (w < 0.0) { kk -= 1.0; w += c; }
+        else if (w >= c) { kk += 1.0; w -= c; }
+        if (!(kk >= 0.0 && kk < 0x1p40)) return false;
+        double g = __builtin_rint(w * 0x1p52) * 0x1p-52;
+        if (g < 0.0) g = 0.0;
+        *k = (long) kk; *r = g;
+        return true;
+    }
+    if (c < 0.0) {
+        const double a = -c;
+        double kk = __builtin_floor((1.0 - s) / a);
+        double w = __builtin_fma(kk, a, s);
+        if (w >= 1.0) { kk -= 1.0; w -= a; }
+        else if (w < 1.0 - a) { kk += 1.0; w += a; }
+        if (!(kk >= 0.0 && kk < 0x1p40)) return false;
+        double g = __builtin_rint(w * 0x1p53) * 0x1p-53;
+        if (g >= 1.0) g = 1.0 - 0x1p-53;
+        *k = (long) kk; *r = g;
+        return true;
+    }
+    return false;
+}
+
+// a - b as a multiple of U = 2^-53, when it is exactly that
+GPSIQ_HD inline bool exact_units(double a, double b, int64_t *d)
+{
+    const double s = a - b;
+    const double bb = s - a, err = (a - (s - bb)) + (-b - bb);      // TwoSum of a + (-b): err == 0 <=> s is the real difference
+    if (err != 0.0) return false;
+    const double u = s * 0x1p53;                                     // exact (a power of two; |s| <= 1)
+    if (!(__builtin_fabs(u) < 0x1p62)) return false;
+    const int64_t i = (int64_t) u;
+    if ((double) i != u) return false;
+    *d = i;
+    return true;
+}
+
+// e + k*U when that is exact
+GPSIQ_HD inline bool exact_shift(double e, int64_t k, double *out)
+{
+    if (k > ((int64_t) 1 << 53) || k < -((int64_t) 1 << 53)) return false;
+    const double t = (double) k * kU, s = e + t;
+    const double bb = s - e, err = (e - (s - bb)) + (t - bb);
+    if (err != 0.0) return false;
+    *out = s;
+    return true;
+}
+
+// ---- one stretch of one block ----------------------------------------------------------------------------------------
+struct Stretch {
+    long    n_in;        // sample index (inside the block; < 0: not used) of the wrap the stretch starts from
+    double  r_in;        // its representative state there
+    long    n_out;       // last wrap at or before the stretch's end sample (n_in itself if there was none)
+    double  x_out;       // the state there
+    double  x_first;     // stretch 0: state at the block's first sample
+    double  x_end;       // state at the stretch's end sample
+    int64_t lo, hi;      // units of U = 2^-53, relative to the stretch's own start
+    int     ok;
+    int     why;         // ok == 0: what stood in the way (kWhy*), for the statistics
+};
+enum { kWhyNone = 0, kWhyAddend = 1, kWhyPrev = 2, kWhyWrap = 3, kWhyState = 4, kWhyAnchor = 5, kWhySlack = 6, kWhyEdge = 7, kWhyJoin = 8, kWhyUnits = 9, kWhyRange = 10 };
+
+// how many stretches a block gets: at least ~4 wraps in each
+GPSIQ_HD inline int stretches(double c, long nsamp, int max_seg)
+{
+    const double cyc = __builtin_fabs(c) * (double) nsamp;
+    int s = (int) (cyc * 0.25);
+    if (s > max_seg) s = max_seg;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// the walk of stretch t of nseg of a block: W the walker of the block's addend, Wp of the previous block's (stretch 0 of a
+// block that is no seed only); p: the block's Prep; prev_c: the previous block's addend (0: none)
+GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep &p, long nsamp, int t, int nseg, Stretch *out)
+{
+    Stretch o;
+    o.n_in = -1; o.r_in = 0.0; o.n_out = -1; o.x_out = 0.0; o.x_first = 0.0; o.x_end = 0.0; o.lo = 0; o.hi = 0; o.ok = 0; o.why = kWhyAddend;
+    *out = o;
+    if ((p.flags & kSkip) || W.general || !(p.c != 0.0)) return;
+    const long a0 = (long) (((int64_t) t * nsamp) / nseg), a1 = (long) (((int64_t) (t + 1) * nsamp) / nseg);
+    const int uexp = W.neg ? 1022 : 1023;
+    typename Walker::Slack sl = {-((int64_t) 1 << 61), (int64_t) 1 << 61, uexp, true};
+    double x;
+    long n;
+    if (t == 0) {
+        if (p.flags & kSeed) x = p.est;
+        else {
+            // the tail of the block before, from its last wrap: the residue class of the state this block starts from
+            out->why = kWhyPrev;
+            if (!Wp || Wp->general || Wp->neg != W.neg) return;
+            long k;
+            out->why = kWhyWrap;
+            if (!last_wrap(p.est, Wp->c, &k, &x) || k > nsamp) return;
+            long m = 0;
+            while (m < k && Wp->cycle(x, m, k)) {}
+        }
+        out->why = kWhyState;
+        if (!(x >= 0.0 && x < 1.0)) return;
+        o.x_first = x;
+        o.n_in = 0; o.r_in = x;
+        n = 0;
+    } else {
+        // the accumulator at sample a0: the block's start + a0 additions + the share of the block's drift
+        const double fa = (double) a0, pr = fa * p.c, pe = __builtin_fma(fa, p.c, -pr);
+        const double s = wrap01(p.est + (pr - __builtin_floor(pr)) + pe + p.core * (fa / (double) nsamp));
+        long k;
+        out->why = kWhyAnchor;
+        if (!last_wrap(s, p.c, &k, &x) || k > a0) return;
+        n = a0 - k;
+        o.n_in = n; o.r_in = x;
+    }
+    o.n_out = o.n_in; o.x_out = x;
+    if (x >= W.thr) sl.note(x);                      // a start inside a table binade has to stay in it (results are noted by the walk)
+    while (n < a1) {
+        const bool wrapped = W.neg ? W.template descend<true>(x, n, a1, &sl) : W.template climb<true>(x, n, a1, &sl);
+        if (!wrapped) break;
+        o.n_out = n; o.x_out = x;
+    }
+    o.x_end = x;
+    // the slack counts units of the wrap grid: 2^-52 for a positive addend
+    if (W.neg) { o.lo = sl.lo; o.hi = sl.hi; }
+    else { o.lo = sl.lo > -((int64_t) 1 << 60) ? 2 * sl.lo : sl.lo; o.hi = sl.hi < ((int64_t) 1 << 60) ? 2 * sl.hi : sl.hi; }
+    o.ok = sl.ok && o.lo <= 0 && o.hi >= 0 && x >= 0.0 && x < 1.0;
+    o.why = o.ok ? kWhyNone : !sl.ok ? kWhySlack : kWhyEdge;
+    *out = o;
+}
+
+// the stretches of a block joined into its map
+GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *rec)
+{
+    Rec r;
+    r.xs = st[0].x_first; r.e = st[nseg - 1].x_end; r.cum = 0; r.lo = st[0].lo; r.hi = st[0].hi; r.ok = st[0].ok; r.even = neg ? 0 : 1;
+    int why = st[0].why;
+    for (int t = 1; t < nseg && r.ok; ++t) {
+        int64_t d;
+        if (!st[t].ok) { r.ok = 0; why = st[t].why; break; }
+        if (st[t - 1].n_out != st[t].n_in) { r.ok = 0; why = kWhyJoin; break; }
+        if (!exact_units(st[t - 1].x_out, st[t].r_in, &d)) { r.ok = 0; why = kWhyUnits; break; }
+        r.cum += d;                                   // stretch t starts cum units above its representative when stretch 0 starts on xs
+        const int64_t l = st[t].lo - r.cum, h = st[t].hi - r.cum;
+        if (l > r.lo) r.lo = l;
+        if (h < r.hi) r.hi = h;
+    }
+    if (r.ok && r.lo > r.hi) { r.ok = 0; why = kWhyRange; }
+    if (!r.ok) r.even |= why << 8;              // the statistics' business only: link_block never looks at a map that is not ok
+    *rec = r;
+}
+
+// level 2, one block: the accumulator after the block from its true start state x through the block's map; false: the map
+// does not apply (walk the block)
+GPSIQ_HD inline bool link_block(const Rec &r, double x, double *next)
+{
+    int64_t d;
+    if (!r.ok || !exact_units(x, r.xs, &d)) return false;
+    if (d < r.lo || d > r.hi || (r.even && (d & 1))) return false;
+    double y;
+    if (!exact_shift(r.e, d + r.cum, &y) || !(y >= 0.0 && y < 1.0)) return false;
+    *next = y;
+    return true;
+}
+
+}  // namespace lane
+}  // namespace gpsiq
+#endif

@@ -82,6 +82,12 @@ _reference_chain = _sig("gpsiq_reference_chain", _i, _vp, _i, _i, _d, _i, _vp, _
 _reference_seeded = _sig("gpsiq_reference_seeded", _i, _vp, _i, _i, _d, _i, _vp, _vp, _vp, _i, C.POINTER(C.c_int))
 _reference_stats = _sig("gpsiq_reference_stats", None, _vp)
 _chain_inputs = _sig("gpsiq_chain_inputs", None, _vp, _i, _vp)
+_chain_maps = _sig("gpsiq_chain_maps", _i, _vp, _i, _i, _d, _i, _vp, _i, _vp, _vp)
+_chain_maps_device = _sig("gpsiq_chain_maps_device", _i, _vp, _vp, _i, _i, _d, _i, _vp, _i, _vp, _vp, C.POINTER(C.c_float))
+_chain_link = _sig("gpsiq_chain_link", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp)
+_chain_summary = _sig("gpsiq_chain_summary", _i, _vp, _i, _i, _d, _i, _vp, _vp)
+_chain_fold = _sig("gpsiq_chain_fold", _i, _vp, _i, _i, _vp)
+_chain_stats = _sig("gpsiq_chain_stats", None, _vp)
 _set_patches = _sig("gpsiq_set_patches", _i, _vp, _vp, _i)
 _set_nco_mode = _sig("gpsiq_set_nco_mode", _i, _vp, _i)
 _generate_batch_multi = _sig("gpsiq_generate_batch_multi", _i, _vp, _i, _vp, _i, _i, _i, _d, _i, _vp, _vp, _vp)
@@ -218,6 +224,70 @@ def reference_chain(cin, fs, nsamp, carr_in=None, prn_in=None):
     _check(_reference_chain(_p(cin), nb, nc, float(fs), int(nsamp), None if ci is None else _p(ci), None if pi is None else _p(pi),
                             _p(start), _p(end), _p(last)))
     return start, end, last
+
+
+def chain_maps(cin, fs, nsamp, start=None, max_stretches=0, ctx=None):
+    """gpsiq_chain_maps (ctx given: gpsiq_chain_maps_device): level 1 of the time-parallel carrier chain, the certified map of
+    every block -> (maps[nblocks][nchan], end[nchan]) (+ the kernels' milliseconds on a device)."""
+    from .abi import CHAIN_IN_DTYPE, CHAIN_EST_DTYPE, CHAIN_MAP_DTYPE
+    cin = np.ascontiguousarray(cin, dtype=CHAIN_IN_DTYPE)
+    nb, nc = cin.shape
+    maps = np.zeros((nb, nc), dtype=CHAIN_MAP_DTYPE)
+    end = np.zeros(nc, dtype=CHAIN_EST_DTYPE)
+    st = None if start is None else np.ascontiguousarray(start, dtype=CHAIN_EST_DTYPE)
+    if ctx is None:
+        _check(_chain_maps(_p(cin), nb, nc, float(fs), int(nsamp), None if st is None else _p(st), int(max_stretches), _p(maps), _p(end)))
+        return maps, end
+    ms = C.c_float(0.0)
+    _check(_chain_maps_device(ctx._h, _p(cin), nb, nc, float(fs), int(nsamp), None if st is None else _p(st), int(max_stretches),
+                              _p(maps), _p(end), C.byref(ms)))
+    return maps, end, float(ms.value)
+
+
+def chain_link(cin, maps, fs, nsamp, carr_in=None, prn_in=None):
+    """gpsiq_chain_link: level 2, the chain itself -> (carr_start[nblocks][nchan], carr_end[nchan], last_prn[nchan]), equal to
+    reference_chain's."""
+    from .abi import CHAIN_IN_DTYPE, CHAIN_MAP_DTYPE
+    cin = np.ascontiguousarray(cin, dtype=CHAIN_IN_DTYPE)
+    maps = np.ascontiguousarray(maps, dtype=CHAIN_MAP_DTYPE)
+    nb, nc = cin.shape
+    assert maps.shape == (nb, nc)
+    start = np.zeros((nb, nc), dtype=np.float64)
+    end = np.zeros(nc, dtype=np.float64)
+    last = np.zeros(nc, dtype=np.int32)
+    ci = None if carr_in is None else np.ascontiguousarray(carr_in, dtype=np.float64)
+    pi = None if prn_in is None else np.ascontiguousarray(prn_in, dtype=np.int32)
+    _check(_chain_link(_p(cin), _p(maps), nb, nc, float(fs), int(nsamp), None if ci is None else _p(ci), None if pi is None else _p(pi),
+                       _p(start), _p(end), _p(last)))
+    return start, end, last
+
+
+def chain_summary(cin, fs, nsamp, start=None):
+    """gpsiq_chain_summary: what a range of blocks does to every slot's estimator (start None: the phase pass)."""
+    from .abi import CHAIN_IN_DTYPE, CHAIN_EST_DTYPE
+    cin = np.ascontiguousarray(cin, dtype=CHAIN_IN_DTYPE)
+    nb, nc = cin.shape
+    out = np.zeros(nc, dtype=CHAIN_EST_DTYPE)
+    st = None if start is None else np.ascontiguousarray(start, dtype=CHAIN_EST_DTYPE)
+    _check(_chain_summary(_p(cin), nb, nc, float(fs), int(nsamp), None if st is None else _p(st), _p(out)))
+    return out
+
+
+def chain_fold(sums):
+    """gpsiq_chain_fold: the estimator state after the ranges sums[0 .. n) ([n][nchan]), i.e. where range n starts."""
+    from .abi import CHAIN_EST_DTYPE
+    sums = np.ascontiguousarray(sums, dtype=CHAIN_EST_DTYPE)
+    n, nc = sums.shape
+    out = np.zeros(nc, dtype=CHAIN_EST_DTYPE)
+    _check(_chain_fold(_p(sums) if n else None, n, nc, _p(out)))
+    return out
+
+
+def chain_stats():
+    """gpsiq_chain_stats: (blocks linked through their map, blocks walked from their true start) since the process started."""
+    out = np.zeros(2, dtype=np.uint64)
+    _chain_stats(_p(out))
+    return int(out[0]), int(out[1])
 
 
 def reference_seeded(desc, fs, nsamp, carr_start):

@@ -32,6 +32,13 @@ NCO_FIXED, NCO_REFERENCE = 0, 1
 # gpsiq_chain_in_t (the three fields of gpsiq_chan_t the serial carrier chain of GPSIQ_NCO_REFERENCE reads)
 CHAIN_IN_DTYPE = np.dtype([("f_carr", "<f8"), ("carr_phase", "<f8"), ("prn", "<i4"), ("reserved", "<i4")], align=True)
 assert CHAIN_IN_DTYPE.itemsize == 24
+# gpsiq_chain_est_t / gpsiq_chain_map_t (the time-parallel carrier chain)
+CHAIN_EST_DTYPE = np.dtype([("r_hi", "<u8"), ("r_lo", "<u8"), ("drift", "<f8"), ("carr", "<f8"), ("f_carr", "<f8"),
+                            ("prn", "<i4"), ("flags", "<i4"), ("first_prn", "<i4"), ("reserved", "<i4")], align=True)
+assert CHAIN_EST_DTYPE.itemsize == 56
+CHAIN_MAP_DTYPE = np.dtype([("xs", "<f8"), ("e", "<f8"), ("cum", "<i8"), ("lo", "<i8"), ("hi", "<i8"), ("ok", "<i4"), ("even", "<i4")], align=True)
+assert CHAIN_MAP_DTYPE.itemsize == 48
+CHAIN_EXACT, CHAIN_RESEEDED, CHAIN_EMPTY = 1, 2, 4
 # gpsiq_shard_carry_t
 SHARD_CARRY_DTYPE = np.dtype([("end_phase", "<u8"), ("advance", "<u8"), ("first_prn", "<i4"), ("last_prn", "<i4"),
                               ("reseeded", "<i4"), ("nblocks", "<i4")], align=True)
