@@ -171,6 +171,13 @@ static void link_slot(LinkJob &j, int i)
 
 static std::atomic<uint64_t> g_chain_stats[2];          // blocks linked through their map / walked from their true start
 
+bool chain_step_mapped(const void *maps, size_t at, double x, double *next) { return lane::link_block(static_cast<const Rec *>(maps)[at], x, next); }
+void chain_count(long linked, long walked)
+{
+    g_chain_stats[0].fetch_add((uint64_t) linked, std::memory_order_relaxed);
+    g_chain_stats[1].fetch_add((uint64_t) walked, std::memory_order_relaxed);
+}
+
 int chain_link(const gpsiq_chain_in_t *in, const void *maps, int nblocks, int nchan, double delt, int nsamp,
                const double *carr_in, const int32_t *prn_in, double *carr_start, double *carr_end, int32_t *last_prn)
 {

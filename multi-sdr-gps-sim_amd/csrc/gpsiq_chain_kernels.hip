@@ -209,7 +209,8 @@ hipError_t launch_chain(const gpsiq_chain_in_t *d_in, int nblocks, int nchan, do
     hipLaunchKernelGGL(chain_lanes<S>, dim3((unsigned) (nchan * ((nblocks + kLaneThreads / S - 1) / (kLaneThreads / S)))), dim3(kLaneThreads), 0, stream, \
                        d_prep, d_c_before, nblocks, nchan, nsamp, max_seg, d_rec)
     if (max_seg < 1) max_seg = 1;
-    if (max_seg > 8) GPSIQ_LANES(16);
+    if (max_seg > 16) GPSIQ_LANES(32);
+    else if (max_seg > 8) GPSIQ_LANES(16);
     else if (max_seg > 4) GPSIQ_LANES(8);
     else GPSIQ_LANES(4);                                        // fewer stretches than lanes per block: the spare lanes idle
 #undef GPSIQ_LANES

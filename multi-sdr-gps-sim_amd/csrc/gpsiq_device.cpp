@@ -801,7 +801,7 @@ static int chain_maps_staged(gpsiq_ctx *c, int nblocks, int nchan, double fs, in
     const size_t n = (size_t) nblocks * (size_t) nchan;
     if (max_stretches <= 0) {
         max_stretches = 16;
-        if (const char *e = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) max_stretches = v; }
+        if (const char *e = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) max_stretches = v; }
     }
     HIP_TRY(hipMemcpyAsync(k.d_in, k.h_in, n * sizeof(gpsiq_chain_in_t), hipMemcpyHostToDevice, k.stream));
     if (start) {
@@ -851,8 +851,7 @@ static bool chain_on_device(int nblocks)
     return nblocks >= 48;
 }
 
-static int chain_starts_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
-                               double *start, double *carr_end, int32_t *last_prn, double *t_ms /* [3] or null: inputs, level 1, level 2 */)
+static int chain_level1_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs, double *t_ms /* [2] or null: inputs, level 1 */)
 {
     const size_t n = (size_t) nblocks * (size_t) nchan;
     const double t0 = t_ms ? wall_ms() : 0.0;
@@ -866,10 +865,7 @@ static int chain_starts_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks
     }, &job);
     const double t1 = t_ms ? wall_ms() : 0.0;
     rc = chain_maps_staged(c, nblocks, nchan, fs, nsamp, nullptr, 0, nullptr);
-    if (rc) return rc;
-    const double t2 = t_ms ? wall_ms() : 0.0;
-    rc = chain_link(c->chain.h_in, c->chain.h_maps, nblocks, nchan, 1.0 / fs, nsamp, nullptr, nullptr, start, carr_end, last_prn);
-    if (t_ms) { t_ms[0] = t1 - t0; t_ms[1] = t2 - t1; t_ms[2] = wall_ms() - t2; }
+    if (t_ms) { t_ms[0] = t1 - t0; t_ms[1] = wall_ms() - t1; }
     return rc;
 }
 
@@ -894,22 +890,21 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     const int chunk = ref_chunk_blocks(nblocks, nsamp);
     std::vector<int> ends;
     piece_ends(0, nblocks, chunk, &ends, ref_kernel_bound(nsamp, nchan));
-    // the carrier chain: on the device, parallel in time (gpsiq_chain_kernels.hip), when the timeline is long enough to be
-    // worth two launches; its result is what gpsiq_generate_seeded is handed by a caller that walked the chain elsewhere
-    double chain_end[GPSIQ_MAX_CHAN] = {}, t_chain[3] = {};
-    int32_t chain_prn[GPSIQ_MAX_CHAN] = {};
+    // the carrier chain: level 1 (every block's certified map) on the device, parallel in time (gpsiq_chain_kernels.hip), when the
+    // timeline is long enough to be worth two launches; the chain tasks then link block to block through the maps
+    double t_chain[2] = {};
     const bool dev_chain = !seeds && chain_on_device(nblocks);
     if (dev_chain) {
-        rc = chain_starts_device(c, ch, nblocks, nchan, nsamp, fs, c->ref_start.data(), chain_end, chain_prn, trace ? t_chain : nullptr);
+        rc = chain_level1_device(c, ch, nblocks, nchan, nsamp, fs, trace ? t_chain : nullptr);
         if (rc) return rc;
-        seeds = c->ref_start.data();
         if (trace)
-            std::fprintf(stderr, "[gpsiq trace] carrier chain on the device: inputs %.3f ms, upload + level 1 (kernels %.3f ms) + maps back %.3f ms, level 2 %.3f ms\n",
-                         t_chain[0], (double) c->chain.last_ms, t_chain[1], t_chain[2]);
+            std::fprintf(stderr, "[gpsiq trace] carrier chain, level 1 on the device: inputs %.3f ms, upload + kernels (%.3f ms) + maps back %.3f ms\n",
+                         t_chain[0], (double) c->chain.last_ms, t_chain[1]);
     }
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
     if (!seeds) w.start_out = c->ref_start.data();
+    if (dev_chain) { w.in = c->chain.h_in; w.maps = c->chain.h_maps; }
     // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
     // thread, and this thread renders every piece as soon as all channels are through it
     pthread_t th;
@@ -945,10 +940,8 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
                              "validate + upload + launch %.2f ms, final wait %.2f ms, whole call %.2f ms\n",
                      nblocks, w.npieces(), chunk, t_wait, npatch, t_queue, wall_ms() - tf, wall_ms() - t0);
     if (carr_phase_out)
-        for (int i = 0; i < nchan; ++i) {
-            const bool held = dev_chain ? chain_prn[i] != 0 : w.last_prn[i] != 0;
-            carr_phase_out[i] = held ? (dev_chain ? chain_end[i] : w.carr_end[i]) : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
-        }
+        for (int i = 0; i < nchan; ++i)
+            carr_phase_out[i] = w.last_prn[i] ? w.carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
     return GPSIQ_OK;
 }
 

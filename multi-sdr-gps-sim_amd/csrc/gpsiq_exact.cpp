@@ -1050,12 +1050,15 @@ void RefWalk::set_error(int code, const char *text, int block)
     abort_flag.store(true, std::memory_order_release);       // the tasks still to come finish at once (their pieces complete, waiters wake)
 }
 
-// channel i through piece k: the start state of every block, then the accumulator after it
+// channel i through piece k: the start state of every block, then the accumulator after it.  With the blocks' certified maps
+// at hand (maps: level 1 of the time-parallel chain, gpsiq_lane.h, walked on the device) a block is one exact subtraction,
+// range check and addition (chain_step_mapped) and only the rare block whose map does not apply is walked.
 void RefWalk::chain_task(int i, size_t k)
 {
     const int b0 = k ? ends[k - 1] : 0, b1 = ends[k];
     double c = carr[i];
     int pv = prev[i];
+    long walked = 0, linked = 0;
     for (int b = b0; b < b1; ++b) {
         const size_t at = (size_t) b * nchan + i;
         // a channel's descriptors lie nchan * 296 bytes apart: every block is a cache miss unless it is asked for early
@@ -1073,9 +1076,12 @@ void RefWalk::chain_task(int i, size_t k)
             set_error(GPSIQ_E_RANGE, "carrier phase or Doppler outside the NCO format", b);
             continue;
         }
-        c = chain_block(f_carr, delt, nsamp, c);
+        double y;
+        if (maps && chain_step_mapped(maps, at, c, &y)) { c = y; ++linked; }
+        else { c = chain_block(f_carr, delt, nsamp, c); ++walked; }
     }
     carr[i] = c; prev[i] = pv;
+    if (maps) chain_count(linked, walked);
 }
 
 // channel i's blocks of piece k: descriptors and patches from their start states
@@ -1103,6 +1109,15 @@ void RefWalk::eval_task(int i, size_t k, CodeCache *codes)
     }
 }
 
+// the maps of blocks [0, upto) have arrived (the device walks level 1 of a long timeline in two launches): their chain tasks may run
+void RefWalk::release_maps(int upto)
+{
+    pthread_mutex_lock(&mu);
+    maps_upto.store(upto, std::memory_order_release);
+    pthread_cond_broadcast(&task_cv);
+    pthread_mutex_unlock(&mu);
+}
+
 void RefWalk::finish_piece(size_t k)
 {
     if (done[k].fetch_add(1, std::memory_order_acq_rel) + 1 == nchan) {
@@ -1126,7 +1141,7 @@ void RefWalk::work()
         for (int i = 0; i < nchan; ++i) {
             if (!seeds && chain_next[i] < np) {
                 pending = true;
-                if (!chain_busy[i] && (chain_next[i] < best_k || (chain_next[i] == best_k && !best_chain))) { best_i = i; best_k = chain_next[i]; best_chain = true; }
+                if (!chain_busy[i] && ends[chain_next[i]] <= maps_upto.load(std::memory_order_acquire) && (chain_next[i] < best_k || (chain_next[i] == best_k && !best_chain))) { best_i = i; best_k = chain_next[i]; best_chain = true; }
             }
             if (!chain_only && eval_next[i] < np) {
                 pending = true;

@@ -72,6 +72,9 @@ struct RefWalk {
     const double *seeds = nullptr;                // [nblocks][nchan] start states known: no chain tasks
     bool    chain_only = false;                   // no EVAL tasks (q, ch may be null when `in` is given)
     double *start_out = nullptr;                  // where the chain publishes the start states (default: own storage)
+    const void *maps = nullptr;                   // [nblocks][nchan] certified maps of the blocks (gpsiq_lane.h): the chain tasks link
+    void release_maps(int upto);                  // ... through them; only blocks [0, maps_upto) may be touched yet (default: all)
+    std::atomic<int> maps_upto{0x7fffffff};
 private:
     void work();
     void chain_task(int i, size_t k);
@@ -91,6 +94,11 @@ private:
     const double *start = nullptr;
     std::vector<double> own_start;
 };
+
+// level 2 of the time-parallel chain for one block (gpsiq_chain.cpp): the accumulator after block `at` of maps from its true start
+// x; false: the block's map does not apply (walk it).  chain_count: the process-wide statistics (gpsiq_chain_stats).
+bool chain_step_mapped(const void *maps, size_t at, double x, double *next);
+void chain_count(long linked, long walked);
 
 // Host threads this process may use: online CPUs, capped by GPSIQ_THREADS (read once).
 int host_threads();

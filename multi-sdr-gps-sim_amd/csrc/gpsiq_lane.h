@@ -31,8 +31,8 @@ namespace lane {
 
 typedef unsigned __int128 u128;
 
-constexpr int kTab = 28;                 // table binades of a lane's walker: |c| >= 2^-27 cycle per sample
-constexpr int kMaxSeg = 16;              // stretches per block at most
+constexpr int kTab = 22;                 // table binades of a lane's walker: |c| >= 2^-22 cycle per sample (slower blocks hold no wrap to start from)
+constexpr int kMaxSeg = 32;              // stretches per block at most
 typedef WalkCore<kTab> Walker;
 constexpr double kU = 0x1p-53;           // the unit of every offset here
 
@@ -174,15 +174,12 @@ GPSIQ_HD inline bool exact_shift(double e, int64_t k, double *out)
 
 // ---- one stretch of one block ----------------------------------------------------------------------------------------
 struct Stretch {
-    long    n_in;        // sample index (inside the block; < 0: not used) of the wrap the stretch starts from
-    double  r_in;        // its representative state there
-    long    n_out;       // last wrap at or before the stretch's end sample (n_in itself if there was none)
-    double  x_out;       // the state there
-    double  x_first;     // stretch 0: state at the block's first sample
+    double  r_in;        // representative state the stretch starts from: at the wrap n_in (stretch 0: at the block's first sample)
+    double  x_out;       // the state at the last wrap at or before the stretch's end sample (n_out; n_in itself if there was none)
     double  x_end;       // state at the stretch's end sample
     int64_t lo, hi;      // units of U = 2^-53, relative to the stretch's own start
-    int     ok;
-    int     why;         // ok == 0: what stood in the way (kWhy*), for the statistics
+    int32_t n_in, n_out; // sample indices inside the block
+    int16_t ok, why;     // ok == 0: what stood in the way (kWhy*), for the statistics
 };
 enum { kWhyNone = 0, kWhyAddend = 1, kWhyPrev = 2, kWhyWrap = 3, kWhyState = 4, kWhyAnchor = 5, kWhySlack = 6, kWhyEdge = 7, kWhyJoin = 8, kWhyUnits = 9, kWhyRange = 10 };
 
@@ -201,12 +198,12 @@ GPSIQ_HD inline int stretches(double c, long nsamp, int max_seg)
 GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep &p, long nsamp, int t, int nseg, Stretch *out)
 {
     Stretch o;
-    o.n_in = -1; o.r_in = 0.0; o.n_out = -1; o.x_out = 0.0; o.x_first = 0.0; o.x_end = 0.0; o.lo = 0; o.hi = 0; o.ok = 0; o.why = kWhyAddend;
+    o.n_in = -1; o.r_in = 0.0; o.n_out = -1; o.x_out = 0.0; o.x_end = 0.0; o.lo = 0; o.hi = 0; o.ok = 0; o.why = kWhyAddend;
     *out = o;
     if ((p.flags & kSkip) || W.general || !(p.c != 0.0)) return;
     const long a0 = (long) (((int64_t) t * nsamp) / nseg), a1 = (long) (((int64_t) (t + 1) * nsamp) / nseg);
-    const int uexp = W.neg ? 1022 : 1023;
-    typename Walker::Slack sl = {-((int64_t) 1 << 61), (int64_t) 1 << 61, uexp, true};
+    typename Walker::FastSlack sl;
+    sl.init(W.neg ? 1022 : 1023);
     double x;
     long n;
     if (t == 0) {
@@ -223,7 +220,6 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
         }
         out->why = kWhyState;
         if (!(x >= 0.0 && x < 1.0)) return;
-        o.x_first = x;
         o.n_in = 0; o.r_in = x;
         n = 0;
     } else {
@@ -234,21 +230,21 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
         out->why = kWhyAnchor;
         if (!last_wrap(s, p.c, &k, &x) || k > a0) return;
         n = a0 - k;
-        o.n_in = n; o.r_in = x;
+        o.n_in = (int32_t) n; o.r_in = x;
     }
     o.n_out = o.n_in; o.x_out = x;
     if (x >= W.thr) sl.note(x);                      // a start inside a table binade has to stay in it (results are noted by the walk)
     while (n < a1) {
         const bool wrapped = W.neg ? W.template descend<true>(x, n, a1, &sl) : W.template climb<true>(x, n, a1, &sl);
         if (!wrapped) break;
-        o.n_out = n; o.x_out = x;
+        o.n_out = (int32_t) n; o.x_out = x;
     }
     o.x_end = x;
     // the slack counts units of the wrap grid: 2^-52 for a positive addend
-    if (W.neg) { o.lo = sl.lo; o.hi = sl.hi; }
-    else { o.lo = sl.lo > -((int64_t) 1 << 60) ? 2 * sl.lo : sl.lo; o.hi = sl.hi < ((int64_t) 1 << 60) ? 2 * sl.hi : sl.hi; }
-    o.ok = sl.ok && o.lo <= 0 && o.hi >= 0 && x >= 0.0 && x < 1.0;
-    o.why = o.ok ? kWhyNone : !sl.ok ? kWhySlack : kWhyEdge;
+    const bool slack_ok = sl.finish(&o.lo, &o.hi);
+    if (!W.neg) { o.lo *= 2; o.hi *= 2; }
+    o.ok = slack_ok && o.lo <= 0 && o.hi >= 0 && x >= 0.0 && x < 1.0;
+    o.why = o.ok ? kWhyNone : !slack_ok ? kWhySlack : kWhyEdge;
     *out = o;
 }
 
@@ -256,7 +252,7 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
 GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *rec)
 {
     Rec r;
-    r.xs = st[0].x_first; r.e = st[nseg - 1].x_end; r.cum = 0; r.lo = st[0].lo; r.hi = st[0].hi; r.ok = st[0].ok; r.even = neg ? 0 : 1;
+    r.xs = st[0].r_in; r.e = st[nseg - 1].x_end; r.cum = 0; r.lo = st[0].lo; r.hi = st[0].hi; r.ok = st[0].ok; r.even = neg ? 0 : 1;
     int why = st[0].why;
     for (int t = 1; t < nseg && r.ok; ++t) {
         int64_t d;

@@ -60,6 +60,45 @@ struct WalkCore {
             if (l > lo) lo = l;
             if (h < hi) hi = h;
         }
+        // a value that may move up by less than `dist` / down by at most `dist` (descending carrier: U = 2^-53), two units short
+        GPSIQ_HD inline void room_above(double dist) { const int64_t h = (int64_t) (dist * 0x1p53) - 2; if (h < hi) hi = h; }
+        GPSIQ_HD inline void room_below(double dist) { const int64_t l = 2 - (int64_t) (dist * 0x1p53); if (l > lo) lo = l; }
+        GPSIQ_HD inline void fail() { ok = false; }
+    };
+
+    // The same bookkeeping in doubles, for the lanes of the time-parallel chain (gpsiq_lane.h; on the device 64-bit shifts and
+    // compares per noted value were a third of the walk): the smallest distance of a noted value to the lower / upper edge of
+    // its binade, exactly (v - 2^e and 2^(e+1) - v are exact), turned into units once at the end -- floor is monotone, so
+    // lo / hi are the ones Slack would have found.  Carrier only (note_limit is the code phase's).
+    struct FastSlack {
+        double dlo, dhi;       // room below / above, in cycles
+        double vmin, vmax;     // range of the noted values: they must be normal and inside the accumulator's range
+        int    unit_exp;
+        bool   ok;
+        GPSIQ_HD inline void init(int uexp) { dlo = 4.0; dhi = 4.0; vmin = 1.0; vmax = 0.0; unit_exp = uexp; ok = true; }
+        GPSIQ_HD inline void note(double v)
+        {
+            const double edge = from_bits(bits_of(v) & ~kMant), dl = v - edge, dh = edge - dl;
+            dlo = dl < dlo ? dl : dlo;
+            dhi = dh < dhi ? dh : dhi;
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+        }
+        GPSIQ_HD inline void note_limit(double, double, double, double) { ok = false; }
+        GPSIQ_HD inline void room_above(double dist) { dhi = dist < dhi ? dist : dhi; }
+        GPSIQ_HD inline void room_below(double dist) { dlo = dist < dlo ? dist : dlo; }
+        GPSIQ_HD inline void fail() { ok = false; }
+        // -> the range of start offsets in units of U (Slack's lo / hi); false: not usable
+        GPSIQ_HD inline bool finish(int64_t *lo, int64_t *hi) const
+        {
+            const double unit = from_bits((uint64_t) (unit_exp - 52) << 52);
+            // Slack::note refuses values outside [2^(unit_exp - 62), 2^(unit_exp + 1)) (biased exponents) and zero / subnormals
+            if (!ok || (vmax >= vmin && (!(vmin >= from_bits((uint64_t) (unit_exp - 62) << 52)) || !(vmax < from_bits((uint64_t) (unit_exp + 1) << 52))))) return false;
+            const double inv = 1.0 / unit;                                 // a power of two: exact
+            *lo = 2 - (int64_t) __builtin_floor(dlo * inv);
+            *hi = (int64_t) __builtin_floor(dhi * inv) - 2;
+            return true;
+        }
     };
 
     // setup = setup_head (the scalars, whether the fast walk takes this addend at all) + setup_piece for every table binade
@@ -121,8 +160,8 @@ struct WalkCore {
 
     // Positive addend: from x (sample n) up to the next wrap.  true: wrapped, x is the state after the wrap (sample n);
     // false: sample ns was reached first, x is its state.
-    template <bool kNote>
-    GPSIQ_HD inline bool climb(double &x, long &n, long ns, Slack *sl) const
+    template <bool kNote, class S>
+    GPSIQ_HD inline bool climb(double &x, long &n, long ns, S *sl) const
     {
         constexpr int64_t one52 = (int64_t) 1 << 52;
         while (x < thr) {                                             // cannot wrap: x + c < thr + thr / 2^kLow
@@ -151,7 +190,7 @@ struct WalkCore {
                     sl->note(y);
                     if (kind == 0) sl->note_limit(x, y, wrap, 0x1p43);
                     const double bb = y - x, err = (x - (y - bb)) + (c - bb);     // the rounding error of x + c, exactly
-                    if (__builtin_fabs(err) == (kind == 0 ? 0x1p-44 : 0x1p-53)) sl->ok = false;   // a tie on the grid the wrap is taken on
+                    if (__builtin_fabs(err) == (kind == 0 ? 0x1p-44 : 0x1p-53)) sl->fail();   // a tie on the grid the wrap is taken on
                 }
                 x = y - wrap;
                 return true;
@@ -163,13 +202,13 @@ struct WalkCore {
     }
 
     // Negative addend (carrier only), the same downwards.
-    template <bool kNote>
-    GPSIQ_HD inline bool descend(double &x, long &n, long ns, Slack *sl) const
+    template <bool kNote, class S>
+    GPSIQ_HD inline bool descend(double &x, long &n, long ns, S *sl) const
     {
         constexpr int64_t one52 = (int64_t) 1 << 52;
         while (x >= thr) {
             if (x >= 1.0) {                                           // a wrap that rounded to exactly 1.0 (see evaluate_block)
-                if (kNote) sl->ok = false;
+                if (kNote) sl->fail();
                 x += c;
                 if (++n == ns) return false;
                 continue;
@@ -201,13 +240,12 @@ struct WalkCore {
                     // both operands are multiples of that binade's ulp and |x + c| < 2^E, so the sum is exact for this x and
                     // for every translated one (which stays in x's binade, see the note on x); only its sign has to hold
                     if ((int64_t) (bits_of(x) >> 52) == ec) {
-                        const int64_t h = (int64_t) (-y * 0x1p53) - 2;            // y + d*U < 0, two units short
-                        if (h < sl->hi) sl->hi = h;
+                        sl->room_above(-y);                                        // y + d*U < 0, two units short
                     } else {
                         sl->note(-y);
                     }
                     const double bb = r - y, err = (y - (r - bb)) + (1.0 - bb);
-                    if (r >= 1.0 || __builtin_fabs(err) == 0x1p-54) sl->ok = false;   // rounded up to 1.0, or a tie on the grid of [0.5, 1)
+                    if (r >= 1.0 || __builtin_fabs(err) == 0x1p-54) sl->fail();   // rounded up to 1.0, or a tie on the grid of [0.5, 1)
                     else sl->note(r);
                 }
                 x = r;
@@ -217,8 +255,7 @@ struct WalkCore {
                 // x <= 2|c| (and x >= |c|, the sum is not negative): x + c is exact (Sterbenz), for this x and for every
                 // translated one, whatever binade the small difference falls into -- it only has to stay non-negative
                 if (x <= -2.0 * c) {
-                    const int64_t l = 2 - (int64_t) (y * 0x1p53);
-                    if (l > sl->lo) sl->lo = l;
+                    sl->room_below(y);
                 } else {
                     sl->note(y);
                 }
@@ -228,7 +265,7 @@ struct WalkCore {
         }
     }
 
-    GPSIQ_HD inline bool cycle(double &x, long &n, long ns) const { return neg ? descend<false>(x, n, ns, nullptr) : climb<false>(x, n, ns, nullptr); }
+    GPSIQ_HD inline bool cycle(double &x, long &n, long ns) const { return neg ? descend<false>(x, n, ns, (Slack *) nullptr) : climb<false>(x, n, ns, (Slack *) nullptr); }
 };
 
 }  // namespace gpsiq

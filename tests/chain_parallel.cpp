@@ -47,7 +47,7 @@ int main(int argc, char **argv)
                 d.reserved = 0;
             }
         }
-        const int max_seg = 1 + (int) (rng() % 16);
+        const int max_seg = 1 + (int) (rng() % 32);
         std::vector<double> want((size_t) nblocks * nchan), got((size_t) nblocks * nchan);
         double want_end[16], got_end[16];
         int32_t want_prn[16], got_prn[16];

@@ -44,7 +44,7 @@ def assert_same_chain(got, want):
 
 
 @pytest.mark.parametrize("fs,nsamp", [(2.6e6, 260000), (10e6, 1000000), (25e6, 2500000), (2.6e6, 33333)])
-@pytest.mark.parametrize("stretches", [1, 5, 16])
+@pytest.mark.parametrize("stretches", [1, 5, 32])
 def test_maps_and_link_equal_the_serial_chain(fs, nsamp, stretches):
     cin = timeline(int(fs) % 997 + stretches, 40, 6)
     want = gpsiq.reference_chain(cin, fs, nsamp)
@@ -121,7 +121,7 @@ def ctx():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fs,nsamp,nblocks,nchan", [(2.6e6, 260000, 300, 16), (10e6, 1000000, 120, 12), (25e6, 2500000, 100, 16), (2.6e6, 33333, 700, 5)])
-@pytest.mark.parametrize("stretches", [3, 8, 16])
+@pytest.mark.parametrize("stretches", [3, 8, 16, 32])
 def test_device_maps_and_link_equal_the_serial_chain(ctx, fs, nsamp, nblocks, nchan, stretches):
     cin = timeline(nblocks + stretches, nblocks, nchan)
     want = gpsiq.reference_chain(cin, fs, nsamp)
