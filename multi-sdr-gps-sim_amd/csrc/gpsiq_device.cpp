@@ -103,10 +103,10 @@ struct gpsiq_ctx {
         gpsiq_chain_in_t  *d_in = nullptr, *h_in = nullptr;
         void              *d_prep = nullptr;           // lane::Prep, 32 bytes each
         gpsiq_chain_map_t *d_maps = nullptr, *h_maps = nullptr;
-        gpsiq_chain_est_t *d_est = nullptr, *h_est = nullptr;       // [2][GPSIQ_MAX_CHAN]: start, end
+        gpsiq_chain_est_t *d_est = nullptr, *h_est = nullptr;       // [3][GPSIQ_MAX_CHAN]: start, end of the first launch (= start of a second), end
         double            *d_c_before = nullptr;
         hipStream_t        stream = nullptr;
-        hipEvent_t         t0 = nullptr, t1 = nullptr;
+        hipEvent_t         t0 = nullptr, t1 = nullptr, landed = nullptr;   // landed: the maps of the last range queued are in h_maps
         float              last_ms = 0.0f;             // device time of the last call's two kernels
     } chain;
 };
@@ -271,6 +271,7 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->chain.d_c_before) (void) hipFree(c->chain.d_c_before);
     if (c->chain.t0) (void) hipEventDestroy(c->chain.t0);
     if (c->chain.t1) (void) hipEventDestroy(c->chain.t1);
+    if (c->chain.landed) (void) hipEventDestroy(c->chain.landed);
     if (c->chain.stream) (void) hipStreamDestroy(c->chain.stream);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->up_stream) (void) hipStreamDestroy(c->up_stream);
@@ -772,9 +773,10 @@ static int chain_reserve(gpsiq_ctx *c, size_t n)
         HIP_TRY(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&k.t0));
         HIP_TRY(hipEventCreate(&k.t1));
-        HIP_TRY(hipMalloc((void **) &k.d_est, 2 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t)));
-        HIP_TRY(hipHostMalloc((void **) &k.h_est, 2 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t), hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **) &k.d_c_before, GPSIQ_MAX_CHAN * sizeof(double)));
+        HIP_TRY(hipEventCreateWithFlags(&k.landed, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **) &k.d_est, 3 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t)));
+        HIP_TRY(hipHostMalloc((void **) &k.h_est, 3 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &k.d_c_before, 2 * GPSIQ_MAX_CHAN * sizeof(double)));
     }
     if (n <= k.cap) return GPSIQ_OK;
     if (k.d_in) (void) hipFree(k.d_in);
@@ -793,27 +795,43 @@ static int chain_reserve(gpsiq_ctx *c, size_t n)
     return GPSIQ_OK;
 }
 
-// level 1 of the chain for the inputs staged in c->chain.h_in: upload, two kernels, the maps back in c->chain.h_maps
-static int chain_maps_staged(gpsiq_ctx *c, int nblocks, int nchan, double fs, int nsamp, const gpsiq_chain_est_t *start, int max_stretches,
-                             gpsiq_chain_est_t *end)
+// Level 1 of the chain for blocks [b0, b0 + nb) of the inputs staged in c->chain.h_in, queued on the chain stream without
+// waiting: upload, two kernels, the maps back into c->chain.h_maps (same rows), `landed` recorded behind them.  part 0 starts
+// from `start` (host, may be null: the timeline begins here); part 1 continues where part 0's scan ended, on the device.
+static int chain_queue(gpsiq_ctx *c, int part, int b0, int nb, int nchan, double fs, int nsamp, const gpsiq_chain_est_t *start, int max_stretches)
 {
     gpsiq_ctx::Chain &k = c->chain;
-    const size_t n = (size_t) nblocks * (size_t) nchan;
+    const size_t off = (size_t) b0 * (size_t) nchan, n = (size_t) nb * (size_t) nchan;
     if (max_stretches <= 0) {
         max_stretches = 16;
         if (const char *e = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) max_stretches = v; }
     }
-    HIP_TRY(hipMemcpyAsync(k.d_in, k.h_in, n * sizeof(gpsiq_chain_in_t), hipMemcpyHostToDevice, k.stream));
-    if (start) {
+    HIP_TRY(hipMemcpyAsync(k.d_in + off, k.h_in + off, n * sizeof(gpsiq_chain_in_t), hipMemcpyHostToDevice, k.stream));
+    const gpsiq_chain_est_t *d_start = nullptr;
+    if (part == 1) d_start = k.d_est + GPSIQ_MAX_CHAN;
+    else if (start) {
         std::memcpy(k.h_est, start, (size_t) nchan * sizeof(gpsiq_chain_est_t));
         HIP_TRY(hipMemcpyAsync(k.d_est, k.h_est, (size_t) nchan * sizeof(gpsiq_chain_est_t), hipMemcpyHostToDevice, k.stream));
+        d_start = k.d_est;
     }
-    HIP_TRY(hipEventRecord(k.t0, k.stream));
-    HIP_TRY(launch_chain(k.d_in, nblocks, nchan, 1.0 / fs, nsamp, start ? k.d_est : nullptr, max_stretches, k.d_prep, k.d_c_before,
-                         k.d_est + GPSIQ_MAX_CHAN, k.d_maps, k.stream));
+    if (part == 0) HIP_TRY(hipEventRecord(k.t0, k.stream));
+    HIP_TRY(launch_chain(k.d_in + off, nb, nchan, 1.0 / fs, nsamp, d_start, max_stretches, static_cast<char *>(k.d_prep) + off * 32,
+                         k.d_c_before + part * GPSIQ_MAX_CHAN, k.d_est + (part + 1) * GPSIQ_MAX_CHAN, k.d_maps + off, k.stream));
     HIP_TRY(hipEventRecord(k.t1, k.stream));
-    HIP_TRY(hipMemcpyAsync(k.h_maps, k.d_maps, n * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, k.stream));
-    HIP_TRY(hipMemcpyAsync(k.h_est + GPSIQ_MAX_CHAN, k.d_est + GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(hipMemcpyAsync(k.h_maps + off, k.d_maps + off, n * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(hipMemcpyAsync(k.h_est + (part + 1) * GPSIQ_MAX_CHAN, k.d_est + (part + 1) * GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t),
+                           hipMemcpyDeviceToHost, k.stream));
+    HIP_TRY(hipEventRecord(k.landed, k.stream));
+    return GPSIQ_OK;
+}
+
+// ... and waited for
+static int chain_maps_staged(gpsiq_ctx *c, int nblocks, int nchan, double fs, int nsamp, const gpsiq_chain_est_t *start, int max_stretches,
+                             gpsiq_chain_est_t *end)
+{
+    gpsiq_ctx::Chain &k = c->chain;
+    int rc = chain_queue(c, 0, 0, nblocks, nchan, fs, nsamp, start, max_stretches);
+    if (rc) { (void) hipStreamSynchronize(k.stream); return rc; }
     HIP_TRY(hipStreamSynchronize(k.stream));
     (void) hipEventElapsedTime(&k.last_ms, k.t0, k.t1);
     if (end) std::memcpy(end, k.h_est + GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t));
@@ -840,33 +858,31 @@ extern "C" int gpsiq_chain_maps_device(gpsiq_ctx_t *c, const gpsiq_chain_in_t *i
     return GPSIQ_OK;
 }
 
-// The start state of every block of a batch (-> start[nblocks][nchan]) and the state after it: chain inputs cut out of the
-// descriptors on host threads, level 1 on the device, level 2 here.  Timelines too short to fill a launch stay with the host's
-// serial walk (RefWalk's chain tasks), as does everything when GPSIQ_CHAIN=host.
-static bool chain_on_device(int nblocks)
+// Whether a GPSIQ_NCO_REFERENCE batch walks level 1 of its carrier chain on the device.  The serial walk on host threads costs
+// ~2.2 us per block and channel on each of min(threads, channels) threads and hides under the kernel of the piece before when
+// the kernel is the slower side (25 Msps on sixteen threads); level 1 on the device costs a launch latency of ~0.25 ms before
+// anything renders and nearly nothing after that.  GPSIQ_CHAIN=host / device decides by hand (read per call: A/B in one process).
+static bool chain_on_device(int nblocks, int nsamp, int nchan)
 {
-    const char *e = std::getenv("GPSIQ_CHAIN");               // read per call: A/B in one process
+    const char *e = std::getenv("GPSIQ_CHAIN");
     if (e && !std::strcmp(e, "host")) return false;
-    if (e && !std::strcmp(e, "device")) return nblocks > 0;
-    return nblocks >= 48;
+    if (e && !std::strcmp(e, "device")) return nblocks > 1;
+    if (nblocks < 48) return false;
+    const int threads = host_threads() < nchan ? host_threads() : nchan;
+    const double t_kernel = (double) nsamp * (double) nchan / 6.0e12;
+    const double t_chain = 2.2e-6 * (double) nchan / (double) (threads > 0 ? threads : 1);
+    return t_chain > 0.5 * t_kernel;
 }
 
-static int chain_level1_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs, double *t_ms /* [2] or null: inputs, level 1 */)
+// chain inputs of blocks [b0, b1) cut out of the descriptors into the page-locked staging: 296-byte descriptors, 24 bytes wanted
+// of each -- memory-bound, so spread over the pool
+static void chain_stage_inputs(gpsiq_ctx *c, const gpsiq_chan_t *ch, int b0, int b1, int nchan)
 {
-    const size_t n = (size_t) nblocks * (size_t) nchan;
-    const double t0 = t_ms ? wall_ms() : 0.0;
-    int rc = chain_reserve(c, n);
-    if (rc) return rc;
-    struct Job { const gpsiq_chan_t *ch; gpsiq_chain_in_t *out; } job = {ch, c->chain.h_in};
-    // 296-byte descriptors, 24 bytes wanted of each: memory-bound, so spread over the pool
-    parallel_for((int) n, 0, 2048, [](void *p, int k0, int k1) {
+    struct Job { const gpsiq_chan_t *ch; gpsiq_chain_in_t *out; } job = {ch + (size_t) b0 * nchan, c->chain.h_in + (size_t) b0 * nchan};
+    parallel_for((b1 - b0) * nchan, (b1 - b0) * nchan >= 8192 ? 0 : 1, 2048, [](void *p, int k0, int k1) {
         const Job &j = *static_cast<Job *>(p);
         gpsiq_chain_inputs(j.ch + k0, k1 - k0, j.out + k0);
     }, &job);
-    const double t1 = t_ms ? wall_ms() : 0.0;
-    rc = chain_maps_staged(c, nblocks, nchan, fs, nsamp, nullptr, 0, nullptr);
-    if (t_ms) { t_ms[0] = t1 - t0; t_ms[1] = wall_ms() - t1; }
-    return rc;
 }
 
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
@@ -890,27 +906,56 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     const int chunk = ref_chunk_blocks(nblocks, nsamp);
     std::vector<int> ends;
     piece_ends(0, nblocks, chunk, &ends, ref_kernel_bound(nsamp, nchan));
-    // the carrier chain: level 1 (every block's certified map) on the device, parallel in time (gpsiq_chain_kernels.hip), when the
-    // timeline is long enough to be worth two launches; the chain tasks then link block to block through the maps
-    double t_chain[2] = {};
-    const bool dev_chain = !seeds && chain_on_device(nblocks);
+    // The carrier chain: level 1 (every block's certified map) on the device, parallel in time (gpsiq_chain_kernels.hip); the chain
+    // tasks then link block to block through the maps.  Nothing renders before the first maps are back, and a launch is ~0.25 ms
+    // however small: the timeline goes in two launches -- a head whose kernels cover the second launch, then the rest --, and the
+    // walkers are let into the rest when its maps have landed (RefWalk::release_maps).
+    double t_chain[3] = {};
+    const bool dev_chain = !seeds && chain_on_device(nblocks, nsamp, nchan);
+    int head = nblocks;
     if (dev_chain) {
-        rc = chain_level1_device(c, ch, nblocks, nchan, nsamp, fs, trace ? t_chain : nullptr);
+        rc = chain_reserve(c, (size_t) nblocks * (size_t) nchan);
         if (rc) return rc;
-        if (trace)
-            std::fprintf(stderr, "[gpsiq trace] carrier chain, level 1 on the device: inputs %.3f ms, upload + kernels (%.3f ms) + maps back %.3f ms\n",
-                         t_chain[0], (double) c->chain.last_ms, t_chain[1]);
+        // the head: pieces worth ~0.5 ms of synthesis (the second launch's latency + its first piece's evaluation)
+        const double t_block = (double) nsamp * (double) nchan / 6.0e12;
+        int want = (int) (0.5e-3 / t_block) + 1;
+        if (const char *e = std::getenv("GPSIQ_CHAIN_HEAD")) want = std::atoi(e);            // blocks; <= 0: one launch (A/B)
+        if (want > 0 && 2 * want < nblocks)
+            for (size_t k = 0; k < ends.size(); ++k)
+                if (ends[k] >= want) { head = ends[k]; break; }
+        if (2 * head > nblocks) head = nblocks;
+        const double tc0 = trace ? wall_ms() : 0.0;
+        chain_stage_inputs(c, ch, 0, head, nchan);
+        rc = chain_queue(c, 0, 0, head, nchan, fs, nsamp, nullptr, 0);
+        if (rc == GPSIQ_OK && head < nblocks) {
+            hipEvent_t head_landed = c->chain.t0;                                          // (t0 is free again: only t1 is read below)
+            HIP_TRY(hipEventRecord(head_landed, c->chain.stream));
+            chain_stage_inputs(c, ch, head, nblocks, nchan);                               // under the head's kernels
+            rc = chain_queue(c, 1, head, nblocks - head, nchan, fs, nsamp, nullptr, 0);
+            if (rc == GPSIQ_OK) HIP_TRY(hipEventSynchronize(head_landed));
+        } else if (rc == GPSIQ_OK) HIP_TRY(hipStreamSynchronize(c->chain.stream));
+        if (rc) { (void) hipStreamSynchronize(c->chain.stream); return rc; }
+        if (trace) t_chain[0] = wall_ms() - tc0;
     }
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
     if (!seeds) w.start_out = c->ref_start.data();
-    if (dev_chain) { w.in = c->chain.h_in; w.maps = c->chain.h_maps; }
+    if (dev_chain) { w.in = c->chain.h_in; w.maps = c->chain.h_maps; w.maps_upto.store(head); }
+    bool rest_released = head >= nblocks;
     // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
     // thread, and this thread renders every piece as soon as all channels are through it
     pthread_t th;
     const bool threaded = w.npieces() > 1 && pthread_create(&th, nullptr, run_walk, &w) == 0;
     if (!threaded) w.run();
     for (size_t k = 0; k < w.npieces() && rc == GPSIQ_OK; ++k) {
+        if (!rest_released && w.ends[k] > head) {             // the first piece beyond the head: by now its maps have (nearly) landed
+            const double tr = trace ? wall_ms() : 0.0;
+            const hipError_t he = hipEventSynchronize(c->chain.landed);
+            if (he != hipSuccess) { rc = fail(GPSIQ_E_DEVICE, "carrier chain, level 1: %s", hipGetErrorString(he)); break; }
+            w.release_maps(nblocks);
+            rest_released = true;
+            if (trace) { t_chain[1] = wall_ms() - tr; t_chain[2] = wall_ms() - t0; }
+        }
         const double tw = trace ? wall_ms() : 0.0;
         rc = w.wait_piece(k);
         if (rc != GPSIQ_OK) { (void) fail(rc, "%s", w.err); break; }
@@ -929,12 +974,16 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) { std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); w.abort(); }     // nothing further is walked for a call that has failed
+    if (!rest_released) { (void) hipStreamSynchronize(c->chain.stream); w.release_maps(nblocks); }   // (an aborted walk: its tasks still finish)
     if (threaded) pthread_join(th, nullptr);                 // the walkers read ch and write q: never leave them running
     const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();
     if (rc != GPSIQ_OK) return fail(rc, "%s", err);
     if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
     if (frc != GPSIQ_OK) return frc;
+    if (trace && dev_chain)
+        std::fprintf(stderr, "[gpsiq trace] carrier chain, level 1 on the device: head of %d blocks staged + walked + back after %.3f ms; the rest waited "
+                             "for %.3f ms, let in at %.3f ms\n", head, t_chain[0], t_chain[1], t_chain[2]);
     if (trace)
         std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in %zu pieces of %d: waited for the walkers %.2f ms (%zu patches), "
                              "validate + upload + launch %.2f ms, final wait %.2f ms, whole call %.2f ms\n",
