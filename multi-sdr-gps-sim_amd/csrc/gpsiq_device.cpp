@@ -803,7 +803,7 @@ static int chain_queue(gpsiq_ctx *c, int part, int b0, int nb, int nchan, double
     gpsiq_ctx::Chain &k = c->chain;
     const size_t off = (size_t) b0 * (size_t) nchan, n = (size_t) nb * (size_t) nchan;
     if (max_stretches <= 0) {
-        max_stretches = 16;
+        max_stretches = 32;
         if (const char *e = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) max_stretches = v; }
     }
     HIP_TRY(hipMemcpyAsync(k.d_in + off, k.h_in + off, n * sizeof(gpsiq_chain_in_t), hipMemcpyHostToDevice, k.stream));
@@ -916,46 +916,45 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     if (dev_chain) {
         rc = chain_reserve(c, (size_t) nblocks * (size_t) nchan);
         if (rc) return rc;
-        // the head: pieces worth ~0.5 ms of synthesis (the second launch's latency + its first piece's evaluation)
+        // the head: pieces worth ~0.4 ms of synthesis (the second launch's latency + its first piece's evaluation)
         const double t_block = (double) nsamp * (double) nchan / 6.0e12;
-        int want = (int) (0.5e-3 / t_block) + 1;
+        int want = (int) (0.4e-3 / t_block) + 1;
         if (const char *e = std::getenv("GPSIQ_CHAIN_HEAD")) want = std::atoi(e);            // blocks; <= 0: one launch (A/B)
         if (want > 0 && 2 * want < nblocks)
             for (size_t k = 0; k < ends.size(); ++k)
                 if (ends[k] >= want) { head = ends[k]; break; }
         if (2 * head > nblocks) head = nblocks;
-        const double tc0 = trace ? wall_ms() : 0.0;
-        chain_stage_inputs(c, ch, 0, head, nchan);
-        rc = chain_queue(c, 0, 0, head, nchan, fs, nsamp, nullptr, 0);
-        if (rc == GPSIQ_OK && head < nblocks) {
-            hipEvent_t head_landed = c->chain.t0;                                          // (t0 is free again: only t1 is read below)
-            HIP_TRY(hipEventRecord(head_landed, c->chain.stream));
-            chain_stage_inputs(c, ch, head, nblocks, nchan);                               // under the head's kernels
-            rc = chain_queue(c, 1, head, nblocks - head, nchan, fs, nsamp, nullptr, 0);
-            if (rc == GPSIQ_OK) HIP_TRY(hipEventSynchronize(head_landed));
-        } else if (rc == GPSIQ_OK) HIP_TRY(hipStreamSynchronize(c->chain.stream));
-        if (rc) { (void) hipStreamSynchronize(c->chain.stream); return rc; }
-        if (trace) t_chain[0] = wall_ms() - tc0;
     }
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
     if (!seeds) w.start_out = c->ref_start.data();
-    if (dev_chain) { w.in = c->chain.h_in; w.maps = c->chain.h_maps; w.maps_upto.store(head); }
-    bool rest_released = head >= nblocks;
+    struct Landed { RefWalk *w; int upto; double *at, t0; };
+    Landed landed[2] = {{&w, head, &t_chain[1], t0}, {&w, nblocks, &t_chain[2], t0}};
+    // runs on a thread of the HIP runtime when the maps of a launch are in host memory: the walkers may link through them
+    auto on_landed = [](void *p) {
+        Landed *l = static_cast<Landed *>(p);
+        if (l->t0 != 0.0) *l->at = wall_ms() - l->t0;
+        l->w->release_maps(l->upto);
+    };
+    if (dev_chain) {
+        w.in = c->chain.h_in; w.maps = c->chain.h_maps; w.maps_upto.store(0);
+        chain_stage_inputs(c, ch, 0, head, nchan);
+        rc = chain_queue(c, 0, 0, head, nchan, fs, nsamp, nullptr, 0);
+        if (rc == GPSIQ_OK && hipLaunchHostFunc(c->chain.stream, on_landed, &landed[0]) != hipSuccess) rc = fail(GPSIQ_E_DEVICE, "hipLaunchHostFunc");
+        if (rc == GPSIQ_OK && head < nblocks) {
+            chain_stage_inputs(c, ch, head, nblocks, nchan);                               // under the head's kernels
+            rc = chain_queue(c, 1, head, nblocks - head, nchan, fs, nsamp, nullptr, 0);
+            if (rc == GPSIQ_OK && hipLaunchHostFunc(c->chain.stream, on_landed, &landed[1]) != hipSuccess) rc = fail(GPSIQ_E_DEVICE, "hipLaunchHostFunc");
+        }
+        if (rc) { (void) hipStreamSynchronize(c->chain.stream); return rc; }
+        if (trace) t_chain[0] = wall_ms() - t0;
+    }
     // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
     // thread, and this thread renders every piece as soon as all channels are through it
     pthread_t th;
     const bool threaded = w.npieces() > 1 && pthread_create(&th, nullptr, run_walk, &w) == 0;
     if (!threaded) w.run();
     for (size_t k = 0; k < w.npieces() && rc == GPSIQ_OK; ++k) {
-        if (!rest_released && w.ends[k] > head) {             // the first piece beyond the head: by now its maps have (nearly) landed
-            const double tr = trace ? wall_ms() : 0.0;
-            const hipError_t he = hipEventSynchronize(c->chain.landed);
-            if (he != hipSuccess) { rc = fail(GPSIQ_E_DEVICE, "carrier chain, level 1: %s", hipGetErrorString(he)); break; }
-            w.release_maps(nblocks);
-            rest_released = true;
-            if (trace) { t_chain[1] = wall_ms() - tr; t_chain[2] = wall_ms() - t0; }
-        }
         const double tw = trace ? wall_ms() : 0.0;
         rc = w.wait_piece(k);
         if (rc != GPSIQ_OK) { (void) fail(rc, "%s", w.err); break; }
@@ -974,7 +973,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) { std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); w.abort(); }     // nothing further is walked for a call that has failed
-    if (!rest_released) { (void) hipStreamSynchronize(c->chain.stream); w.release_maps(nblocks); }   // (an aborted walk: its tasks still finish)
+    if (dev_chain) (void) hipStreamSynchronize(c->chain.stream);      // the callbacks have run: every chain task is runnable, also of an aborted walk
     if (threaded) pthread_join(th, nullptr);                 // the walkers read ch and write q: never leave them running
     const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();
@@ -982,8 +981,8 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     if (w.rc != GPSIQ_OK) return fail(w.rc, "%s", w.err);
     if (frc != GPSIQ_OK) return frc;
     if (trace && dev_chain)
-        std::fprintf(stderr, "[gpsiq trace] carrier chain, level 1 on the device: head of %d blocks staged + walked + back after %.3f ms; the rest waited "
-                             "for %.3f ms, let in at %.3f ms\n", head, t_chain[0], t_chain[1], t_chain[2]);
+        std::fprintf(stderr, "[gpsiq trace] carrier chain, level 1 on the device: two launches queued by %.3f ms; the maps of the head (%d blocks) back at "
+                             "%.3f ms, of the rest at %.3f ms\n", t_chain[0], head, t_chain[1], t_chain[2]);
     if (trace)
         std::fprintf(stderr, "[gpsiq trace] reference NCO, %d blocks in %zu pieces of %d: waited for the walkers %.2f ms (%zu patches), "
                              "validate + upload + launch %.2f ms, final wait %.2f ms, whole call %.2f ms\n",

@@ -1,0 +1,51 @@
+"""A/B of the knobs of the device carrier chain inside gpsiq_generate_batch (GPSIQ_NCO_REFERENCE): GPSIQ_CHAIN_HEAD,
+GPSIQ_CHAIN_STRETCHES, GPSIQ_REF_CHUNK_BLOCKS, and one GPSIQ_TRACE=2 timeline of the default.  Run on the GPU box."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+import gpsiq  # noqa: E402
+from gpsiq.abi import NCO_REFERENCE  # noqa: E402
+from gpsiq.scenario import synth_blocks  # noqa: E402
+import torch  # noqa: E402
+
+
+def best(fn, n=8):
+    t = float("inf")
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        t = min(t, time.perf_counter() - t0)
+    return t
+
+
+def main():
+    ctx = gpsiq.Context(0)
+    ring = torch.empty(2 << 30, dtype=torch.uint8, device="cuda:0")
+    pat = synth_blocks(64, 16)
+    ctx.set_nco_mode(NCO_REFERENCE)
+    for label, fs, ss, nb in (("2M6_int8", 2.6e6, 1, 2000), ("10M_int16", 10e6, 2, 536), ("25M_int16", 25e6, 2, 200)):
+        ns = int(round(fs / 10))
+        d = pat[np.arange(nb) % 64]
+        call = lambda: ctx.generate_batch(d, ns, fs, ss, device_ptr=ring.data_ptr())  # noqa: E731
+        call()
+        os.environ["GPSIQ_TRACE"] = "2"
+        call()
+        del os.environ["GPSIQ_TRACE"]
+        print(f"{label}: default {best(call) * 1e3:.3f} ms", flush=True)
+        for knob, values in (("GPSIQ_CHAIN_HEAD", ("0", "64", "128", "256", "384", "600")), ("GPSIQ_CHAIN_STRETCHES", ("8", "16", "32")),
+                             ("GPSIQ_REF_CHUNK_BLOCKS", ("64", "128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device"))):
+            for v in values:
+                os.environ[knob] = v
+                call()
+                print(f"  {knob}={v}: {best(call) * 1e3:.3f} ms", flush=True)
+            del os.environ[knob]
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
