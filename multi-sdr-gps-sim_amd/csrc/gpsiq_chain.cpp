@@ -92,12 +92,12 @@ static void map_block(const Prep *prep, int nchan, int i, int b, double c_before
     std::memset(&r, 0, sizeof r);
     *rec = r;
     if ((p.flags & lane::kSkip) || !(std::fabs(p.c) < 0.5) || p.c == 0.0) return;
-    if (!(*w_c == p.c)) { W->setup(p.c, 1); *w_c = p.c; }
+    if (!(*w_c == p.c)) { W->setup(p.c); *w_c = p.c; }
     const lane::Walker *prev = nullptr;
     if (!(p.flags & lane::kSeed)) {
         const double cp = b > 0 ? prep[(size_t) (b - 1) * nchan + i].c : c_before;
         if (cp == 0.0 || !(std::fabs(cp) < 0.5)) return;
-        if (!(*wp_c == cp)) { Wp->setup(cp, 1); *wp_c = cp; }
+        if (!(*wp_c == cp)) { Wp->setup(cp); *wp_c = cp; }
         prev = Wp;
     }
     if (W->general) return;

@@ -167,14 +167,14 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
         if (b < 0) c = c_before[i];
         else if (b < nblocks) { const Prep p = prep[(size_t) b * nchan + i]; c = (p.flags & lane::kSkip) ? 0.0 : p.c; }
         const bool ok = c != 0.0 && __builtin_fabs(c) < 0.5;
-        walker[tid].setup_head(ok ? c : 0.25, 1);              // an addend the walk does not take: general, never walked
+        walker[tid].setup_head(ok ? c : 0.25);              // an addend the walk does not take: general, never walked
         usable[tid] = ok && !walker[tid].general;
     }
     __syncthreads();
     // their tables: one (addend, binade) pair per thread and round -- a 64-bit division each
     for (int q = tid; q < (kBlocks + 1) * lane::kTab; q += kLaneThreads) {
         const int w = q / lane::kTab, s = q % lane::kTab;
-        if (usable[w] && s > Walker::kLow && s <= (int) (walker[w].top_exp - walker[w].ec)) walker[w].setup_piece(s);
+        if (usable[w] && s > Walker::kLow && s <= (int) (1022 - walker[w].ec)) walker[w].setup_piece(s);
     }
     __syncthreads();
     const int blk = tid / kSeg, t = tid % kSeg, b = b0 + blk;

@@ -33,7 +33,7 @@ typedef unsigned __int128 u128;
 
 constexpr int kTab = 22;                 // table binades of a lane's walker: |c| >= 2^-22 cycle per sample (slower blocks hold no wrap to start from)
 constexpr int kMaxSeg = 32;              // stretches per block at most
-typedef WalkCore<kTab> Walker;
+typedef FpWalk<kTab> Walker;                 // (WalkCore<kTab> is the same walk on integer mantissas: twice the device time)
 constexpr double kU = 0x1p-53;           // the unit of every offset here
 
 // what a block needs besides its own addend: 32 bytes per channel and block, written by prepare (scan over the timeline)
@@ -202,7 +202,7 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
     *out = o;
     if ((p.flags & kSkip) || W.general || !(p.c != 0.0)) return;
     const long a0 = (long) (((int64_t) t * nsamp) / nseg), a1 = (long) (((int64_t) (t + 1) * nsamp) / nseg);
-    typename Walker::FastSlack sl;
+    typename WalkCore<kTab>::FastSlack sl;
     sl.init(W.neg ? 1022 : 1023);
     double x;
     long n;

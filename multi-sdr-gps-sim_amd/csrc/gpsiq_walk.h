@@ -268,5 +268,183 @@ struct WalkCore {
     GPSIQ_HD inline bool cycle(double &x, long &n, long ns) const { return neg ? descend<false>(x, n, ns, (Slack *) nullptr) : climb<false>(x, n, ns, (Slack *) nullptr); }
 };
 
+
+// The carrier walk once more with the table steps in FLOATING POINT, for the lanes of the time-parallel chain (gpsiq_lane.h).
+// WalkCore moves a state inside a binade on its 53-bit integer mantissa (64-bit integer adds, compares and a multiply per
+// step: pairs of 32-bit instructions on the device, a third of them quarter rate); but every quantity there is an integer
+// below 2^53 times the binade's ulp u, so the same step is EXACT in doubles: the distance to the binade's edge x - 2^e, the
+// comparisons with rem*u and (rem + dm)*u, the jump x + k*dm*u (the result is a state of the binade: representable).  The
+// plain additions at the binade crossings, the wraps and the low binades are WalkCore's own lines.  The one step that needs a
+// division (a run entered in the middle of a binade: the first step of a walk) goes back to integers.  Same results, same
+// notes: tests/chain_parallel.cpp holds FpWalk against WalkCore state for state, and the chain built on it against the
+// serial chain (NcoWalk) bit for bit.  Carrier only (wrap into [0, 1)).
+template <int kTab>
+struct FpWalk {
+    struct Piece { double S, kS, rem_t, span_t; int32_t k, tie; };     // step, k steps, the two thresholds on the distance (see dist())
+    static constexpr int kLow = GPSIQ_WALK_KLOW;
+    double  c, thr;
+    int64_t ec;
+    bool    neg, general;
+    Piece   F[kTab];
+
+    GPSIQ_HD void setup_head(double addend)
+    {
+        c = addend;
+        const uint64_t bc = bits_of(c) & ~(UINT64_C(1) << 63);
+        ec = (int64_t) (bc >> 52);
+        const int64_t mc = (int64_t) ((bc & kMant) | (kMant + 1));
+        neg = c < 0.0;
+        general = ec > 1022 - 6 || ec < 1022 - 40 || 1022 - ec >= kTab;
+        if (!general && neg) {                                   // an exact tie in the top binade of a descending carrier: WalkCore::setup_head
+            const int top = (int) (1022 - ec);
+            if ((mc & (((int64_t) 1 << top) - 1)) == (int64_t) 1 << (top - 1)) general = true;
+        }
+        thr = general ? 0.0 : from_bits((uint64_t) (ec + kLow + 1) << 52);
+    }
+
+    // the integer piece of binade ec + s (WalkCore::setup_piece)
+    GPSIQ_HD inline void int_piece(int s, int64_t *dm_, int64_t *span_, bool *tie_) const
+    {
+        const int64_t mc = (int64_t) ((bits_of(c) & kMant) | (kMant + 1));
+        int64_t dm = mc >> s;
+        const int64_t rem = mc & (((int64_t) 1 << s) - 1), half = (int64_t) 1 << (s - 1);
+        bool tie = false;
+        if (rem > half) ++dm;
+        else if (rem == half) { tie = true; dm += dm & 1; }
+        *dm_ = dm; *tie_ = tie;
+        *span_ = neg ? ((int64_t) 1 << 52) - 2 : ((int64_t) 1 << 52) - 1;
+    }
+
+    GPSIQ_HD void setup_piece(int s)
+    {
+        int64_t dm, span;
+        bool tie;
+        int_piece(s, &dm, &span, &tie);
+        const int64_t k = span / dm, kdm = k * dm, rem = span - kdm;
+        const double u = from_bits((uint64_t) (ec + s - 52) << 52);            // the binade's ulp
+        Piece &p = F[s];
+        p.S = (double) dm * u; p.kS = (double) kdm * u; p.k = (int32_t) k; p.tie = tie ? 1 : 0;
+        // upwards the distance is x - 2^e = off*u; downwards 2^(e+1) - x = (off + 1)*u with off = 2^53 - 1 - mx
+        p.rem_t = (double) (neg ? rem + 1 : rem) * u;
+        p.span_t = (double) (neg ? span + 1 : span) * u;
+    }
+
+    GPSIQ_HD void setup(double addend)
+    {
+        setup_head(addend);
+        if (general) return;
+        for (int s = kLow + 1; s <= (int) (1022 - ec); ++s) setup_piece(s);
+    }
+
+    // the run from x inside a table binade: steps and distance moved.  dist: the distance the thresholds are written for.
+    GPSIQ_HD inline void run_of(uint64_t bx, double dist, int32_t *run, double *moved) const
+    {
+        const int s = (int) ((int64_t) (bx >> 52) - ec);
+        const Piece &p = F[s];
+        if (p.tie && (bx & 1)) { *run = 0; *moved = 0.0; }              // an odd mantissa in a tie binade: one real addition first
+        else if (dist <= p.rem_t) { *run = p.k; *moved = p.kS; }
+        else if (dist <= p.rem_t + p.S) { *run = p.k - 1; *moved = p.kS - p.S; }
+        else if (dist > p.span_t) { *run = 0; *moved = 0.0; }
+        else {                                                          // entered in the middle of the binade: the division, on integers
+            int64_t dm, span;
+            bool tie;
+            int_piece(s, &dm, &span, &tie);
+            const int64_t mx = (int64_t) ((bx & kMant) | (kMant + 1));
+            const int64_t off = neg ? (((int64_t) 1 << 53) - 1) - mx : mx - ((int64_t) 1 << 52);
+            const int64_t r = (span - off) / dm;
+            *run = (int32_t) r;
+            *moved = (double) (r * dm) * from_bits((uint64_t) ((bx >> 52) - 52) << 52);
+        }
+    }
+
+    template <bool kNote, class Sl>
+    GPSIQ_HD inline bool climb(double &x, long &n, long ns, Sl *sl) const
+    {
+        while (x < thr) {                                             // cannot wrap: x + c < thr + thr / 2^kLow
+            x += c;
+            if (kNote) sl->note(x);
+            if (++n == ns) return false;
+        }
+        for (;;) {                                                    // x in [thr, 1)
+            const uint64_t bx = bits_of(x);
+            const double edge = from_bits(bx & ~kMant);
+            int32_t run;
+            double moved;
+            run_of(bx, x - edge, &run, &moved);
+            if ((long) run >= ns - n) { x += (double) (ns - n) * F[(int64_t) (bx >> 52) - ec].S; n = ns; if (kNote) sl->note(x); return false; }
+            x += moved;
+            n += run;
+            if (kNote && run) sl->note(x);
+            const double y = x + c;                                   // leaves the binade, or wraps
+            ++n;
+            if (y >= 1.0) {
+                if (kNote) {
+                    sl->note(y);
+                    const double bb = y - x, err = (x - (y - bb)) + (c - bb);     // the rounding error of x + c, exactly
+                    if (__builtin_fabs(err) == 0x1p-53) sl->fail();               // a tie on the grid the wrap is taken on
+                }
+                x = y - 1.0;
+                return true;
+            }
+            x = y;
+            if (kNote) sl->note(x);
+            if (n == ns) return false;
+        }
+    }
+
+    template <bool kNote, class Sl>
+    GPSIQ_HD inline bool descend(double &x, long &n, long ns, Sl *sl) const
+    {
+        while (x >= thr) {
+            if (x >= 1.0) {                                           // a wrap that rounded to exactly 1.0
+                if (kNote) sl->fail();
+                x += c;
+                if (++n == ns) return false;
+                continue;
+            }
+            const uint64_t bx = bits_of(x);
+            const double edge = from_bits(bx & ~kMant);
+            int32_t run;
+            double moved;
+            run_of(bx, (edge + edge) - x, &run, &moved);
+            if ((long) run >= ns - n) { x -= (double) (ns - n) * F[(int64_t) (bx >> 52) - ec].S; n = ns; if (kNote) sl->note(x); return false; }
+            x -= moved;
+            n += run;
+            if (kNote && run) sl->note(x);
+            x += c;                                                   // into the binade underneath; x >= thr >= 2^kLow |c|: still positive
+            if (kNote) sl->note(x);
+            if (++n == ns) return false;
+        }
+        for (;;) {                                                    // x < thr: plain additions until the sum turns negative (WalkCore::descend)
+            const double y = x + c;
+            ++n;
+            if (y < 0.0) {
+                const double r = y + 1.0;
+                if (kNote) {
+                    if ((int64_t) (bits_of(x) >> 52) == ec) sl->room_above(-y);
+                    else sl->note(-y);
+                    const double bb = r - y, err = (y - (r - bb)) + (1.0 - bb);
+                    if (r >= 1.0 || __builtin_fabs(err) == 0x1p-54) sl->fail();
+                    else sl->note(r);
+                }
+                x = r;
+                return true;
+            }
+            if (kNote) {
+                if (x <= -2.0 * c) sl->room_below(y);
+                else sl->note(y);
+            }
+            x = y;
+            if (n == ns) return false;
+        }
+    }
+
+    struct NoSlack { GPSIQ_HD void note(double) {} GPSIQ_HD void room_above(double) {} GPSIQ_HD void room_below(double) {} GPSIQ_HD void fail() {} };
+    GPSIQ_HD inline bool cycle(double &x, long &n, long ns) const
+    {
+        return neg ? descend<false>(x, n, ns, (NoSlack *) nullptr) : climb<false>(x, n, ns, (NoSlack *) nullptr);
+    }
+};
+
 }  // namespace gpsiq
 #endif

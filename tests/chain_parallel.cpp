@@ -9,12 +9,65 @@
 
 using namespace gpsiq;
 
+// FpWalk (the lanes' walker: table steps in doubles) against WalkCore (integer mantissas), state for state and note for note
+static long walkers_agree(std::mt19937_64 &rng, int cases)
+{
+    std::uniform_real_distribution<double> up(0.0, 1.0);
+    long bad = 0;
+    for (int it = 0; it < cases; ++it) {
+        const double fs = (it % 4 == 0) ? 25e6 : (it % 4 == 1) ? 10e6 : (it % 4 == 2 ? 2.6e6 : 2097152.0);
+        double f = (up(rng) * 2 - 1) * 9000;
+        if (it % 11 == 0) f = (up(rng) * 2 - 1) * 40;
+        double c = f / fs;
+        if (it % 7 >= 4) { uint64_t b = bits_of(c); const int z = 8 + (int) (rng() % 40); b &= ~((UINT64_C(1) << z) - 1); if (it % 7 >= 5) b |= UINT64_C(1) << z; c = from_bits(b); }
+        WalkCore<lane::kTab> a;
+        FpWalk<lane::kTab> b;
+        a.setup(c, 1);
+        b.setup(c);
+        if (a.general != b.general) { if (bad++ < 5) std::printf("walkers: general differs for c = %a\n", c); continue; }
+        if (a.general) continue;
+        for (int rep = 0; rep < 4; ++rep) {
+            double x0 = up(rng);
+            if (rep == 1) x0 = std::ldexp((double) (rng() >> 11), -53);                       // any state of the top grid
+            if (rep == 2) x0 = std::ldexp(1.0, -(int) (rng() % 30)) * (1.0 + std::ldexp((double) (rng() % 5), -52));   // binade edges
+            if (rep == 3) x0 = std::fabs(c) * up(rng) * 1.5;                                    // just after a wrap
+            if (!(x0 >= 0.0 && x0 < 1.0)) continue;
+            const long ns = 1 + (long) (rng() % 3000000);
+            double xa = x0, xb = x0;
+            long na = 0, nb = 0;
+            WalkCore<lane::kTab>::FastSlack sa, sb;
+            sa.init(c < 0 ? 1022 : 1023); sb.init(c < 0 ? 1022 : 1023);
+            if (x0 >= a.thr) { sa.note(x0); sb.note(x0); }
+            bool same = true;
+            for (int cyc = 0; cyc < 400 && na < ns && same; ++cyc) {
+                const bool wa = a.neg ? a.descend<true>(xa, na, ns, &sa) : a.climb<true>(xa, na, ns, &sa);
+                const bool wb = b.neg ? b.descend<true>(xb, nb, ns, &sb) : b.climb<true>(xb, nb, ns, &sb);
+                same = wa == wb && na == nb && bits_of(xa) == bits_of(xb);
+                if (!wa) break;
+            }
+            int64_t la = 0, ha = 0, lb = 0, hb = 0;
+            const bool oa = sa.finish(&la, &ha), ob = sb.finish(&lb, &hb);
+            if (!same || oa != ob || (oa && (la != lb || ha != hb))) {
+                if (bad++ < 5) std::printf("walkers differ: c = %a, x0 = %a, ns = %ld: x %a / %a, n %ld / %ld, slack %d [%ld, %ld] / %d [%ld, %ld]\n",
+                                           c, x0, ns, xa, xb, na, nb, (int) oa, (long) la, (long) ha, (int) ob, (long) lb, (long) hb);
+            }
+            // and without notes (the tail of the block before)
+            double ya = x0, yb = x0;
+            long ma = 0, mb = 0;
+            while (ma < ns && a.cycle(ya, ma, ns)) {}
+            while (mb < ns && b.cycle(yb, mb, ns)) {}
+            if (bits_of(ya) != bits_of(yb) || (bits_of(ya) != bits_of(xa) && na == ns)) { if (bad++ < 5) std::printf("walkers differ without notes: c = %a, x0 = %a\n", c, x0); }
+        }
+    }
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
     std::mt19937_64 rng(argc > 1 ? (unsigned long) atol(argv[1]) : 1);
     const int cases = argc > 2 ? atoi(argv[2]) : 40;
     std::uniform_real_distribution<double> up(0.0, 1.0);
-    long blocks = 0, bad = 0;
+    long blocks = 0, bad = walkers_agree(rng, 200 * cases);
     uint64_t s0[2], s1[2];
     gpsiq_chain_stats(s0);
     for (int it = 0; it < cases; ++it) {
