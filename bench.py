@@ -652,10 +652,11 @@ def rccl_selftest(dev, backend="nccl"):
 
 def reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather, dry, xdev):
     """GPSIQ_NCO_REFERENCE (the model whose output IS the reference's) time-sharded over the ranks, per rank: its own blocks'
-    descriptors -> gpsiq/shard.py reference_own_shard (carrier chain sharded by CHANNEL: 24 B per channel and block all-gathered,
-    gpsiq_reference_chain over this rank's channels of the whole timeline, 8 B per channel and block all-gathered back;
-    gpsiq_reference_seeded over its own blocks) -> gpsiq_set_descriptors + gpsiq_set_patches -> one gpsiq_launch.  Reported per
-    rank with what bounds it; `value` = all ranks' samples / slowest rank's time, best of 2 passes."""
+    descriptors -> gpsiq/shard.py reference_own_shard: the carrier chain sharded by TIME (reference_chain_by_time: two all-gathers
+    of 56 B per slot for the estimate of where the range starts, the certified map of every own block on this rank's GPU, the
+    true states relayed rank to rank, 12 B per slot), gpsiq_reference_seeded over its own blocks -> gpsiq_set_descriptors +
+    gpsiq_set_patches -> one gpsiq_launch.  Reported per rank with what bounds it; `value` = all ranks' samples / slowest rank's
+    time, best of 2 passes."""
     import gpsiq
     from gpsiq.abi import NCO_REFERENCE  # noqa: F401
     from gpsiq.scenario import synth_blocks
@@ -681,7 +682,7 @@ def reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather
                 r = cpu_gather(b)
                 _p["exchange"] = _p.get("exchange", 0.0) + time.perf_counter() - t
                 return r
-            q_r, patches, _, _ = reference_own_shard(d_own, fs_r, ns_r, rank, world, timed_gather)
+            q_r, patches, _, _ = reference_own_shard(d_own, fs_r, ns_r, rank, world, timed_gather, by_time=True, ctx=None if dry else ctx)
             t1 = time.perf_counter()
             if not dry:
                 ctx.set_descriptors(q_r)
@@ -697,19 +698,19 @@ def reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather
             if best is None or tot < best[0]:
                 best = (tot, t1 - t0, parts.get("exchange", 0.0), t2 - t1, t3 - t2, len(patches))
         tot, host, exch, upload, kern, npatch = best
-        mine = {"rank": rank, "host_chain_and_evaluation_ms": round((host - exch) * 1e3, 3), "exchange_ms": round(exch * 1e3, 3),
+        mine = {"rank": rank, "chain_and_evaluation_ms": round((host - exch) * 1e3, 3), "exchange_ms": round(exch * 1e3, 3),
                 "validate_upload_ms": round(upload * 1e3, 3), "kernel_and_patches_ms": None if dry else round(kern * 1e3, 3),
                 "patched_samples": npatch, "threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus()}
         mine["bound"] = None if dry else ("host" if host > kern else "kernel")
         per_rank = [json.loads(b.decode()) for b in cpu_gather(json.dumps(mine).ljust(320).encode())]
         out["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks per GPU, one serial pass "
-                                          "(host chain + evaluation, upload, one launch)",
+                                          "(chain: maps on the GPU + link on the host; evaluation on the host; upload; one launch)",
                               "value": None if dry else round(nb_r * world * ns_r / tot / 1e6, 1), "unit": "Msamples/s",
                               "x_realtime": None if dry else round(nb_r * world * 0.1 / tot, 1), "seconds": round(tot, 5), "per_rank": per_rank,
                               "bound": None if dry else ("host" if any(r["bound"] == "host" for r in per_rank) else "kernel")}
-    out["what"] = ("GPSIQ_NCO_REFERENCE time-sharded over the ranks: carrier chain sharded by channel (two small host all-gathers), evaluation and "
-                   "rendering by time; the chain is the only serial part (per channel), so the host side is bounded below by "
-                   "blocks x chain time x channels / host threads whatever the number of GPUs")
+    out["what"] = ("GPSIQ_NCO_REFERENCE time-sharded over the ranks: every rank walks the carrier chain of ITS OWN blocks (level 1, the certified "
+                   "map of every block, on its GPU; level 2 an addition per block on the host, relayed rank to rank), evaluates and renders them; "
+                   "what is left on the host per rank is the evaluation of its own blocks (~0.4 us per block and channel on each thread)")
     return out
 
 

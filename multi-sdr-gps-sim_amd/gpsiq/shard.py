@@ -64,21 +64,57 @@ def gather_ragged(all_gather_bytes, payload):
     return [p[:n] for p, n in zip(parts, lens)]
 
 
-def reference_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes):
-    """GPSIQ_NCO_REFERENCE time-sharded over processes: this rank's rows of gpsiq_reference_batch over the WHOLE timeline
-    -- (q_own, patches_own with block indices counted from its first block, carr_end[nchan] after the last block of the
-    whole timeline) -- from its own blocks' descriptors.  Only the carrier chain is serial in time, and it is serial per
-    channel: so the chain is sharded by CHANNEL (rank r walks channels [c0, c1) of the whole timeline: 24 bytes per channel and
-    block in, 8 bytes out), everything else by time (every rank evaluates its own blocks from their start states):
-        1. all-gather the chain inputs of everybody's blocks (gpsiq_chain_inputs: f_carr, carr_phase, prn);
-        2. gpsiq_reference_chain over this rank's channels, all blocks;
-        3. all-gather the start states;
-        4. gpsiq_reference_seeded over this rank's blocks, all channels.
-    Two small host-side exchanges at set-up (a gloo group, MPI, pipes ...); nothing on the data path."""
+def reference_chain_by_time(cin_own, fs, nsamp, rank, world, all_gather_bytes, ctx=None, max_stretches=0):
+    """The carrier chain of GPSIQ_NCO_REFERENCE sharded by TIME: this rank's rows of gpsiq_reference_chain over the whole
+    timeline -- (carr_start_own[nblocks_own][nchan], carr_end[nchan], last_prn[nchan] after the LAST block of the timeline) --
+    from the chain inputs (gpsiq_chain_inputs) of its own blocks only.  The expensive part, the certified map of every block
+    (gpsiq_chain_maps; on the GPU when ctx is given), needs nothing but an ESTIMATE of where the range starts:
+        1. every rank summarises its range (exact phase advance), all-gather, fold the ranks before: the phase its range starts at;
+        2. the same again with the modelled rounding drift, which wants that absolute phase: two exchanges of 56 bytes per slot;
+        3. level 1 of its own blocks, all ranks at once;
+        4. the true states are relayed: rank r links its range (gpsiq_chain_link: an addition per block) from the accumulator
+           rank r - 1 ended on -- 12 bytes per slot and rank, one after the other."""
+    from . import chain_fold, chain_link, chain_maps, chain_summary
+    from .abi import CHAIN_EST_DTYPE, CHAIN_IN_DTYPE
+    cin_own = np.ascontiguousarray(cin_own, dtype=CHAIN_IN_DTYPE)
+    nchan = cin_own.shape[1]
+
+    def gathered(est):
+        return np.stack([np.frombuffer(b, dtype=CHAIN_EST_DTYPE) for b in all_gather_bytes(est.tobytes())])
+
+    phase = gathered(chain_summary(cin_own, fs, nsamp))
+    drift = gathered(chain_summary(cin_own, fs, nsamp, start=chain_fold(phase[:rank])))
+    maps = chain_maps(cin_own, fs, nsamp, start=chain_fold(drift[:rank]), max_stretches=max_stretches, ctx=ctx)[0]
+    start, carr, prn = None, None, None
+    for r in range(world):
+        blob = bytes(12 * nchan)
+        if r == rank:
+            start, end, last = chain_link(cin_own, maps, fs, nsamp, carr, prn)
+            blob = end.tobytes() + last.tobytes()
+        got = all_gather_bytes(blob)[r]
+        carr = np.frombuffer(got[:8 * nchan], dtype=np.float64).copy()
+        prn = np.frombuffer(got[8 * nchan:], dtype=np.int32).copy()
+    return start, carr, prn
+
+
+def reference_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes, by_time=True, ctx=None):
+    """GPSIQ_NCO_REFERENCE time-sharded over processes: this rank's rows of gpsiq_reference_batch over the WHOLE timeline,
+    from its own blocks' descriptors -> (q_own, patches_own with block indices counted from its first block, carr_end[nchan]
+    and last_prn[nchan] after the last block of the whole timeline; carr_end of a slot whose last_prn is 0 is 0.0: the slot is
+    unused there, a caller that continues the timeline takes the next descriptor's own phase).
+    by_time (default): the chain is sharded by time too (reference_chain_by_time above: every rank walks only its own blocks,
+    on its GPU when ctx is given), then every rank evaluates its own blocks from their start states (gpsiq_reference_seeded).
+    by_time False, the recipe of round 4: the chain sharded by CHANNEL -- all-gather the chain inputs of everybody's blocks
+    (24 bytes per channel and block), gpsiq_reference_chain over this rank's channels of the whole timeline, all-gather the
+    start states (8 bytes per channel and block).  Host-side exchanges at set-up either way; nothing on the data path."""
     from . import chain_inputs, reference_chain, reference_seeded, shard_range
     from .abi import CHAIN_IN_DTYPE
     desc_own = np.ascontiguousarray(desc_own)
     nchan = desc_own.shape[1]
+    if by_time:
+        start_own, carr_end, last_prn = reference_chain_by_time(chain_inputs(desc_own), fs, nsamp, rank, world, all_gather_bytes, ctx=ctx)
+        q, patches = reference_seeded(desc_own, fs, nsamp, start_own)
+        return q, patches, carr_end, last_prn
     parts = gather_ragged(all_gather_bytes, chain_inputs(desc_own).tobytes())
     cin = np.concatenate([np.frombuffer(p, dtype=CHAIN_IN_DTYPE).reshape(-1, nchan) for p in parts])       # timeline order = rank order
     first = sum(len(p) // (CHAIN_IN_DTYPE.itemsize * nchan) for p in parts[:rank])
@@ -101,7 +137,6 @@ def reference_own_shard(desc_own, fs, nsamp, rank, world, all_gather_bytes):
         carr_end[a0:a1] = np.frombuffer(blob[n_st:n_st + 8 * w], dtype=np.float64)
         last_prn[a0:a1] = np.frombuffer(blob[n_st + 8 * w:n_st + 12 * w], dtype=np.int32)
     q, patches = reference_seeded(desc_own, fs, nsamp, start[first:first + len(desc_own)])
-    # what gpsiq_reference_batch hands out after the last block: the accumulator of a slot in use, the descriptor's own phase otherwise
     return q, patches, carr_end, last_prn
 
 

@@ -101,7 +101,7 @@ def _ref_timeline():
     return d
 
 
-def _ref_worker(rank, world, port, out):
+def _ref_worker(rank, world, port, out, by_time):
     sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
     import torch.distributed as dist
     import gpsiq
@@ -109,7 +109,7 @@ def _ref_worker(rank, world, port, out):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     b0, b1 = shard_range(RNB, rank, world)
     # this rank sees ONLY its own rows of the timeline
-    q, patches, carr_end, last_prn = reference_own_shard(_ref_timeline()[b0:b1], RFS, RNS, rank, world, torch_all_gather_bytes(dist))
+    q, patches, carr_end, last_prn = reference_own_shard(_ref_timeline()[b0:b1], RFS, RNS, rank, world, torch_all_gather_bytes(dist), by_time=by_time)
     gathered = [None] * world
     dist.all_gather_object(gathered, (b0, b1, q.tobytes(), patches.tobytes(), carr_end.tobytes(), last_prn.tobytes()))
     if rank == 0:
@@ -118,12 +118,14 @@ def _ref_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("by_time", [True, False])
 @pytest.mark.parametrize("world", [2, 3])
-def test_reference_nco_shards_equal_the_whole_timeline(world):
-    """Two (three) gloo ranks, each holding only its own blocks' descriptors: the carrier chain sharded by channel
-    (gpsiq_reference_chain over each rank's channels of the whole timeline), everything else by time
-    (gpsiq_reference_seeded over each rank's blocks) -- descriptors, patches and the carried phase equal
-    gpsiq_reference_batch over the whole timeline in one process."""
+def test_reference_nco_shards_equal_the_whole_timeline(world, by_time):
+    """Two (three) gloo ranks, each holding only its own blocks' descriptors.  by_time: the carrier chain sharded by TIME
+    (gpsiq/shard.py::reference_chain_by_time: every rank walks the certified maps of its own blocks, the true states are
+    relayed rank to rank); else by channel (gpsiq_reference_chain over each rank's channels of the whole timeline).
+    Everything else by time (gpsiq_reference_seeded over each rank's blocks) -- descriptors, patches and the carried phase
+    equal gpsiq_reference_batch over the whole timeline in one process."""
     import gpsiq
     from gpsiq.abi import PATCH_DTYPE, QCHAN_DTYPE
     s = socket.socket()
@@ -132,7 +134,7 @@ def test_reference_nco_shards_equal_the_whole_timeline(world):
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_ref_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_ref_worker, args=(r, world, port, out, by_time)) for r in range(world)]
     for p in procs:
         p.start()
     gathered = out.get(timeout=180)
@@ -153,3 +155,58 @@ def test_reference_nco_shards_equal_the_whole_timeline(world):
         assert np.array_equal(np.frombuffer(cb)[act], carr[act])              # every rank knows the state after the whole timeline
         assert np.array_equal(np.frombuffer(lb, dtype=np.int32), np.where(act, d[-1]["prn"], 0))
     assert seen == len(patches)
+
+
+# ---- the carrier chain alone, sharded by time ---------------------------------------------------------------------------
+CFS, CNS, CNB, CNCH = 2.6e6, 260000, 90, 9
+
+
+def _chain_timeline():
+    from test_chain_parallel import timeline
+    return timeline(41, CNB, CNCH)
+
+
+def _chain_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import gpsiq
+    from gpsiq.shard import reference_chain_by_time, torch_all_gather_bytes
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cuts = [0, 31, 31, CNB] if world == 3 else [0, 37, CNB]         # uneven ranges, one rank without blocks
+    before = gpsiq.chain_stats()
+    start, end, prn = reference_chain_by_time(_chain_timeline()[cuts[rank]:cuts[rank + 1]], CFS, CNS, rank, world, torch_all_gather_bytes(dist))
+    linked, walked = (a - b for a, b in zip(gpsiq.chain_stats(), before))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (cuts[rank], start.tobytes(), end.tobytes(), prn.tobytes(), linked, walked))
+    if rank == 0:
+        out.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_time_sharded_chain_equals_the_serial_chain_over_the_whole_timeline(world):
+    """gpsiq_reference_chain over 90 blocks x 9 slots in one process == the ranks' own rows of the chain sharded by time,
+    bit for bit, and every rank ends up with the state after the whole timeline; most blocks go through their maps."""
+    import gpsiq
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_chain_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_start, want_end, want_prn = gpsiq.reference_chain(_chain_timeline(), CFS, CNS)
+    rows = b"".join(g[1] for g in sorted(gathered, key=lambda g: g[0]))
+    assert rows == want_start.tobytes()
+    for g in gathered:
+        assert g[2] == want_end.tobytes() and g[3] == want_prn.tobytes()
+    linked, walked = sum(g[4] for g in gathered), sum(g[5] for g in gathered)
+    assert linked > 4 * walked, (linked, walked)
