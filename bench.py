@@ -340,6 +340,31 @@ def main():
     xdev = "cuda" if (backend == "nccl" and not dry) else "cpu"
     gather = torch_all_gather_bytes(dist, xdev)
     variant = gpsiq.variants()[args.variant]
+    placement = None
+    if world > 1:
+        # Where every rank runs, before anything of libgpsiq touches a device: the first collective of the job is this 256-byte
+        # all-gather, so a broken RCCL / gloo shows up HERE, named, and not as a hang in the middle of the bench; two ranks that
+        # resolved to one device (a launcher that did not set LOCAL_RANK, a box with fewer GPUs than ranks) fail the run.
+        me = {"rank": rank, "local_rank": local_rank, "device": None if dry else dev,
+              "pci_bus_id": None if dry else pci_bus_id(torch, dev), "host": os.uname().nodename,
+              "cpus_granted": effective_cpus(), "GPSIQ_THREADS": os.environ.get("GPSIQ_THREADS")}
+        try:
+            placement = [json.loads(b.decode()) for b in gather(json.dumps(me).ljust(256).encode())]
+        except Exception as ex:
+            print(f"bench.py: rank {rank}: the first collective ({backend}) failed before libgpsiq was used: {type(ex).__name__}: {ex}", file=sys.stderr)
+            sys.exit(4)
+        seen = {}
+        for pl in placement:
+            key = (pl["host"], pl["pci_bus_id"] if pl["pci_bus_id"] else pl["device"])
+            if not dry and key in seen and os.environ.get("GPSIQ_BENCH_SHARE_GPU", "0") in ("", "0"):
+                if rank == 0:
+                    print(f"bench.py: ranks {seen[key]} and {pl['rank']} resolve to the same device {key}: refusing to run", file=sys.stderr)
+                sys.exit(5)
+            seen[key] = pl["rank"]
+        if rank == 0:
+            for pl in placement:
+                print("[bench] rank {rank}: host {host}, local rank {local_rank}, device {device} (PCI {pci_bus_id}), {cpus_granted} CPUs granted, "
+                      "GPSIQ_THREADS={GPSIQ_THREADS}".format(**pl), file=sys.stderr)
 
     # one global timeline of world*B blocks; this rank builds, quantises and seeds ONLY its own rows.
     # Descriptors: distinct code/Doppler state per block for a 64-block pattern tiled over the timeline.
@@ -499,6 +524,10 @@ def main():
                            "host_refresh_and_quantise_ms_per_round": round(best_s[1] / R * 1e3, 2), "seed_exchange": exchange,
                            "what": "the chain above over one continuous timeline in rounds, launches asynchronous: the host side of round "
                                    "m+1 overlaps the kernel of round m (double-buffered descriptor sets); slowest rank, best of 4 passes"}
+        # the refresh needs ~6 host threads per GPU to stay under the kernel: what this host grants per rank
+        thr = int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus()
+        e2e["streamed"]["expected_bound_at_this_host"] = {"threads_per_rank": thr, "threads_needed_per_gpu": 6,
+                                                           "expected": "kernel" if thr >= 6 else "host", "host_share_of_kernel_rate": round(min(1.0, thr / 6.0), 2)}
         # what the rounds of a long run are bound by on the slowest rank (the serial batch above is host + kernel by construction)
         e2e["bound"] = e2e["streamed"]["bound"]
         ref_sharded = None
@@ -558,30 +587,47 @@ def main():
             #   plain-add kernels (all sums inside int16): 3 x 4.3 + 4.3 / 2 + 2 x 4.4 = 23.85 cycles
             #   packed kernels (larger gains):             3 x 4.3 + 2 x 2.5 + 2 x 4.4 = 26.7 cycles
             # peak = every SIMD of 256 CUs issuing only that core at the 2.4 GHz maximum clock.
-            cnt = counters_obj(f"{int(fs)}_{nchan}_{ss}_{nblocks}", launch_ms)
-            if cnt:
-                out["counters"] = cnt
-            out["issue_roofline"] = {"bound": "valu-issue", "note": "vs the kernel's OWN instruction stream (how close it runs to the cost of its "
-                                     "seven-instruction core), not a statement that the stream is minimal: see `counters` for the "
-                                     "instruction-mix-independent fractions",
-                                     "unit": "Gchannel-samples/s", "core_cycles": core_cycles,
-                                     "achieved": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / 1e9, 1),
-                                     "peak": round(256 * 4 * 64 * 2.4e9 / core_cycles / 1e9, 1),
-                                     "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / core_cycles), 4)}
+            cnt = counters_obj(f"{int(fs)}_{nchan}_{ss}_{nblocks}", launch_ms) or {}
+            # not a roofline: the kernel against the cost of its OWN instruction stream (profiles/r05_synth_tile_row_loop.txt)
+            cnt["own_stream_efficiency"] = {"note": "launch time vs the issue cost of the kernel's own seven-instruction core at the measured "
+                                            "single-instruction rates; says how close the kernel runs to its stream, not that the stream is minimal",
+                                            "core_cycles": core_cycles,
+                                            "frac": round(nblocks * nsamp * nchan / (launch_ms * 1e-3) / (256 * 4 * 64 * 2.4e9 / core_cycles), 4)}
+            out["counters"] = cnt
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if extra:
             if "reference_nco" in extra:
                 out["reference_nco"] = extra.pop("reference_nco")
+                # the mode whose output IS the reference's, beside the headline: whole gpsiq_generate_batch call at the same workload
+                out["exact_mode_value"] = out["reference_nco"]["value"]
+                out["exact_mode_unit"] = "Msamples/s"
+                out["exact_mode_roofline"] = out["reference_nco"]["roofline"]
+                out["exact_mode_bound"] = out["reference_nco"]["legs"]["2M6_int8_16ch"]["bound"]
             out["extra"] = extra
         if ref_sharded is not None:
             out["reference_nco"] = dict(ref_sharded, nco_mode="reference (GPSIQ_NCO_REFERENCE), time-sharded: see `what`",
                                         value=ref_sharded["legs"]["2M6_int8_16ch"]["value"], unit="Msamples/s")
+            out["exact_mode_value"], out["exact_mode_unit"] = out["reference_nco"]["value"], "Msamples/s"
+            out["exact_mode_bound"] = ref_sharded["legs"]["2M6_int8_16ch"]["bound"]
+        if placement is not None:
+            out["placement"] = placement
         print(json.dumps(out), flush=True)
     if ctx is not None:
         ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pci_bus_id(torch, dev):
+    """PCI bus id of a device, as a string; None where this torch does not say."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        if hasattr(p, "pci_bus_id"):
+            return "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+    except Exception:
+        pass
+    return None
 
 
 def rccl_selftest(dev, backend="nccl"):
@@ -782,7 +828,9 @@ def extra_legs(ctx, ring, stream, args, first):
     for label in ("host_dst_batch", "host_dst_batch_unchunked"):
         ex[label]["frac_of_raw_copy"] = round(ex[label]["pcie_GBps"] / ex["pcie_d2h_raw"]["GBps"], 3)
 
-    for label, mode in (("block_call", NCO_FIXED), ("block_call_reference_nco", NCO_REFERENCE)):
+    pageable = np.empty(blk, dtype=np.uint8)             # what a malloc'd staging block is: the copy off the device goes through a bounce buffer
+    for label, mode, dst_ptr in (("block_call", NCO_FIXED, pinned.data_ptr()), ("block_call_reference_nco", NCO_REFERENCE, pinned.data_ptr()),
+                                 ("block_call_pageable", NCO_FIXED, pageable.ctypes.data)):
         ctx.set_nco_mode(mode)
         lat, carr = [], None
         for k in range(50):
@@ -790,11 +838,13 @@ def extra_legs(ctx, ring, stream, args, first):
             if carr is not None:
                 ch1["carr_phase"] = carr
             t1 = time.perf_counter()
-            _, carr = ctx.generate_block(ch1, nsamp, fs, ss, host_ptr=pinned.data_ptr())
+            _, carr = ctx.generate_block(ch1, nsamp, fs, ss, host_ptr=dst_ptr)
             lat.append(time.perf_counter() - t1)
         lat = sorted(lat[10:])
-        ex[label] = {"what": "gpsiq_generate_block -> page-locked host memory, one 0.1 s block per call, carr_phase handed back in "
-                             "(the patched gps thread's call)", "median_us": round(lat[len(lat) // 2] * 1e6, 1),
+        ex[label] = {"what": "gpsiq_generate_block -> " + ("PAGEABLE host memory (malloc instead of gpsiq_host_alloc: what getting the staging block "
+                             "of INTEGRATION.md wrong costs)" if label.endswith("pageable") else "page-locked host memory") +
+                             ", one 0.1 s block per call, carr_phase handed back in (the patched gps thread's call)",
+                     "median_us": round(lat[len(lat) // 2] * 1e6, 1),
                      "max_us": round(lat[-1] * 1e6, 1), "x_realtime": round(0.1 / lat[len(lat) // 2], 1)}
     # the same call without waiting: 50 blocks queued back to back, one wait at the end
     ctx.set_nco_mode(NCO_FIXED)
@@ -848,10 +898,11 @@ def extra_legs(ctx, ring, stream, args, first):
             t1 = time.perf_counter()
             q_r, patches, _ = gpsiq.reference_blocks(d_r, fs_r, ns_r)
             th = min(th, time.perf_counter() - t1)
-        # the two halves on their own: the serial carrier chain (what no number of GPUs speeds up), and the evaluation of the
-        # blocks from their start states (what shards over threads, devices and ranks)
+        # the parts on their own.  The carrier chain: level 1 (the certified map of every block) on the device, level 2 (an exact
+        # addition per block, the odd block walked) on the host; the serial walk on host threads it replaces, for comparison; the
+        # evaluation of the blocks from their start states (shards over threads, devices and ranks)
         cin = gpsiq.chain_inputs(d_r)
-        tc = te = float("inf")
+        tc = te = tl = float("inf")
         s0 = gpsiq.reference_stats()
         for _ in range(3):
             t1 = time.perf_counter()
@@ -861,19 +912,45 @@ def extra_legs(ctx, ring, stream, args, first):
             gpsiq.reference_seeded(d_r, fs_r, ns_r, starts)
             te = min(te, time.perf_counter() - t1)
         s1 = gpsiq.reference_stats()
+        chain_ms = min(gpsiq.chain_maps(cin, fs_r, ns_r, ctx=ctx)[2] for _ in range(5))
+        maps = gpsiq.chain_maps(cin, fs_r, ns_r, ctx=ctx)[0]
+        c0 = gpsiq.chain_stats()
+        linked_starts = gpsiq.chain_link(cin, maps, fs_r, ns_r)[0]
+        c1 = gpsiq.chain_stats()
+        for _ in range(3):
+            t1 = time.perf_counter()
+            gpsiq.chain_link(cin, maps, fs_r, ns_r)
+            tl = min(tl, time.perf_counter() - t1)
         ctx.set_descriptors(q_r)
         ctx.set_patches(patches)
         ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 3, stream=stream)
         km = min(ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 5, stream=stream) for _ in range(2))
+        os.environ["GPSIQ_CHAIN"] = "host"                     # the call with the serial chain on host threads (round 4's path), same process
+        ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
+        dt_host = float("inf")
+        for _ in range(4):
+            t1 = time.perf_counter()
+            ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
+            dt_host = min(dt_host, time.perf_counter() - t1)
+        del os.environ["GPSIQ_CHAIN"]
+        host_side = te + tl                                    # what is left on the host: link + evaluation (they pipeline under the kernel)
+        device_side = km + chain_ms
         ref["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks, gpsiq_generate_batch -> device memory",
                               "value": round(nb_r * ns_r / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / dt, 1),
-                              "call_ms": round(dt * 1e3, 3), "host_walk_and_candidates_ms": round(th * 1e3, 3),
-                              "host_chain_only_ms": round(tc * 1e3, 3), "host_evaluation_only_ms": round(te * 1e3, 3),
-                              "chain_us_per_block_and_thread": round(tc * 1e6 * min(effective_cpus(), args.nchan) / (nb_r * args.nchan), 3),
+                              "call_ms": round(dt * 1e3, 3),
+                              "call_ms_chain_on_host_threads": round(dt_host * 1e3, 3),
+                              "chain": {"level1_device_kernels_ms": round(chain_ms, 3), "level2_host_link_ms": round(tl * 1e3, 3),
+                                        "blocks_linked_through_their_map": int(c1[0] - c0[0]), "blocks_walked_from_their_true_start": int(c1[1] - c0[1]),
+                                        "equal_to_the_serial_chain": bool(linked_starts.tobytes() == starts.tobytes()),
+                                        "serial_walk_on_host_threads_ms": round(tc * 1e3, 3),
+                                        "serial_walk_us_per_block_and_thread": round(tc * 1e6 * min(effective_cpus(), args.nchan) / (nb_r * args.nchan), 3)},
+                              "host_walk_and_candidates_ms": round(th * 1e3, 3),
+                              "host_evaluation_only_ms": round(te * 1e3, 3),
                               "candidate_states_decided_without_a_walk": round((s1[1] - s0[1]) / max(1, s1[0] - s0[0]), 5),
-                              "gpus_the_chain_can_feed": round(km / (tc * 1e3), 2),
+                              "gpus_the_chain_can_feed": round(km / (tl * 1e3), 2),
+                              "gpus_the_host_can_feed": round(km / (host_side * 1e3), 2),
                               "kernel_and_patches_ms": round(km, 3), "patched_samples": int(len(patches)),
-                              "bound": "host" if th * 1e3 > km else "kernel",
+                              "bound": "host" if host_side * 1e3 > device_side else "kernel",
                               "roofline": roofline_obj(nb_r * blk_r, dt * 1e3),
                               "roofline_kernel_only": roofline_obj(nb_r * blk_r, km)}
     # the same model from nothing: RINEX-derived ephemeris, static receiver -> per-block host refresh (gpsiq_refresh_epochs, the
@@ -907,11 +984,13 @@ def extra_legs(ctx, ring, stream, args, first):
     ref["value"] = ref["legs"]["2M6_int8_16ch"]["value"]
     ref["unit"] = "Msamples/s"
     ref["roofline"] = ref["legs"]["2M6_int8_16ch"]["roofline"]
-    ref["what"] = ("whole gpsiq_generate_batch call (carrier chain + evaluation + upload + kernel + patches) at the headline workload.  Only the "
-                   "chain is serial in time (per channel: host_chain_only_ms on min(cpus, channels) threads); the evaluation of a block needs its "
-                   "start state alone and nearly every candidate is decided without walking an accumulator "
-                   "(candidate_states_decided_without_a_walk).  gpus_the_chain_can_feed = kernel time / chain time on this host: above it more "
-                   "GPUs wait for the chain")
+    ref["what"] = ("whole gpsiq_generate_batch call (carrier chain + evaluation + upload + kernel + patches) at the headline workload.  The chain is "
+                   "parallel in time: every block's certified map on the device (chain.level1_device_kernels_ms: two launches, the second under the "
+                   "first pieces' synthesis), the chain itself an exact addition per block on the host (chain.level2_host_link_ms, inside the "
+                   "walkers' tasks); the evaluation of a block needs its start state alone and nearly every candidate is decided without "
+                   "walking an accumulator.  bound: host (link + evaluation) against device (synthesis + patches + chain kernels), which pipeline; "
+                   "gpus_the_chain_can_feed = kernel time / link time, gpus_the_host_can_feed = kernel time / (link + evaluation) on this "
+                   "host's threads.  call_ms_chain_on_host_threads: the same call with round 4's serial walk (GPSIQ_CHAIN=host)")
     ex["reference_nco"] = ref
     ctx.set_nco_mode(NCO_FIXED)
     # the batch call with a device destination from double-precision descriptors: host quantiser + upload + kernel

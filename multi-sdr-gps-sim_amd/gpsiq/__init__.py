@@ -16,7 +16,8 @@ from .abi import (CHAN_DTYPE, QCHAN_DTYPE, SC08, SC16, SINK_HACKRF, SINK_IQFILE,
                   NCO_FIXED, NCO_REFERENCE, SHARD_CARRY_DTYPE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpsiq.so")
+# GPSIQ_LIB: another build of the library (tests/test_gpu_build.py loads the one it has just compiled on the GPU box)
+LIB_PATH = os.environ.get("GPSIQ_LIB") or os.path.join(_HERE, "libgpsiq.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

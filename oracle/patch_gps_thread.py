@@ -43,7 +43,7 @@ DECLS = '''    gpsiq_ctx_t *gq = NULL;
     double gq_carr[MAX_CHAN];
     void *gq_blk = NULL;'''
 
-ALLOC = '''    gq_blk = malloc((size_t) IQ_BUFFER_SIZE * (size_t) simulator->sample_size);   /* staging for the HackRF chunking only */'''
+ALLOC = '''    gq_blk = gpsiq_host_alloc((size_t) IQ_BUFFER_SIZE * (size_t) simulator->sample_size);   /* page-locked staging for the HackRF chunking only: the block's copy off the device lands in it */'''
 
 INIT = '''    {
         const char *gq_nco = getenv("GPSIQ_NCO");
@@ -86,7 +86,7 @@ CALL = '''        /* libgpsiq: one call synthesises the block (gps.c:2767-2846) 
         }'''
 
 FREE = '''    gpsiq_destroy(gq);
-    free(gq_blk);'''
+    gpsiq_host_free(gq_blk);'''
 
 out = []
 for n, line in enumerate(L, 1):

@@ -25,6 +25,7 @@ def test_gpus_2_starts_two_ranks_by_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None and out["scaling"] == "weak"
     assert out["config"]["blocks_per_gpu_per_step"] == 60
+    assert [p["rank"] for p in out["placement"]] == [0, 1] and "[bench] rank 1: host " in r.stderr
     e = out["end_to_end"]
     assert e["blocks_per_gpu"] == 30 and e["channels"] == 16 and e["host_refresh_and_quantise_ms"] > 0.0
     assert e["streamed"]["rounds"] == 16 and e["streamed"]["blocks_per_gpu_per_round"] == 30 and e["streamed"]["seconds"] > 0.0
@@ -60,7 +61,13 @@ def test_gpus_8_dry_run_is_one_line_from_eight_ranks():
     assert all(p["host_ms_per_round"] > 0.0 and p["threads"] == out["config"]["host_threads_per_rank"] for p in st["per_rank"])
     assert st["bound"] is None and all(p["kernel_ms_per_round"] is None for p in st["per_rank"])       # no device in a dry run
     assert "bound" in out["end_to_end"] and out["end_to_end"]["bound"] is None
-    # GPSIQ_NCO_REFERENCE time-sharded over the 8 ranks (chain by channel: two channels per rank; evaluation by time), per rank
+    # where every rank runs: one line per rank on stderr before anything else, the same in the JSON
+    assert [p["rank"] for p in out["placement"]] == list(range(8)) and all(p["cpus_granted"] >= 1 and p["GPSIQ_THREADS"] for p in out["placement"])
+    for k in range(8):
+        assert f"[bench] rank {k}: host " in r.stderr
+    assert out["end_to_end"]["streamed"]["expected_bound_at_this_host"]["threads_needed_per_gpu"] == 6
+    assert out["exact_mode_unit"] == "Msamples/s" and "exact_mode_value" in out
+    # GPSIQ_NCO_REFERENCE time-sharded over the 8 ranks (chain and evaluation by time: every rank its own blocks), per rank
     ref = out["reference_nco"]
     for leg in ("2M6_int8_16ch", "25M_int16_16ch"):
         pr = ref["legs"][leg]["per_rank"]
