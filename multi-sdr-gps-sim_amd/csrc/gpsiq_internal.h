@@ -2,7 +2,7 @@
 #ifndef GPSIQ_INTERNAL_H
 #define GPSIQ_INTERNAL_H
 
-#include "../../include/gpsiq.h"
+#include "../../include/gpsiq_extras.h"      // gpsiq.h (the boundary) + gpsiq_rows.h (section 8f rows) + the frozen convenience set
 #include "gpsiq_tables.h"
 
 #include <pthread.h>

@@ -34,7 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "gpsiq.h"
+#include "gpsiq_extras.h"
 
 #define BLOCKS_PER_CALL 100    /* bounds the page-locked staging buffer */
 

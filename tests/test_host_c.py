@@ -67,7 +67,7 @@ def test_host_half_under_sanitizers(tmp_path, san):
     if "undefined" in san:
         flags.append("-fno-sanitize-recover=undefined")
     objs = []
-    for src in ("gpsiq_host.cpp", "gpsiq_exact.cpp", "gpsiq_refresh.cpp", "gpsiq_nav.cpp", "gpsiq_rinex.cpp"):
+    for src in ("gpsiq_host.cpp", "gpsiq_exact.cpp", "gpsiq_chain.cpp", "gpsiq_refresh.cpp", "gpsiq_nav.cpp", "gpsiq_rinex.cpp"):
         o = str(tmp_path / (src + ".o"))
         b = subprocess.run(["g++", "-std=c++17", *flags, "-c", os.path.join(csrc, src), "-o", o], capture_output=True, text=True)
         if b.returncode != 0:
@@ -100,7 +100,7 @@ def test_reference_walker_consumed_in_pieces_under_sanitizers(tmp_path, san):
     if "undefined" in san:
         flags.append("-fno-sanitize-recover=undefined")
     b = subprocess.run(["g++", *flags, "-o", exe, os.path.join(root, "tests", "sanitize_refwalk.cpp"), os.path.join(csrc, "gpsiq_host.cpp"),
-                        os.path.join(csrc, "gpsiq_exact.cpp"), "-lpthread", "-lm"], capture_output=True, text=True)
+                        os.path.join(csrc, "gpsiq_exact.cpp"), os.path.join(csrc, "gpsiq_chain.cpp"), "-lpthread", "-lm"], capture_output=True, text=True)
     if b.returncode != 0:
         pytest.skip("no sanitizer toolchain / runtime here: " + b.stderr[-300:])
     for threads in (None, "2"):           # the default pool; fewer threads than channels (piece-major)
@@ -122,7 +122,7 @@ def test_drift_enclosure_holds_the_walked_accumulator(tmp_path):
     csrc = os.path.join(root, "multi-sdr-gps-sim_amd", "csrc")
     exe = str(tmp_path / "drift_enclosure")
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"), "-I" + csrc, "-o", exe,
-                    os.path.join(root, "tests", "drift_enclosure.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), "-lpthread", "-lm"], check=True)
+                    os.path.join(root, "tests", "drift_enclosure.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), os.path.join(csrc, "gpsiq_chain.cpp"), "-lpthread", "-lm"], check=True)
     for seed in ("1",):
         r = subprocess.run([exe, seed], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -139,7 +139,7 @@ def test_eight_cycles_at_once_equal_the_scalar_walk(tmp_path):
     csrc = os.path.join(root, "multi-sdr-gps-sim_amd", "csrc")
     exe = str(tmp_path / "batch_walk")
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"), "-I" + csrc, "-o", exe,
-                    os.path.join(root, "tests", "batch_walk.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), "-lpthread", "-lm"], check=True)
+                    os.path.join(root, "tests", "batch_walk.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), os.path.join(csrc, "gpsiq_chain.cpp"), "-lpthread", "-lm"], check=True)
     r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     f = dict(kv.split("=") for kv in r.stdout.split())
