@@ -296,8 +296,7 @@ int gpsiq_shard_seed(gpsiq_qchan_t *q, int nblocks, int nchan, int nsamp,
                      const gpsiq_shard_carry_t *all /* [world][nchan], rank-major */, int rank);
 
 /* ---- [boundary] device context and the drop-in calls ------------------------ */
-/* device = HIP device ordinal.  Fails (GPSIQ_E_DEVICE) when no GPU is present:
- * there is no CPU fallback in this library. */
+/* device = HIP device ordinal.  GPSIQ_E_DEVICE when no GPU is present: the library has no CPU path. */
 int  gpsiq_create(gpsiq_ctx_t **ctx, int device);
 void gpsiq_destroy(gpsiq_ctx_t *ctx);
 
@@ -312,7 +311,8 @@ int  gpsiq_set_nco_mode(gpsiq_ctx_t *ctx, int mode);
  * the loop leaves it in chan[i].carr_phase.  The context remembers the exact
  * 59-bit phase per slot: when the next call passes back the same prn and the same
  * carr_phase double it handed out, the exact value is continued; any other value
- * (allocateChannel re-initialising a slot, gps.c:2208-2214) re-seeds from the double. */
+ * (allocateChannel re-initialising a slot, gps.c:2208-2214) re-seeds from the double.
+ * (Staged through a slot of its own: the resident set of gpsiq_set_descriptors is not touched.) */
 int gpsiq_generate_block(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, double *carr_phase_out);

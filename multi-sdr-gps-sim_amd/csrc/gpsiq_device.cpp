@@ -707,6 +707,9 @@ struct RefRender {
         const hipError_t s2 = hipStreamSynchronize(c->stream);
         if (s0 != hipSuccess || s1 != hipSuccess || s2 != hipSuccess)
             return fail(GPSIQ_E_DEVICE, "reference NCO pieces: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1 != hipSuccess ? s1 : s2));
+        // every launch waited for its set's upload on the device and has finished: later launches on the resident set need not
+        // wait for that (long completed) event again
+        for (auto &b : c->buf) b.upload_pending = false;
         return GPSIQ_OK;
     }
 };
@@ -721,7 +724,8 @@ struct RefRender {
 // GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
 static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool kernel_bound = false)
 {
-    static const bool ramp = [] { const char *e = std::getenv("GPSIQ_REF_CHUNK_RAMP"); return !e || std::atoi(e) != 0; }();
+    const char *ramp_env = std::getenv("GPSIQ_REF_CHUNK_RAMP");              // read per call, like GPSIQ_PIECE_GROWTH below
+    const bool ramp = !ramp_env || std::atoi(ramp_env) != 0;
     const int half = chunk > 1 ? chunk / 2 : 1;
     if (!ramp || n <= 4 * chunk) {
         for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
@@ -757,10 +761,23 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool
 // threads (2.7 us at 2.6 Msps, 4.5 us at 25 Msps, in the call).  At 25 Msps on sixteen threads the two sides are within 1.5 x of
 // each other and the symmetric ramp measured better (1.77 against 1.91 ms per 200 blocks): only a clear case takes the few
 // growing pieces.
+// The two rates: MI355X + EPYC 9575F as measured; another GPU or host names its own (read per call, like every other knob here):
+// GPSIQ_RATE_KERNEL in channel-samples per second, GPSIQ_RATE_CHAIN_US in microseconds per block and channel of the serial walk.
+static double rate_kernel()
+{
+    if (const char *e = std::getenv("GPSIQ_RATE_KERNEL")) { const double v = std::atof(e); if (v > 1e9) return v; }
+    return 6.0e12;
+}
+static double rate_chain_us()
+{
+    if (const char *e = std::getenv("GPSIQ_RATE_CHAIN_US")) { const double v = std::atof(e); if (v > 0.01) return v; }
+    return 2.2;
+}
+
 static bool ref_kernel_bound(int nsamp, int nchan)
 {
     const int threads = host_threads() < nchan ? host_threads() : nchan;
-    const double t_kernel = (double) nsamp * (double) nchan / 6.0e12;
+    const double t_kernel = (double) nsamp * (double) nchan / rate_kernel();
     const double t_host = (double) nchan * (2.5e-6 + 0.8e-12 * (double) nsamp) / (double) (threads > 0 ? threads : 1);
     return t_kernel > 2.0 * t_host;
 }
@@ -869,8 +886,8 @@ static bool chain_on_device(int nblocks, int nsamp, int nchan)
     if (e && !std::strcmp(e, "device")) return nblocks > 1;
     if (nblocks < 48) return false;
     const int threads = host_threads() < nchan ? host_threads() : nchan;
-    const double t_kernel = (double) nsamp * (double) nchan / 6.0e12;
-    const double t_chain = 2.2e-6 * (double) nchan / (double) (threads > 0 ? threads : 1);
+    const double t_kernel = (double) nsamp * (double) nchan / rate_kernel();
+    const double t_chain = rate_chain_us() * 1e-6 * (double) nchan / (double) (threads > 0 ? threads : 1);
     return t_chain > 0.5 * t_kernel;
 }
 
@@ -886,6 +903,17 @@ static void chain_stage_inputs(gpsiq_ctx *c, const gpsiq_chan_t *ch, int b0, int
 }
 
 static void *run_walk(void *w) { static_cast<RefWalk *>(w)->run(); return nullptr; }
+
+// ref_q / ref_start are kept between calls (a fresh 1.5 MB per call is four hundred page faults on the critical thread) -- but not
+// at the size of the largest batch the context has ever seen: a call that needed less than an eighth of what is held (and what is
+// held is more than 16 MB) gives the rest back
+static void trim_retained(gpsiq_ctx *c, size_t need)
+{
+    if (c->ref_q.capacity() > (size_t) 8 * need && c->ref_q.capacity() * sizeof(gpsiq_qchan_t) > ((size_t) 16 << 20)) {
+        std::vector<gpsiq_qchan_t>(need).swap(c->ref_q);
+        std::vector<double>(c->ref_start.size() < need ? c->ref_start.size() : need).swap(c->ref_start);
+    }
+}
 
 // GPSIQ_NCO_REFERENCE form of both drop-in calls: the carrier is the caller's double, walked exactly
 static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
@@ -917,7 +945,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         rc = chain_reserve(c, (size_t) nblocks * (size_t) nchan);
         if (rc) return rc;
         // the head: pieces worth ~0.4 ms of synthesis (the second launch's latency + its first piece's evaluation)
-        const double t_block = (double) nsamp * (double) nchan / 6.0e12;
+        const double t_block = (double) nsamp * (double) nchan / rate_kernel();
         int want = (int) (0.4e-3 / t_block) + 1;
         if (const char *e = std::getenv("GPSIQ_CHAIN_HEAD")) want = std::atoi(e);            // blocks; <= 0: one launch (A/B)
         if (want > 0 && 2 * want < nblocks)
@@ -990,6 +1018,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     if (carr_phase_out)
         for (int i = 0; i < nchan; ++i)
             carr_phase_out[i] = w.last_prn[i] ? w.carr_end[i] : ch[(size_t) (nblocks - 1) * nchan + i].carr_phase;
+    trim_retained(c, (size_t) nblocks * (size_t) nchan);
     return GPSIQ_OK;
 }
 
@@ -1090,15 +1119,21 @@ int gpsiq_generate_block_async(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nchan
     }
     if (nsamp > 0) {
         const int v = max_step <= kRowsMaxCodeStep ? kSeg : max_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
-        HIP_TRY(hipMemcpyAsync(a.d, a.h, (size_t) nchan * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_variant(v, a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, c->stream, na, amp, nullptr));
-        if (!patches.empty()) {
+        // once the first copy is queued a failure must not return with work in flight on the slot's page-locked staging (the next
+        // call would rewrite it under the copy): the stream is drained first
+        hipError_t e = hipMemcpyAsync(a.d, a.h, (size_t) nchan * sizeof(gpsiq_qchan_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_variant(v, a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, c->stream, na, amp, nullptr);
+        if (e == hipSuccess && !patches.empty()) {
             std::memcpy(a.h_patch, patches.data(), patches.size() * sizeof(gpsiq_patch_t));
-            HIP_TRY(hipMemcpyAsync(a.d_patch, a.h_patch, patches.size() * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_patches(a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, a.d_patch, (int) patches.size(), c->stream));
+            e = hipMemcpyAsync(a.d_patch, a.h_patch, patches.size() * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_patches(a.d, nchan, nsamp, sample_size, a.out, stride, 0, 1, c->d_tab, a.d_patch, (int) patches.size(), c->stream);
         }
-        HIP_TRY(hipMemcpyAsync(dst, a.out, blk_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(a.done, c->stream));
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, a.out, blk_bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(a.done, c->stream);
+        if (e != hipSuccess) {
+            (void) hipStreamSynchronize(c->stream);
+            return fail(GPSIQ_E_DEVICE, "block: %s", hipGetErrorString(e));
+        }
         a.busy = true;
         c->anext = (c->anext + 1) & 3;
     }
@@ -1194,6 +1229,7 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         char err[400] = "";
         if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
         const int src = gpsiq_synchronize(c, c->stream);              // on every path: the kernels write the caller's buffer
+        if (src == GPSIQ_OK) for (auto &b : c->buf) b.upload_pending = false;     // the uploads the launches waited for are done
         if (rc != GPSIQ_OK) return fail(rc, "%s", err);
         if (src != GPSIQ_OK) return src;
         if (trace) std::fprintf(stderr, "[gpsiq trace] batch %d blocks in pieces of %d: whole call %.2f ms\n", nblocks, piece, wall_ms() - t0);
