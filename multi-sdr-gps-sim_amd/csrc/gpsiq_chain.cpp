@@ -103,7 +103,12 @@ static void map_block(const Prep *prep, int nchan, int i, int b, double c_before
     if (W->general) return;
     const int nseg = lane::stretches(p.c, nsamp, max_seg);
     lane::Stretch st[lane::kMaxSeg];
-    for (int t = 0; t < nseg; ++t) lane::walk_stretch(*W, prev, p, nsamp, t, nseg, &st[t]);
+    // the block's table of whole cycles, when the block has cycles enough to pay for it (the device builds one entry per lane)
+    lane::Cycle tab[lane::kEntriesHost];
+    const bool use_tab = std::fabs(p.c) * (double) nsamp > 2.0 * lane::kEntriesHost;
+    if (use_tab)
+        for (int k = 0; k < lane::kEntriesHost; ++k) lane::build_cycle(*W, k, lane::kEntriesHost, &tab[k]);
+    for (int t = 0; t < nseg; ++t) lane::walk_stretch(*W, prev, p, nsamp, t, nseg, use_tab ? tab : nullptr, lane::kEntriesHost, &st[t]);
     lane::join_stretches(st, nseg, W->neg, rec);
 }
 

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     __shared__ __attribute__((aligned(16))) unsigned char walker_raw[sizeof(Walker) * (kBlocks + 1)];
     Walker *walker = reinterpret_cast<Walker *>(walker_raw);
     __shared__ Stretch stretch[kLaneThreads];
+    __shared__ lane::Cycle cycles[kLaneThreads];               // cycles[blk * kSeg + k]: entry k of block blk's table
     __shared__ int usable[kBlocks + 1];
     const int groups = (nblocks + kBlocks - 1) / kBlocks;
     const int i = blockIdx.x / groups, b0 = (blockIdx.x % groups) * kBlocks;
@@ -178,14 +179,24 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     }
     __syncthreads();
     const int blk = tid / kSeg, t = tid % kSeg, b = b0 + blk;
+    // the block's table of whole cycles: every lane of the block walks one, from post-wrap states spread over their range
+    const bool live = b < nblocks && usable[blk + 1];
+    Prep p = {0.0, 0.0, 0.0, lane::kSkip, 0};
+    if (live) p = prep[(size_t) b * nchan + i];
+    const bool use_tab = live && kSeg >= 8 && __builtin_fabs(p.c) * (double) nsamp > 2.0 * kSeg;
+    if (use_tab) {
+        lane::Cycle e;
+        lane::build_cycle(walker[blk + 1], t, kSeg, &e);
+        cycles[tid] = e;
+    }
+    __syncthreads();
     int nseg = 0;
-    if (b < nblocks && usable[blk + 1]) {
-        const Prep p = prep[(size_t) b * nchan + i];
+    if (live) {
         nseg = lane::stretches(p.c, nsamp, max_seg < kSeg ? max_seg : kSeg);
         if (t < nseg) {
             const Walker *prev = (!(p.flags & lane::kSeed) && usable[blk]) ? &walker[blk] : nullptr;
             Stretch st;
-            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, &st);
+            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, use_tab ? &cycles[blk * kSeg] : nullptr, kSeg, &st);
             stretch[tid] = st;
         }
     }

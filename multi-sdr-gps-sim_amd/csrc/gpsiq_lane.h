@@ -193,9 +193,66 @@ GPSIQ_HD inline int stretches(double c, long nsamp, int max_seg)
     return s;
 }
 
+// ---- the block's table of whole cycles -----------------------------------------------------------------------------------
+// From one wrap to the next the accumulator runs through the same dozen binades whatever the post-wrap state was, and a cycle
+// walked from one post-wrap state holds, translated, for a whole range of them (the walk's own range): a block's ~260 cycles are
+// a dozen distinct ones.  So the lanes of a block first walk ONE cycle each, from post-wrap states spread evenly over their
+// range [0, c] or [1 + c, 1) (kEntries of them: an entry {range of start states, state increment, samples}), and a stretch then
+// LOOKS its cycles UP: a comparison and an exact addition instead of ~20 binade steps, with the distance of the state to the
+// entry's edges noted like the distance of a result to its binade's edges.  A state no entry covers (a sliver between two
+// sampled cycles, a cycle with an exact tie on its wrap) is walked as before.  This is NcoWalk's wrap-to-wrap table (gpsiq_exact.cpp)
+// built from an even sample instead of on demand: the device has the lanes for it.
+struct Cycle { double first, last, inc; int32_t steps, ok; };       // 32 bytes; first / last / inc are multiples of the wrap grid
+
+constexpr int kEntriesHost = 32;
+
+GPSIQ_HD inline void build_cycle(const Walker &W, int k, int nent, Cycle *out)
+{
+    Cycle e;
+    e.first = 0.0; e.last = 0.0; e.inc = 0.0; e.steps = 0; e.ok = 0;
+    *out = e;
+    if (W.general) return;
+    const double a = __builtin_fabs(W.c);
+    const double grid = W.neg ? 0x1p-53 : 0x1p-52, inv = W.neg ? 0x1p53 : 0x1p52;
+    const double x0 = __builtin_rint(((W.neg ? 1.0 - a : 0.0) + a * (((double) k + 0.5) / (double) nent)) * inv) * grid;
+    if (!(x0 >= 0.0 && x0 < 1.0)) return;
+    typename WalkCore<kTab>::FastSlack sl;
+    sl.init(W.neg ? 1022 : 1023);
+    if (x0 >= W.thr) sl.note(x0);
+    double x = x0;
+    long n = 0;
+    const long cap = (long) (2.0 / a) + 8;                          // a cycle is 1/|c| samples give or take one
+    const bool wrapped = W.neg ? W.template descend<true>(x, n, cap, &sl) : W.template climb<true>(x, n, cap, &sl);
+    int64_t lo, hi;
+    if (!wrapped || !sl.finish(&lo, &hi) || lo > 0 || hi < 0 || !(x >= 0.0 && x < 1.0)) return;
+    // post-wrap states lie in [0, 1): what the range allows beyond that is never asked for
+    double first = x0 + (lo < -((int64_t) 1 << 53) ? -1.0 : (double) lo * grid), last = x0 + (hi > ((int64_t) 1 << 53) ? 1.0 : (double) hi * grid);
+    if (first < 0.0) first = 0.0;
+    if (last > 1.0 - grid) last = 1.0 - grid;
+    e.first = first; e.last = last; e.inc = x - x0; e.steps = (int32_t) n; e.ok = 1;
+    *out = e;
+}
+
+// the entry that holds post-wrap state x, or null: the entry sampled nearest to x first, then its neighbours
+GPSIQ_HD inline const Cycle *find_cycle(const Cycle *tab, int nent, const Walker &W, double x)
+{
+    const double a = __builtin_fabs(W.c);
+    int k0 = (int) ((x - (W.neg ? 1.0 - a : 0.0)) / a * (double) nent);
+    if (k0 < 0) k0 = 0;
+    if (k0 >= nent) k0 = nent - 1;
+    for (int d = 0; d < nent; ++d) {
+        const int k = k0 + ((d & 1) ? (d + 1) / 2 : -(d / 2));      // k0, k0 + 1, k0 - 1, k0 + 2, ...
+        if (k < 0 || k >= nent) continue;
+        const Cycle &e = tab[k];
+        if (e.ok && x >= e.first && x <= e.last) return &e;
+        if (d >= 8) break;                                          // farther away than four samples either side: a sliver, walk it
+    }
+    return nullptr;
+}
+
 // the walk of stretch t of nseg of a block: W the walker of the block's addend, Wp of the previous block's (stretch 0 of a
-// block that is no seed only); p: the block's Prep; prev_c: the previous block's addend (0: none)
-GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep &p, long nsamp, int t, int nseg, Stretch *out)
+// block that is no seed only); p: the block's Prep; tab[nent]: the block's table of cycles (null: every cycle walked)
+GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep &p, long nsamp, int t, int nseg, const Cycle *tab, int nent, Stretch *out)
 {
     Stretch o;
     o.n_in = -1; o.r_in = 0.0; o.n_out = -1; o.x_out = 0.0; o.x_end = 0.0; o.lo = 0; o.hi = 0; o.ok = 0; o.why = kWhyAddend;
@@ -206,6 +263,7 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
     sl.init(W.neg ? 1022 : 1023);
     double x;
     long n;
+    bool at_wrap;                                    // x is the state right after a wrap: the table may know its cycle
     if (t == 0) {
         if (p.flags & kSeed) x = p.est;
         else {
@@ -222,6 +280,7 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
         if (!(x >= 0.0 && x < 1.0)) return;
         o.n_in = 0; o.r_in = x;
         n = 0;
+        at_wrap = false;
     } else {
         // the accumulator at sample a0: the block's start + a0 additions + the share of the block's drift
         const double fa = (double) a0, pr = fa * p.c, pe = __builtin_fma(fa, p.c, -pr);
@@ -231,13 +290,34 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
         if (!last_wrap(s, p.c, &k, &x) || k > a0) return;
         n = a0 - k;
         o.n_in = (int32_t) n; o.r_in = x;
+        at_wrap = true;
     }
     o.n_out = o.n_in; o.x_out = x;
     if (x >= W.thr) sl.note(x);                      // a start inside a table binade has to stay in it (results are noted by the walk)
+    const bool need_end = t == nseg - 1;             // only the block's last stretch is asked for the state at its end sample
     while (n < a1) {
+        if (at_wrap && tab) {
+            const Cycle *e = find_cycle(tab, nent, W, x);
+            if (e) {
+                if (n + e->steps <= a1) {            // the whole cycle lies inside the stretch: the entry IS the cycle, translated
+                    sl.room_below(x - e->first);
+                    sl.room_above(e->last - x);
+                    x += e->inc;                     // exact: both are multiples of the wrap grid, and so is the state after the wrap
+                    n += e->steps;
+                    o.n_out = (int32_t) n; o.x_out = x;
+                    continue;
+                }
+                if (!need_end) {                     // the next wrap lies beyond the stretch: nothing more to find out here
+                    sl.room_below(x - e->first);     // (as long as this state is one the entry holds for)
+                    sl.room_above(e->last - x);
+                    break;
+                }
+            }
+        }
         const bool wrapped = W.neg ? W.template descend<true>(x, n, a1, &sl) : W.template climb<true>(x, n, a1, &sl);
         if (!wrapped) break;
         o.n_out = (int32_t) n; o.x_out = x;
+        at_wrap = true;
     }
     o.x_end = x;
     // the slack counts units of the wrap grid: 2^-52 for a positive addend
