@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     __shared__ __attribute__((aligned(16))) unsigned char walker_raw[sizeof(Walker) * (kBlocks + 1)];
     Walker *walker = reinterpret_cast<Walker *>(walker_raw);
     __shared__ Stretch stretch[kLaneThreads];
-    __shared__ lane::Cycle cycles[kLaneThreads];               // cycles[blk * kSeg + k]: entry k of block blk's table
+    __shared__ lane::Cycle cycles[kSeg >= 32 ? kLaneThreads : 1];     // cycles[blk * kSeg + k]: entry k of block blk's table
     __shared__ int usable[kBlocks + 1];
     const int groups = (nblocks + kBlocks - 1) / kBlocks;
     const int i = blockIdx.x / groups, b0 = (blockIdx.x % groups) * kBlocks;
@@ -183,11 +183,12 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     const bool live = b < nblocks && usable[blk + 1];
     Prep p = {0.0, 0.0, 0.0, lane::kSkip, 0};
     if (live) p = prep[(size_t) b * nchan + i];
-    const bool use_tab = live && kSeg >= 8 && __builtin_fabs(p.c) * (double) nsamp > 2.0 * kSeg;
+    // (with fewer than 32 lanes per block the sample is too thin: a tenth of the look-ups miss, and a wave waits for its unluckiest lane)
+    const bool use_tab = live && kSeg >= 32 && __builtin_fabs(p.c) * (double) nsamp > 2.0 * kSeg;
     if (use_tab) {
         lane::Cycle e;
         lane::build_cycle(walker[blk + 1], t, kSeg, &e);
-        cycles[tid] = e;
+        cycles[kSeg >= 32 ? tid : 0] = e;
     }
     __syncthreads();
     int nseg = 0;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
         if (t < nseg) {
             const Walker *prev = (!(p.flags & lane::kSeed) && usable[blk]) ? &walker[blk] : nullptr;
             Stretch st;
-            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, use_tab ? &cycles[blk * kSeg] : nullptr, kSeg, &st);
+            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, use_tab ? &cycles[kSeg >= 32 ? blk * kSeg : 0] : nullptr, kSeg, &st);
             stretch[tid] = st;
         }
     }

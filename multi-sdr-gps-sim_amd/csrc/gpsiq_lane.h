@@ -295,25 +295,25 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
     o.n_out = o.n_in; o.x_out = x;
     if (x >= W.thr) sl.note(x);                      // a start inside a table binade has to stay in it (results are noted by the walk)
     const bool need_end = t == nseg - 1;             // only the block's last stretch is asked for the state at its end sample
-    while (n < a1) {
-        if (at_wrap && tab) {
+    // Two loops, for the device's sake: inside, a lane looks up cycle after cycle for as long as the table knows them (a dozen
+    // instructions each); outside, ONE cycle is walked (a thousand instructions) by the lanes that met a state no entry covers
+    // -- 2 % of the look-ups, so with one loop every round of a 64-lane wave would have a lane walking and 63 waiting for it.
+    bool done = false;
+    while (!done) {
+        while (at_wrap && tab && n < a1) {
             const Cycle *e = find_cycle(tab, nent, W, x);
-            if (e) {
-                if (n + e->steps <= a1) {            // the whole cycle lies inside the stretch: the entry IS the cycle, translated
-                    sl.room_below(x - e->first);
-                    sl.room_above(e->last - x);
-                    x += e->inc;                     // exact: both are multiples of the wrap grid, and so is the state after the wrap
-                    n += e->steps;
-                    o.n_out = (int32_t) n; o.x_out = x;
-                    continue;
-                }
-                if (!need_end) {                     // the next wrap lies beyond the stretch: nothing more to find out here
-                    sl.room_below(x - e->first);     // (as long as this state is one the entry holds for)
-                    sl.room_above(e->last - x);
-                    break;
-                }
+            if (!e) break;
+            sl.room_below(x - e->first);             // this state is one the entry holds for; how far it may move
+            sl.room_above(e->last - x);
+            if (n + e->steps > a1) {                 // the next wrap lies beyond the stretch
+                done = !need_end;                    // nothing more to find out here, unless the state at the end sample is wanted
+                break;
             }
+            x += e->inc;                             // the whole cycle lies inside the stretch: the entry IS the cycle, translated
+            n += e->steps;                           // (exact: both are multiples of the wrap grid, and so is the state after the wrap)
+            o.n_out = (int32_t) n; o.x_out = x;
         }
+        if (done || n >= a1) break;
         const bool wrapped = W.neg ? W.template descend<true>(x, n, a1, &sl) : W.template climb<true>(x, n, a1, &sl);
         if (!wrapped) break;
         o.n_out = (int32_t) n; o.x_out = x;
