@@ -2,7 +2,7 @@
 # Every step writes under gpurun_out/<TAG>_*; profiles are summarised into profiles/<TAG>_* by scripts/prof_summary.py.
 #   tests    pytest -m gpu, the whole suite                      refnco   the reference-NCO GPU tests only
 #   chain    device carrier chain: its tests, scripts/chain_timing.py   chainab  scripts/chain_ab.py (knobs + piece timelines)
-#   chainpmc rocprofv3 counters of the chain kernels (scripts/chain_pmc.py)
+#   chainpmc rocprofv3 counters of the chain kernels (scripts/chain_pmc.py)      soak     tests/soak_chain_device.py, 3 seeds
 #   cpu      pytest -m "not gpu" on the box's host               smoke    __graft_entry__.smoke()
 #   bench    the default bench line                              sweep    bench.py --sweep (all kernel variants, refresh sweep)
 #   2rank    bench.py --gpus 2 over gloo on the box's one GPU (the N > 1 code path; GPSIQ_BENCH_SHARE_GPU=1)
@@ -24,6 +24,8 @@ for step in "$@"; do
           -d $O/a -o pmc -- python $GRAFT_REPO_ROOT/scripts/chain_pmc.py > $O/a.log 2>&1; grep Msps $O/a.log ) ;;
     refnco)
       ( timeout 1500 python -m pytest tests/test_gpu_reference_nco.py tests/test_config5_shares.py -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${TAG}_refnco_tests.log 2>&1; tail -4 gpurun_out/${TAG}_refnco_tests.log ;;
+    soak)
+      for s in 1 2 3; do ( timeout 200 python tests/soak_chain_device.py ${SOAK_SECONDS:-50} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_chain_device.txt ;;
     tests)
       ( timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${TAG}_pytest_gpu.log ;;
     cpu)
