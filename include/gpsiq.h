@@ -222,7 +222,7 @@ int gpsiq_reference_seeded(const gpsiq_chan_t *ch, int nblocks, int nchan, doubl
 /* The chain, parallel in time (csrc/gpsiq_lane.h has the method).  x += c in double is a TRANSLATION on a whole residue class
  * of start states, so every block can be walked on its own from a representative start state near an estimate of the true
  * one (exact real arithmetic + modelled rounding drift), which yields a certified map of the block
- *     start xs + d*2^-53, lo <= d <= hi   ->   end e + (d + cum)*2^-53;
+ *     start xs + d*2^-53, lo <= d <= hi   ->   end e + (d + cum[parity of d])*2^-53;
  * the chain proper is then one exact subtraction, range check and addition per block (gpsiq_chain_link), with a true walk
  * of the rare block whose map does not apply.  carr_start / carr_end / last_prn are gpsiq_reference_chain's, bit for bit.
  *   gpsiq_chain_maps     level 1 of blocks [0, nblocks): every block independent of every other -- host threads here,
@@ -254,8 +254,8 @@ typedef struct gpsiq_chain_est {
 #define GPSIQ_CHAIN_EMPTY    4   /* summary of no blocks */
 typedef struct gpsiq_chain_map {
     double  xs, e;        /* representative state at the block's first sample; state after the block */
-    int64_t cum, lo, hi;  /* units of 2^-53 */
-    int32_t ok, even;     /* ok 0: no map, the block is walked; even: d must be even (positive addend) */
+    int64_t cum[2], lo, hi;   /* units of 2^-53; cum[p]: d an even / odd number of steps of the wrap's grid (a tie on a wrap sends odd ones aside) */
+    int32_t ok, info;     /* ok 0: no map, the block is walked; bit p: holds for parity p.  info: bits 0-7 units per grid step */
 } gpsiq_chain_map_t;
 int gpsiq_chain_maps(const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
                      const gpsiq_chain_est_t *start, int max_stretches, gpsiq_chain_map_t *maps, gpsiq_chain_est_t *end);

@@ -18,7 +18,7 @@ using lane::Rec;
 using lane::u128;
 
 static_assert(sizeof(gpsiq_chain_map_t) == sizeof(Rec), "gpsiq_chain_map_t is lane::Rec");
-static_assert(sizeof(Prep) == 32 && sizeof(Rec) == 48 && sizeof(gpsiq_chain_est_t) == 56, "layouts shared with the device");
+static_assert(sizeof(Prep) == 32 && sizeof(Rec) == 56 && sizeof(gpsiq_chain_est_t) == 56, "layouts shared with the device");
 
 // One slot's estimator between two blocks, unpacked.
 struct EstState {

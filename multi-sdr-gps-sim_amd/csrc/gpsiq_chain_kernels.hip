@@ -13,7 +13,7 @@
 //                   a wave take the same binades in the same order and diverge only at the ends of runs.  The walkers'
 //                   per-binade tables (one 64-bit division per binade) are built once per block in LDS, the divisions spread
 //                   over the workgroup's threads; the stretches of a block are joined by its first lane.
-// No MFMA (no contraction), no LDS staging of anything big: 48 bytes out per block and slot; the kernel is latency-bound on
+// No MFMA (no contraction), no LDS staging of anything big: 56 bytes out per block and slot; the kernel is latency-bound on
 // dependent FP64 / 64-bit integer VALU chains, which is why the work is cut into as many lanes as there are wraps to spare.
 #include <hip/hip_runtime.h>
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     __syncthreads();
     if (b < nblocks && t == 0) {
         Rec r;
-        r.xs = 0.0; r.e = 0.0; r.cum = 0; r.lo = 0; r.hi = 0; r.ok = 0; r.even = 0;
+        r.xs = 0.0; r.e = 0.0; r.cum[0] = 0; r.cum[1] = 0; r.lo = 0; r.hi = 0; r.ok = 0; r.info = 0;
         if (nseg > 0) lane::join_stretches(&stretch[blk * kSeg], nseg, walker[blk + 1].neg, &r);
         rec[(size_t) b * nchan + i] = r;
     }

@@ -22,7 +22,7 @@ size_t variant_scratch_bytes(int variant, int nsamp, int nblocks);
 hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size, void *dst, size_t block_stride,
                           int block0, int nblocks, const DeviceTables *tab, const gpsiq_patch_t *patches, int npatch,
                           hipStream_t stream);
-// the time-parallel carrier chain (gpsiq_chain_kernels.hip; the buffers are opaque here: 32-byte Prep, 48-byte maps)
+// the time-parallel carrier chain (gpsiq_chain_kernels.hip; the buffers are opaque here: 32-byte Prep, 56-byte maps)
 hipError_t launch_chain(const gpsiq_chain_in_t *d_in, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
                         int max_seg, void *d_prep, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream);
 int chain_link(const gpsiq_chain_in_t *in, const void *maps, int nblocks, int nchan, double delt, int nsamp,

@@ -49,14 +49,15 @@ enum : int32_t {
     kSkip = 2,           // no map for this block (unused slot, an addend the fast walk does not take): true walk, or nothing
 };
 
-// the certified map of one block (level 1 result), 48 bytes
+// the certified map of one block (level 1 result), 56 bytes
 struct Rec {
     double  xs;          // representative state at the block's first sample
     double  e;           // state after the block when the last stretch starts from its own representative
-    int64_t cum;         // the true end is e + (d + cum)*U for a true start xs + d*U
-    int64_t lo, hi;      // ... if lo <= d <= hi (units of U = 2^-53; positive addends need an even d)
-    int32_t ok;          // 0: no map (level 2 walks the block from its true start)
-    int32_t even;        // d must be even (positive addend: the wrap rounds on the grid of [1, 2))
+    int64_t cum[2];      // the true end is e + (d + cum[p])*U for a true start xs + d*U, p = parity of d counted in steps of the wrap's
+                         // grid (1 unit for a negative addend, 2 for a positive one): an exact tie on a wrap sends odd offsets one step aside
+    int64_t lo, hi;      // ... if lo <= d <= hi (units of U = 2^-53)
+    int32_t ok;          // 0: no map (level 2 walks the block from its true start); bit 0: the map holds for even p, bit 1: for odd p
+    int32_t info;        // bits 0-7: units per grid step (d must be a multiple), bits 8-15: why not ok (the statistics' business)
 };
 
 // ---- exact real arithmetic of the phase: 2^-128 cycle units, the wrap is the overflow -----------------------------------
@@ -179,9 +180,10 @@ struct Stretch {
     double  x_end;       // state at the stretch's end sample
     int64_t lo, hi;      // units of U = 2^-53, relative to the stretch's own start
     int32_t n_in, n_out; // sample indices inside the block
-    int16_t ok, why;     // ok == 0: what stood in the way (kWhy*), for the statistics
+    int16_t ok, why;     // ok == 0: what stood in the way (kWhy*), for the statistics; ok == 2: for even offsets of the wrap's grid only
+    int16_t sigma, pad;  // the stretch's first exact tie on a wrap: odd offsets go on sigma grid steps aside (0: none)
 };
-enum { kWhyNone = 0, kWhyAddend = 1, kWhyPrev = 2, kWhyWrap = 3, kWhyState = 4, kWhyAnchor = 5, kWhySlack = 6, kWhyEdge = 7, kWhyJoin = 8, kWhyUnits = 9, kWhyRange = 10 };
+enum { kWhyNone = 0, kWhyAddend = 1, kWhyPrev = 2, kWhyWrap = 3, kWhyState = 4, kWhyAnchor = 5, kWhySlack = 6, kWhyEdge = 7, kWhyJoin = 8, kWhyUnits = 9, kWhyRange = 10, kWhyParity = 11 };
 
 // how many stretches a block gets: at least ~4 wraps in each
 GPSIQ_HD inline int stretches(double c, long nsamp, int max_seg)
@@ -224,7 +226,7 @@ GPSIQ_HD inline void build_cycle(const Walker &W, int k, int nent, Cycle *out)
     const long cap = (long) (2.0 / a) + 8;                          // a cycle is 1/|c| samples give or take one
     const bool wrapped = W.neg ? W.template descend<true>(x, n, cap, &sl) : W.template climb<true>(x, n, cap, &sl);
     int64_t lo, hi;
-    if (!wrapped || !sl.finish(&lo, &hi) || lo > 0 || hi < 0 || !(x >= 0.0 && x < 1.0)) return;
+    if (!wrapped || sl.sigma || W.top_tie || !sl.finish(&lo, &hi) || lo > 0 || hi < 0 || !(x >= 0.0 && x < 1.0)) return;
     // post-wrap states lie in [0, 1): what the range allows beyond that is never asked for
     double first = x0 + (lo < -((int64_t) 1 << 53) ? -1.0 : (double) lo * grid), last = x0 + (hi > ((int64_t) 1 << 53) ? 1.0 : (double) hi * grid);
     if (first < 0.0) first = 0.0;
@@ -255,7 +257,7 @@ GPSIQ_HD inline const Cycle *find_cycle(const Cycle *tab, int nent, const Walker
 GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep &p, long nsamp, int t, int nseg, const Cycle *tab, int nent, Stretch *out)
 {
     Stretch o;
-    o.n_in = -1; o.r_in = 0.0; o.n_out = -1; o.x_out = 0.0; o.x_end = 0.0; o.lo = 0; o.hi = 0; o.ok = 0; o.why = kWhyAddend;
+    o.n_in = -1; o.r_in = 0.0; o.n_out = -1; o.x_out = 0.0; o.x_end = 0.0; o.lo = 0; o.hi = 0; o.ok = 0; o.why = kWhyAddend; o.sigma = 0; o.pad = 0;
     *out = o;
     if ((p.flags & kSkip) || W.general || !(p.c != 0.0)) return;
     const long a0 = (long) (((int64_t) t * nsamp) / nseg), a1 = (long) (((int64_t) (t + 1) * nsamp) / nseg);
@@ -324,6 +326,8 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
     const bool slack_ok = sl.finish(&o.lo, &o.hi);
     if (!W.neg) { o.lo *= 2; o.hi *= 2; }
     o.ok = slack_ok && o.lo <= 0 && o.hi >= 0 && x >= 0.0 && x < 1.0;
+    if (o.ok && W.top_tie) o.ok = 2;                 // (every cycle's first addition is a tie on the unit's own grid: even offsets only)
+    o.sigma = (int16_t) sl.sigma;
     o.why = o.ok ? kWhyNone : !slack_ok ? kWhySlack : kWhyEdge;
     *out = o;
 }
@@ -332,20 +336,35 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
 GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *rec)
 {
     Rec r;
-    r.xs = st[0].r_in; r.e = st[nseg - 1].x_end; r.cum = 0; r.lo = st[0].lo; r.hi = st[0].hi; r.ok = st[0].ok; r.even = neg ? 0 : 1;
+    const int64_t grid = neg ? 1 : 2;                 // units of U per step of the wrap's grid
+    r.xs = st[0].r_in; r.e = st[nseg - 1].x_end; r.cum[0] = 0; r.cum[1] = 0; r.lo = st[0].lo; r.hi = st[0].hi; r.ok = st[0].ok ? 3 : 0;
     int why = st[0].why;
-    for (int t = 1; t < nseg && r.ok; ++t) {
-        int64_t d;
-        if (!st[t].ok) { r.ok = 0; why = st[t].why; break; }
-        if (st[t - 1].n_out != st[t].n_in) { r.ok = 0; why = kWhyJoin; break; }
-        if (!exact_units(st[t - 1].x_out, st[t].r_in, &d)) { r.ok = 0; why = kWhyUnits; break; }
-        r.cum += d;                                   // stretch t starts cum units above its representative when stretch 0 starts on xs
-        const int64_t l = st[t].lo - r.cum, h = st[t].hi - r.cum;
-        if (l > r.lo) r.lo = l;
-        if (h < r.hi) r.hi = h;
+    // Branch p: the block's true start lies d = (2k + p) grid steps above xs.  cum[p]: how far the stretch at hand starts above
+    // ITS representative in that branch, less d.  A stretch with a tie sends an odd offset sigma steps aside (FastSlack::tie),
+    // a stretch that translates for even offsets only (ok == 2) closes the branch in which its offset is odd.
+    for (int t = 0; t < nseg && r.ok; ++t) {
+        if (t > 0) {
+            int64_t d;
+            if (!st[t].ok) { r.ok = 0; why = st[t].why; break; }
+            if (st[t - 1].n_out != st[t].n_in) { r.ok = 0; why = kWhyJoin; break; }
+            if (!exact_units(st[t - 1].x_out, st[t].r_in, &d) || d % grid) { r.ok = 0; why = kWhyUnits; break; }
+            r.cum[0] += d; r.cum[1] += d;
+            // the stretch's range holds for its own offset, before and after a step aside: a grid step short either side
+            const int64_t cmin = r.cum[0] < r.cum[1] ? r.cum[0] : r.cum[1], cmax = r.cum[0] < r.cum[1] ? r.cum[1] : r.cum[0];
+            const int64_t l = st[t].lo - cmin + grid, h = st[t].hi - cmax - grid;
+            if (l > r.lo) r.lo = l;
+            if (h < r.hi) r.hi = h;
+        }
+        for (int p = 0; p < 2; ++p) {
+            const bool odd = ((p + r.cum[p] / grid) & 1) != 0;              // parity of this stretch's offset, in grid steps
+            if (odd && st[t].ok == 2) r.ok &= ~(1 << p);
+            if (odd && st[t].sigma) r.cum[p] += (int64_t) st[t].sigma * grid;
+        }
+        if (!r.ok) why = kWhyParity;
     }
+    if (r.ok && st[0].sigma) { r.lo += grid; r.hi -= grid; }
     if (r.ok && r.lo > r.hi) { r.ok = 0; why = kWhyRange; }
-    if (!r.ok) r.even |= why << 8;              // the statistics' business only: link_block never looks at a map that is not ok
+    r.info = (int32_t) grid | (r.ok ? 0 : why << 8);
     *rec = r;
 }
 
@@ -355,9 +374,12 @@ GPSIQ_HD inline bool link_block(const Rec &r, double x, double *next)
 {
     int64_t d;
     if (!r.ok || !exact_units(x, r.xs, &d)) return false;
-    if (d < r.lo || d > r.hi || (r.even && (d & 1))) return false;
+    const int64_t grid = r.info & 0xff;
+    if (d < r.lo || d > r.hi || grid < 1 || d % grid) return false;
+    const int p = (int) ((d / grid) & 1);
+    if (!(r.ok & (1 << p))) return false;
     double y;
-    if (!exact_shift(r.e, d + r.cum, &y) || !(y >= 0.0 && y < 1.0)) return false;
+    if (!exact_shift(r.e, d + r.cum[p], &y) || !(y >= 0.0 && y < 1.0)) return false;
     *next = y;
     return true;
 }

@@ -64,6 +64,7 @@ struct WalkCore {
         GPSIQ_HD inline void room_above(double dist) { const int64_t h = (int64_t) (dist * 0x1p53) - 2; if (h < hi) hi = h; }
         GPSIQ_HD inline void room_below(double dist) { const int64_t l = 2 - (int64_t) (dist * 0x1p53); if (l > lo) lo = l; }
         GPSIQ_HD inline void fail() { ok = false; }
+        GPSIQ_HD inline void tie(double) { ok = false; }       // an exact tie on a wrap: not translation invariant for odd offsets
     };
 
     // The same bookkeeping in doubles, for the lanes of the time-parallel chain (gpsiq_lane.h; on the device 64-bit shifts and
@@ -75,7 +76,8 @@ struct WalkCore {
         double vmin, vmax;     // range of the noted values: they must be normal and inside the accumulator's range
         int    unit_exp;
         bool   ok;
-        GPSIQ_HD inline void init(int uexp) { dlo = 4.0; dhi = 4.0; vmin = 1.0; vmax = 0.0; unit_exp = uexp; ok = true; }
+        int    sigma;          // 0, or the first exact tie met on a wrap: +1 the sum went down to the even value, -1 up (tie())
+        GPSIQ_HD inline void init(int uexp) { dlo = 4.0; dhi = 4.0; vmin = 1.0; vmax = 0.0; unit_exp = uexp; ok = true; sigma = 0; }
         GPSIQ_HD inline void note(double v)
         {
             const double edge = from_bits(bits_of(v) & ~kMant), dl = v - edge, dh = edge - dl;
@@ -88,6 +90,12 @@ struct WalkCore {
         GPSIQ_HD inline void room_above(double dist) { dhi = dist < dhi ? dist : dhi; }
         GPSIQ_HD inline void room_below(double dist) { dlo = dist < dlo ? dist : dlo; }
         GPSIQ_HD inline void fail() { ok = false; }
+        // A sum exactly half way between two values of the wrap's grid goes to the even one.  Moved by an EVEN number of grid
+        // units it is half way again between values of the same parities and goes the same way: the walk translates.  Moved by
+        // an ODD number d it goes the other way: where this walk went down (err = exact - rounded > 0) to y, that one goes up to
+        // y + (d + 1) units, where this one went up, down to y + (d - 1): from there on its offset is d + sigma, an even number
+        // -- and even offsets translate through every later tie.  So only the FIRST tie of a walk matters, and its direction.
+        GPSIQ_HD inline void tie(double err) { if (!sigma) sigma = err > 0.0 ? 1 : -1; }
         // -> the range of start offsets in units of U (Slack's lo / hi); false: not usable
         GPSIQ_HD inline bool finish(int64_t *lo, int64_t *hi) const
         {
@@ -190,7 +198,7 @@ struct WalkCore {
                     sl->note(y);
                     if (kind == 0) sl->note_limit(x, y, wrap, 0x1p43);
                     const double bb = y - x, err = (x - (y - bb)) + (c - bb);     // the rounding error of x + c, exactly
-                    if (__builtin_fabs(err) == (kind == 0 ? 0x1p-44 : 0x1p-53)) sl->fail();   // a tie on the grid the wrap is taken on
+                    if (__builtin_fabs(err) == (kind == 0 ? 0x1p-44 : 0x1p-53)) sl->tie(err);   // a tie on the grid the wrap is taken on
                 }
                 x = y - wrap;
                 return true;
@@ -245,8 +253,8 @@ struct WalkCore {
                         sl->note(-y);
                     }
                     const double bb = r - y, err = (y - (r - bb)) + (1.0 - bb);
-                    if (r >= 1.0 || __builtin_fabs(err) == 0x1p-54) sl->fail();   // rounded up to 1.0, or a tie on the grid of [0.5, 1)
-                    else sl->note(r);
+                    if (r >= 1.0) sl->fail();                                     // rounded up to 1.0
+                    else { if (__builtin_fabs(err) == 0x1p-54) sl->tie(err); sl->note(r); }  // (a tie on the grid of [0.5, 1))
                 }
                 x = r;
                 return true;
@@ -285,6 +293,7 @@ struct FpWalk {
     double  c, thr;
     int64_t ec;
     bool    neg, general;
+    bool    top_tie;            // descending carrier with an exact tie in [0.5, 1), whose ulp IS the unit: even offsets only
     Piece   F[kTab];
 
     GPSIQ_HD void setup_head(double addend)
@@ -295,9 +304,10 @@ struct FpWalk {
         const int64_t mc = (int64_t) ((bc & kMant) | (kMant + 1));
         neg = c < 0.0;
         general = ec > 1022 - 6 || ec < 1022 - 40 || 1022 - ec >= kTab;
-        if (!general && neg) {                                   // an exact tie in the top binade of a descending carrier: WalkCore::setup_head
+        top_tie = false;
+        if (!general && neg) {                                   // (WalkCore::setup_head hands such an addend to the general walker)
             const int top = (int) (1022 - ec);
-            if ((mc & (((int64_t) 1 << top) - 1)) == (int64_t) 1 << (top - 1)) general = true;
+            top_tie = (mc & (((int64_t) 1 << top) - 1)) == (int64_t) 1 << (top - 1);
         }
         thr = general ? 0.0 : from_bits((uint64_t) (ec + kLow + 1) << 52);
     }
@@ -381,7 +391,7 @@ struct FpWalk {
                 if (kNote) {
                     sl->note(y);
                     const double bb = y - x, err = (x - (y - bb)) + (c - bb);     // the rounding error of x + c, exactly
-                    if (__builtin_fabs(err) == 0x1p-53) sl->fail();               // a tie on the grid the wrap is taken on
+                    if (__builtin_fabs(err) == 0x1p-53) sl->tie(err);             // a tie on the grid the wrap is taken on
                 }
                 x = y - 1.0;
                 return true;
@@ -424,8 +434,8 @@ struct FpWalk {
                     if ((int64_t) (bits_of(x) >> 52) == ec) sl->room_above(-y);
                     else sl->note(-y);
                     const double bb = r - y, err = (y - (r - bb)) + (1.0 - bb);
-                    if (r >= 1.0 || __builtin_fabs(err) == 0x1p-54) sl->fail();
-                    else sl->note(r);
+                    if (r >= 1.0) sl->fail();
+                    else { if (__builtin_fabs(err) == 0x1p-54) sl->tie(err); sl->note(r); }
                 }
                 x = r;
                 return true;
@@ -439,7 +449,7 @@ struct FpWalk {
         }
     }
 
-    struct NoSlack { GPSIQ_HD void note(double) {} GPSIQ_HD void room_above(double) {} GPSIQ_HD void room_below(double) {} GPSIQ_HD void fail() {} };
+    struct NoSlack { GPSIQ_HD void note(double) {} GPSIQ_HD void room_above(double) {} GPSIQ_HD void room_below(double) {} GPSIQ_HD void fail() {} GPSIQ_HD void tie(double) {} };
     GPSIQ_HD inline bool cycle(double &x, long &n, long ns) const
     {
         return neg ? descend<false>(x, n, ns, (NoSlack *) nullptr) : climb<false>(x, n, ns, (NoSlack *) nullptr);

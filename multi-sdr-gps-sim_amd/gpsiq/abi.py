@@ -36,8 +36,8 @@ assert CHAIN_IN_DTYPE.itemsize == 24
 CHAIN_EST_DTYPE = np.dtype([("r_hi", "<u8"), ("r_lo", "<u8"), ("drift", "<f8"), ("carr", "<f8"), ("f_carr", "<f8"),
                             ("prn", "<i4"), ("flags", "<i4"), ("first_prn", "<i4"), ("reserved", "<i4")], align=True)
 assert CHAIN_EST_DTYPE.itemsize == 56
-CHAIN_MAP_DTYPE = np.dtype([("xs", "<f8"), ("e", "<f8"), ("cum", "<i8"), ("lo", "<i8"), ("hi", "<i8"), ("ok", "<i4"), ("even", "<i4")], align=True)
-assert CHAIN_MAP_DTYPE.itemsize == 48
+CHAIN_MAP_DTYPE = np.dtype([("xs", "<f8"), ("e", "<f8"), ("cum", "<i8", (2,)), ("lo", "<i8"), ("hi", "<i8"), ("ok", "<i4"), ("info", "<i4")], align=True)
+assert CHAIN_MAP_DTYPE.itemsize == 56
 CHAIN_EXACT, CHAIN_RESEEDED, CHAIN_EMPTY = 1, 2, 4
 # gpsiq_shard_carry_t
 SHARD_CARRY_DTYPE = np.dtype([("end_phase", "<u8"), ("advance", "<u8"), ("first_prn", "<i4"), ("last_prn", "<i4"),

@@ -104,8 +104,7 @@ def test_soak_program_random_and_adversarial_timelines(tmp_path):
     csrc = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")
     exe = str(tmp_path / "chain_parallel")
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", exe,
-                    os.path.join(ROOT, "tests", "chain_parallel.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), os.path.join(csrc, "gpsiq_exact.cpp"),
-                    "-lpthread", "-lm"], check=True)
+                    os.path.join(ROOT, "tests", "chain_parallel.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), "-lpthread", "-lm"], check=True)
     for seed in (1, 2):
         r = subprocess.run([exe, str(seed), "45"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and " bad=0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
