@@ -152,6 +152,10 @@ static void link_slot(LinkJob &j, int i)
     long walked = 0, linked = 0;
     for (int b = 0; b < j.nblocks; ++b) {
         const size_t at = (size_t) b * j.nchan + i;
+        if (b + 8 < j.nblocks) {                     // a slot's rows lie nchan rows apart: every block a cache miss unless asked for early
+            __builtin_prefetch(&j.in[at + (size_t) 8 * j.nchan]);
+            __builtin_prefetch(&j.rec[at + (size_t) 8 * j.nchan]);
+        }
         const gpsiq_chain_in_t &d = j.in[at];
         if (d.prn <= 0) { pv = 0; x = 0.0; j.carr_start[at] = 0.0; continue; }
         if ((b == 0 && !have_in) || pv != d.prn) x = d.carr_phase;
@@ -177,6 +181,7 @@ static void link_slot(LinkJob &j, int i)
 static std::atomic<uint64_t> g_chain_stats[2];          // blocks linked through their map / walked from their true start
 
 bool chain_step_mapped(const void *maps, size_t at, double x, double *next) { return lane::link_block(static_cast<const Rec *>(maps)[at], x, next); }
+void chain_prefetch_map(const void *maps, size_t at) { __builtin_prefetch(&static_cast<const Rec *>(maps)[at]); }
 void chain_count(long linked, long walked)
 {
     g_chain_stats[0].fetch_add((uint64_t) linked, std::memory_order_relaxed);

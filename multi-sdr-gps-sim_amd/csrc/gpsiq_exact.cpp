@@ -1062,7 +1062,10 @@ void RefWalk::chain_task(int i, size_t k)
     for (int b = b0; b < b1; ++b) {
         const size_t at = (size_t) b * nchan + i;
         // a channel's descriptors lie nchan * 296 bytes apart: every block is a cache miss unless it is asked for early
-        if (b + 6 < b1) { if (in) __builtin_prefetch(&in[at + (size_t) 6 * nchan]); else __builtin_prefetch(&ch[at + (size_t) 6 * nchan]); }
+        if (b + 6 < b1) {
+            if (in) __builtin_prefetch(&in[at + (size_t) 6 * nchan]); else __builtin_prefetch(&ch[at + (size_t) 6 * nchan]);
+            if (maps) chain_prefetch_map(maps, at + (size_t) 6 * nchan);
+        }
         const double f_carr = in ? in[at].f_carr : ch[at].f_carr, phase0 = in ? in[at].carr_phase : ch[at].carr_phase;
         const int prn = in ? in[at].prn : ch[at].prn;
         if (prn <= 0) { pv = 0; c = 0.0; start_out[at] = 0.0; continue; }

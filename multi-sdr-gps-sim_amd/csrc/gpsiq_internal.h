@@ -98,6 +98,7 @@ private:
 // level 2 of the time-parallel chain for one block (gpsiq_chain.cpp): the accumulator after block `at` of maps from its true start
 // x; false: the block's map does not apply (walk it).  chain_count: the process-wide statistics (gpsiq_chain_stats).
 bool chain_step_mapped(const void *maps, size_t at, double x, double *next);
+void chain_prefetch_map(const void *maps, size_t at);
 void chain_count(long linked, long walked);
 
 // Host threads this process may use: online CPUs, capped by GPSIQ_THREADS (read once).
