@@ -337,6 +337,7 @@ GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *
 {
     Rec r;
     const int64_t grid = neg ? 1 : 2;                 // units of U per step of the wrap's grid
+    const int gsh = neg ? 0 : 1;                      // (shifts and masks below: a 64-bit division costs the device a hundred instructions)
     r.xs = st[0].r_in; r.e = st[nseg - 1].x_end; r.cum[0] = 0; r.cum[1] = 0; r.lo = st[0].lo; r.hi = st[0].hi; r.ok = st[0].ok ? 3 : 0;
     int why = st[0].why;
     // Branch p: the block's true start lies d = (2k + p) grid steps above xs.  cum[p]: how far the stretch at hand starts above
@@ -347,7 +348,7 @@ GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *
             int64_t d;
             if (!st[t].ok) { r.ok = 0; why = st[t].why; break; }
             if (st[t - 1].n_out != st[t].n_in) { r.ok = 0; why = kWhyJoin; break; }
-            if (!exact_units(st[t - 1].x_out, st[t].r_in, &d) || d % grid) { r.ok = 0; why = kWhyUnits; break; }
+            if (!exact_units(st[t - 1].x_out, st[t].r_in, &d) || (d & (grid - 1))) { r.ok = 0; why = kWhyUnits; break; }
             r.cum[0] += d; r.cum[1] += d;
             // the stretch's range holds for its own offset, before and after a step aside: a grid step short either side
             const int64_t cmin = r.cum[0] < r.cum[1] ? r.cum[0] : r.cum[1], cmax = r.cum[0] < r.cum[1] ? r.cum[1] : r.cum[0];
@@ -356,9 +357,9 @@ GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *
             if (h < r.hi) r.hi = h;
         }
         for (int p = 0; p < 2; ++p) {
-            const bool odd = ((p + r.cum[p] / grid) & 1) != 0;              // parity of this stretch's offset, in grid steps
+            const bool odd = ((p + (r.cum[p] >> gsh)) & 1) != 0;            // parity of this stretch's offset, in grid steps
             if (odd && st[t].ok == 2) r.ok &= ~(1 << p);
-            if (odd && st[t].sigma) r.cum[p] += (int64_t) st[t].sigma * grid;
+            if (odd && st[t].sigma) r.cum[p] += st[t].sigma > 0 ? grid : -grid;
         }
         if (!r.ok) why = kWhyParity;
     }
@@ -374,9 +375,9 @@ GPSIQ_HD inline bool link_block(const Rec &r, double x, double *next)
 {
     int64_t d;
     if (!r.ok || !exact_units(x, r.xs, &d)) return false;
-    const int64_t grid = r.info & 0xff;
-    if (d < r.lo || d > r.hi || grid < 1 || d % grid) return false;
-    const int p = (int) ((d / grid) & 1);
+    const int64_t grid = r.info & 0xff;                          // 1 or 2
+    if (d < r.lo || d > r.hi || grid < 1 || grid > 2 || (d & (grid - 1))) return false;
+    const int p = (int) ((d >> (grid - 1)) & 1);
     if (!(r.ok & (1 << p))) return false;
     double y;
     if (!exact_shift(r.e, d + r.cum[p], &y) || !(y >= 0.0 && y < 1.0)) return false;
