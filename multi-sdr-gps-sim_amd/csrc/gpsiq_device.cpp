@@ -1341,7 +1341,19 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
             piece_ends(r0, r1 - r0, ref_chunk_blocks(r1 - r0, nsamp), &ends, ref_kernel_bound(nsamp, nchan));
             owner.insert(owner.end(), ends.size() - before, i);
         }
+        // the carrier chain: level 1 of the whole timeline on the first device (one launch; a GPU walks an hour of config 5 in
+        // milliseconds where sixteen host threads took a tenth of a second), the link inside the walkers' chain tasks
+        const bool dev_chain = chain_on_device(nblocks, nsamp, nchan);
+        int crc = GPSIQ_OK;
+        if (dev_chain) {
+            crc = hipSetDevice(c0->device) == hipSuccess ? chain_reserve(c0, (size_t) nblocks * (size_t) nchan) : fail(GPSIQ_E_DEVICE, "hipSetDevice");
+            if (crc == GPSIQ_OK) {
+                chain_stage_inputs(c0, ch, 0, nblocks, nchan);
+                crc = chain_maps_staged(c0, nblocks, nchan, fs, nsamp, nullptr, 0, nullptr);
+            }
+        }
         RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
+        if (dev_chain && crc == GPSIQ_OK) { w.in = c0->chain.h_in; w.maps = c0->chain.h_maps; }     // (a failed level 1: the serial walk)
         pthread_t wth;
         const bool threaded = pthread_create(&wth, nullptr, run_walk, &w) == 0;
         if (!threaded) w.run();

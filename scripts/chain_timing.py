@@ -36,7 +36,7 @@ def main():
         want = gpsiq.reference_chain(cin, fs, ns)
         t_serial = best(lambda: gpsiq.reference_chain(cin, fs, ns), 3)
         print(f"{label}: {nb} blocks x 16 ch; serial chain on host threads {t_serial * 1e3:.3f} ms", flush=True)
-        for seg in (4, 8, 16):
+        for seg in (8, 16, 32):
             ms = min(gpsiq.chain_maps(cin, fs, ns, max_stretches=seg, ctx=ctx)[2] for _ in range(5))
             t_call = best(lambda: gpsiq.chain_maps(cin, fs, ns, max_stretches=seg, ctx=ctx), 5)
             maps = gpsiq.chain_maps(cin, fs, ns, max_stretches=seg, ctx=ctx)[0]
