@@ -240,16 +240,22 @@ extern "C" int gpsiq_chain_summary(const gpsiq_chain_in_t *in, int nblocks, int 
     int rc = check_chain_args(in, nblocks, nchan, fs, nsamp);
     if (rc) return rc;
     if (!sum) return fail(GPSIQ_E_ARG, "null pointer");
-    for (int i = 0; i < nchan; ++i) {
-        EstState st;
-        u128 r0 = 0;
-        if (start) { st.load(start[i]); r0 = st.R; st.D = 0.0; }
-        else st.prn = -1;                                        // the phase pass: what came before is not known yet
-        const bool rs = chain_scan_slot(in, nblocks, nchan, i, 1.0 / fs, nsamp, &st, start != nullptr, nullptr, nullptr);
-        if (!rs && start) st.R -= r0;                            // what the range adds; absolute from its last re-seed otherwise
-        if (st.prn < 0) st.prn = 0;
-        st.store(&sum[i], (rs ? GPSIQ_CHAIN_RESEEDED : 0) | (nblocks == 0 ? GPSIQ_CHAIN_EMPTY : 0));
-    }
+    struct Job { const gpsiq_chain_in_t *in; int nblocks, nchan, nsamp; double delt; const gpsiq_chain_est_t *start; gpsiq_chain_est_t *sum; };
+    Job job = {in, nblocks, nchan, nsamp, 1.0 / fs, start, sum};
+    // a slot per thread (the drift pass is ~0.1 us per block and slot)
+    parallel_for(nchan, nblocks >= 256 ? 0 : 1, 1, [](void *ctx, int i0, int i1) {
+        const Job &j = *static_cast<Job *>(ctx);
+        for (int i = i0; i < i1; ++i) {
+            EstState st;
+            u128 r0 = 0;
+            if (j.start) { st.load(j.start[i]); r0 = st.R; st.D = 0.0; }
+            else st.prn = -1;                                    // the phase pass: what came before is not known yet
+            const bool rs = chain_scan_slot(j.in, j.nblocks, j.nchan, i, j.delt, j.nsamp, &st, j.start != nullptr, nullptr, nullptr);
+            if (!rs && j.start) st.R -= r0;                      // what the range adds; absolute from its last re-seed otherwise
+            if (st.prn < 0) st.prn = 0;
+            st.store(&j.sum[i], (rs ? GPSIQ_CHAIN_RESEEDED : 0) | (j.nblocks == 0 ? GPSIQ_CHAIN_EMPTY : 0));
+        }
+    }, &job);
     return GPSIQ_OK;
 }
 
