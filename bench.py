@@ -22,9 +22,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     — algorithmic IQ bytes per launch / mean launch duration (HIP events on the launch
                  stream) against the 8 TB/s HBM peak,
   counters     — instruction-mix-independent fractions of the dominant kernel from committed rocprofv3 PMC passes of this
-                 command (profiles/pmc_counters.json): VALU issue fraction, LDS busy, LDS bank-conflict ratio,
-  reference_nco — the model whose output is the reference's own (GPSIQ_NCO_REFERENCE): whole batch call at the
-                 headline workload and at 25 Msps, host side alone, kernel alone, which of the two bounds it (N = 1),
+                 command (profiles/pmc_counters.json): VALU issue fraction, LDS busy, LDS bank-conflict ratio
+                 (+ own_stream_efficiency: the kernel against the cost of its own instruction stream; not a roofline),
+  exact_mode_value / _roofline / _bound — the model whose output IS the reference's (GPSIQ_NCO_REFERENCE), whole
+                 gpsiq_generate_batch call at the headline workload, beside `value`,
+  reference_nco — that mode in detail: the call at the headline workload and at 25 Msps, the same with the carrier chain on host
+                 threads, the chain's parts (level 1 kernels on the device, level 2 link on the host, blocks linked / walked,
+                 equality with the serial chain), evaluation alone, kernel alone, which side bounds it; at N > 1 the mode
+                 time-sharded over the ranks (chain by time),
+  placement    — (N > 1) where every rank runs: host, device ordinal, PCI bus id, CPUs granted, GPSIQ_THREADS,
   cpu_baseline — the reference's own loop (oracle/_ref, kind "reference") or our port of it
                  (oracle/, kind "port") timed on this host, 1 core, bounded sample (N = 1 only),
   end_to_end   — the same per-GPU block count from scratch on every rank: host refresh of its own
