@@ -29,7 +29,7 @@
 #include "gui.h"     /* status_color_t, gui_status_wprintw() (called by validate_parityN) */
 #include "almanac.h" /* almanac_gps_t (eph2sbf argument) */
 
-#include "../include/gpsiq.h"   /* gpsiq_chan_t: the descriptor layout the tests pass in */
+#include "../include/gpsiq_extras.h"   /* gpsiq_chan_t and the structs of the rows either side (gpsiq_rows.h): the layouts the tests pass in */
 
 static int ref_fs = 3000000;
 static int ref_nchan = 12;
