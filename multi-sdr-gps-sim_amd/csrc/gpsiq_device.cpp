@@ -105,8 +105,9 @@ struct gpsiq_ctx {
         gpsiq_chain_map_t *d_maps = nullptr, *h_maps = nullptr;
         gpsiq_chain_est_t *d_est = nullptr, *h_est = nullptr;       // [3][GPSIQ_MAX_CHAN]: start, end of the first launch (= start of a second), end
         double            *d_c_before = nullptr;
-        hipStream_t        stream = nullptr;
+        hipStream_t        stream = nullptr, back = nullptr;   // uploads + kernels; the maps' way back + the callbacks (never in the kernels' way)
         hipEvent_t         t0 = nullptr, t1 = nullptr, landed = nullptr;   // landed: the maps of the last range queued are in h_maps
+        hipEvent_t         walked[2] = {nullptr, nullptr};     // a launch's kernels are done
         float              last_ms = 0.0f;             // device time of the last call's two kernels
     } chain;
 };
@@ -272,6 +273,8 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->chain.t0) (void) hipEventDestroy(c->chain.t0);
     if (c->chain.t1) (void) hipEventDestroy(c->chain.t1);
     if (c->chain.landed) (void) hipEventDestroy(c->chain.landed);
+    for (auto &e : c->chain.walked) if (e) (void) hipEventDestroy(e);
+    if (c->chain.back) (void) hipStreamDestroy(c->chain.back);
     if (c->chain.stream) (void) hipStreamDestroy(c->chain.stream);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->up_stream) (void) hipStreamDestroy(c->up_stream);
@@ -787,7 +790,11 @@ static int chain_reserve(gpsiq_ctx *c, size_t n)
 {
     gpsiq_ctx::Chain &k = c->chain;
     if (!k.stream) {
+        // (equal priorities: with the synthesis stream above the chain's, the second launch's maps came back late -- 0.98 ms
+        // instead of 0.78 -- and the pieces behind the head waited for them: 2.6 ms per call instead of 2.4, profiles/r05_chain_ab.txt)
         HIP_TRY(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&k.back, hipStreamNonBlocking));
+        for (auto &e : k.walked) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&k.t0));
         HIP_TRY(hipEventCreate(&k.t1));
         HIP_TRY(hipEventCreateWithFlags(&k.landed, hipEventDisableTiming));
@@ -835,10 +842,21 @@ static int chain_queue(gpsiq_ctx *c, int part, int b0, int nb, int nchan, double
     HIP_TRY(launch_chain(k.d_in + off, nb, nchan, 1.0 / fs, nsamp, d_start, max_stretches, static_cast<char *>(k.d_prep) + off * 32,
                          k.d_c_before + part * GPSIQ_MAX_CHAN, k.d_est + (part + 1) * GPSIQ_MAX_CHAN, k.d_maps + off, k.stream));
     HIP_TRY(hipEventRecord(k.t1, k.stream));
-    HIP_TRY(hipMemcpyAsync(k.h_maps + off, k.d_maps + off, n * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, k.stream));
+    // the maps' way back on a stream of its own: the next launch's kernels follow these at once (a callback queued between
+    // them held the second launch up by ~0.1 ms)
+    HIP_TRY(hipEventRecord(k.walked[part], k.stream));
+    HIP_TRY(hipStreamWaitEvent(k.back, k.walked[part], 0));
+    HIP_TRY(hipMemcpyAsync(k.h_maps + off, k.d_maps + off, n * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, k.back));
     HIP_TRY(hipMemcpyAsync(k.h_est + (part + 1) * GPSIQ_MAX_CHAN, k.d_est + (part + 1) * GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t),
-                           hipMemcpyDeviceToHost, k.stream));
-    HIP_TRY(hipEventRecord(k.landed, k.stream));
+                           hipMemcpyDeviceToHost, k.back));
+    HIP_TRY(hipEventRecord(k.landed, k.back));
+    return GPSIQ_OK;
+}
+
+static int chain_drain(gpsiq_ctx *c)
+{
+    const hipError_t a = hipStreamSynchronize(c->chain.stream), b = hipStreamSynchronize(c->chain.back);
+    if (a != hipSuccess || b != hipSuccess) return fail(GPSIQ_E_DEVICE, "carrier chain, level 1: %s", hipGetErrorString(a != hipSuccess ? a : b));
     return GPSIQ_OK;
 }
 
@@ -848,8 +866,9 @@ static int chain_maps_staged(gpsiq_ctx *c, int nblocks, int nchan, double fs, in
 {
     gpsiq_ctx::Chain &k = c->chain;
     int rc = chain_queue(c, 0, 0, nblocks, nchan, fs, nsamp, start, max_stretches);
-    if (rc) { (void) hipStreamSynchronize(k.stream); return rc; }
-    HIP_TRY(hipStreamSynchronize(k.stream));
+    if (rc) { (void) chain_drain(c); return rc; }
+    rc = chain_drain(c);
+    if (rc) return rc;
     (void) hipEventElapsedTime(&k.last_ms, k.t0, k.t1);
     if (end) std::memcpy(end, k.h_est + GPSIQ_MAX_CHAN, (size_t) nchan * sizeof(gpsiq_chain_est_t));
     return GPSIQ_OK;
@@ -933,13 +952,15 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     if (rc) return rc;
     const int chunk = ref_chunk_blocks(nblocks, nsamp);
     std::vector<int> ends;
+    const bool dev_chain = !seeds && chain_on_device(nblocks, nsamp, nchan);
+    // (few growing pieces also with the chain on the device were tried: a 600-block piece is 0.3 ms of evaluation before it can
+    // render, and the device waits for it: 2.6 ms per call against 2.4 at 2.6 Msps, profiles/r05_chain_ab.txt)
     piece_ends(0, nblocks, chunk, &ends, ref_kernel_bound(nsamp, nchan));
     // The carrier chain: level 1 (every block's certified map) on the device, parallel in time (gpsiq_chain_kernels.hip); the chain
     // tasks then link block to block through the maps.  Nothing renders before the first maps are back, and a launch is ~0.25 ms
     // however small: the timeline goes in two launches -- a head whose kernels cover the second launch, then the rest --, and the
     // walkers are let into the rest when its maps have landed (RefWalk::release_maps).
     double t_chain[3] = {};
-    const bool dev_chain = !seeds && chain_on_device(nblocks, nsamp, nchan);
     int head = nblocks;
     if (dev_chain) {
         rc = chain_reserve(c, (size_t) nblocks * (size_t) nchan);
@@ -948,10 +969,9 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         const double t_block = (double) nsamp * (double) nchan / rate_kernel();
         int want = (int) (0.4e-3 / t_block) + 1;
         if (const char *e = std::getenv("GPSIQ_CHAIN_HEAD")) want = std::atoi(e);            // blocks; <= 0: one launch (A/B)
-        if (want > 0 && 2 * want < nblocks)
-            for (size_t k = 0; k < ends.size(); ++k)
-                if (ends[k] >= want) { head = ends[k]; break; }
-        if (2 * head > nblocks) head = nblocks;
+        if (want > 0 && 2 * want < nblocks)                    // the piece end nearest to that, in the first half of the timeline
+            for (size_t k = 0; k < ends.size() && 2 * ends[k] <= nblocks; ++k)
+                if (head == nblocks || std::abs(ends[k] - want) < std::abs(head - want)) head = ends[k];
     }
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
@@ -968,13 +988,13 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         w.in = c->chain.h_in; w.maps = c->chain.h_maps; w.maps_upto.store(0);
         chain_stage_inputs(c, ch, 0, head, nchan);
         rc = chain_queue(c, 0, 0, head, nchan, fs, nsamp, nullptr, 0);
-        if (rc == GPSIQ_OK && hipLaunchHostFunc(c->chain.stream, on_landed, &landed[0]) != hipSuccess) rc = fail(GPSIQ_E_DEVICE, "hipLaunchHostFunc");
+        if (rc == GPSIQ_OK && hipLaunchHostFunc(c->chain.back, on_landed, &landed[0]) != hipSuccess) rc = fail(GPSIQ_E_DEVICE, "hipLaunchHostFunc");
         if (rc == GPSIQ_OK && head < nblocks) {
             chain_stage_inputs(c, ch, head, nblocks, nchan);                               // under the head's kernels
             rc = chain_queue(c, 1, head, nblocks - head, nchan, fs, nsamp, nullptr, 0);
-            if (rc == GPSIQ_OK && hipLaunchHostFunc(c->chain.stream, on_landed, &landed[1]) != hipSuccess) rc = fail(GPSIQ_E_DEVICE, "hipLaunchHostFunc");
+            if (rc == GPSIQ_OK && hipLaunchHostFunc(c->chain.back, on_landed, &landed[1]) != hipSuccess) rc = fail(GPSIQ_E_DEVICE, "hipLaunchHostFunc");
         }
-        if (rc) { (void) hipStreamSynchronize(c->chain.stream); return rc; }
+        if (rc) { (void) chain_drain(c); return rc; }
         if (trace) t_chain[0] = wall_ms() - t0;
     }
     // one piece (a block call, a short batch): walk here, then render; else the walk runs on the pool, driven by a helper
@@ -1001,7 +1021,7 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) { std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); w.abort(); }     // nothing further is walked for a call that has failed
-    if (dev_chain) (void) hipStreamSynchronize(c->chain.stream);      // the callbacks have run: every chain task is runnable, also of an aborted walk
+    if (dev_chain) (void) chain_drain(c);                             // the callbacks have run: every chain task is runnable, also of an aborted walk
     if (threaded) pthread_join(th, nullptr);                 // the walkers read ch and write q: never leave them running
     const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();

@@ -1,5 +1,5 @@
 """A/B of the knobs of the device carrier chain inside gpsiq_generate_batch (GPSIQ_NCO_REFERENCE): GPSIQ_CHAIN_HEAD,
-GPSIQ_CHAIN_STRETCHES, GPSIQ_REF_CHUNK_BLOCKS, and one GPSIQ_TRACE=2 timeline of the default.  Run on the GPU box."""
+GPSIQ_CHAIN_STRETCHES, GPSIQ_REF_CHUNK_BLOCKS, GPSIQ_CHAIN, and one GPSIQ_TRACE=2 timeline of the default.  Run on the GPU box."""
 import os
 import sys
 import time
@@ -24,9 +24,9 @@ def best(fn, n=8):
 
 
 def main():
-    ctx = gpsiq.Context(0)
     ring = torch.empty(2 << 30, dtype=torch.uint8, device="cuda:0")
     pat = synth_blocks(64, 16)
+    ctx = gpsiq.Context(0)
     ctx.set_nco_mode(NCO_REFERENCE)
     for label, fs, ss, nb in (("2M6_int8", 2.6e6, 1, 2000), ("10M_int16", 10e6, 2, 536), ("25M_int16", 25e6, 2, 200)):
         ns = int(round(fs / 10))
@@ -37,13 +37,14 @@ def main():
         call()
         del os.environ["GPSIQ_TRACE"]
         print(f"{label}: default {best(call) * 1e3:.3f} ms", flush=True)
-        for knob, values in (("GPSIQ_CHAIN_HEAD", ("0", "64", "128", "256", "384", "600")), ("GPSIQ_CHAIN_STRETCHES", ("8", "16", "32")),
-                             ("GPSIQ_REF_CHUNK_BLOCKS", ("64", "128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device"))):
+        for knob, values in (("GPSIQ_CHAIN_HEAD", ("0", "128", "256", "400", "600", "900")), ("GPSIQ_CHAIN_STRETCHES", ("16", "32")),
+                             ("GPSIQ_REF_CHUNK_BLOCKS", ("128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device"))):
             for v in values:
                 os.environ[knob] = v
                 call()
                 print(f"  {knob}={v}: {best(call) * 1e3:.3f} ms", flush=True)
             del os.environ[knob]
+        print(f"{label}: default again {best(call) * 1e3:.3f} ms", flush=True)
     ctx.close()
 
 
