@@ -969,9 +969,10 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         const double t_block = (double) nsamp * (double) nchan / rate_kernel();
         int want = (int) (0.4e-3 / t_block) + 1;
         if (const char *e = std::getenv("GPSIQ_CHAIN_HEAD")) want = std::atoi(e);            // blocks; <= 0: one launch (A/B)
-        if (want > 0 && 2 * want < nblocks)                    // the piece end nearest to that, in the first half of the timeline
-            for (size_t k = 0; k < ends.size() && 2 * ends[k] <= nblocks; ++k)
-                if (head == nblocks || std::abs(ends[k] - want) < std::abs(head - want)) head = ends[k];
+        if (want > 0 && 2 * want < nblocks)                    // the first piece end at or beyond that (a bigger head measured better than a
+            for (size_t k = 0; k < ends.size(); ++k)           // smaller one: 2.35 ms per call at 900 blocks, 2.49 at 256, 2.55 at 128)
+                if (ends[k] >= want) { head = ends[k]; break; }
+        if (2 * head > nblocks) head = nblocks;                // what is left would not be worth a launch of its own
     }
     RefWalk w(ch, nblocks, nchan, 1.0 / fs, nsamp, q.data(), nullptr, nullptr, ends);
     w.seeds = seeds;                                         // start states known (gpsiq_generate_seeded): evaluation tasks only
