@@ -167,3 +167,103 @@ def test_device_chain_is_mostly_maps_at_the_headline_workload(ctx):
     linked, walked = (a - b for a, b in zip(gpsiq.chain_stats(), before))
     assert walked < 0.02 * cin.size, (linked, walked)
     print(f"device chain, 2000 x 16 blocks: kernels {ms:.3f} ms, linked {linked}, walked {walked}")
+
+
+BAD = [("f_carr", np.nan), ("f_carr", np.inf), ("f_carr", 1.4e6), ("f_carr", -1.31e6), ("f_carr", 5e-324), ("f_carr", 0.0),
+       ("carr_phase", 1.5), ("carr_phase", np.nan), ("carr_phase", 1.0), ("carr_phase", -0.25)]
+
+
+def spoiled(field, value, nblocks=120, at=70):
+    """A timeline with ONE input the NCO format may not take (or just takes) in a late block."""
+    cin = timeline(5, nblocks, 6, modes=False)
+    cin[field][at, 2] = value
+    if field == "carr_phase":
+        cin["prn"][at:, 2] = 1 + cin["prn"][0, 2] % 32                    # another satellite: the descriptor's phase is taken
+    return cin
+
+
+def chain_or_error(fn):
+    try:
+        return fn(), None
+    except gpsiq.GpsiqError as e:
+        return None, str(e)
+
+
+def assert_same_outcome(cin, maps, fs, nsamp):
+    want, werr = chain_or_error(lambda: gpsiq.reference_chain(cin, fs, nsamp))
+    got, gerr = chain_or_error(lambda: gpsiq.chain_link(cin, maps, fs, nsamp))
+    assert werr == gerr
+    if want is not None:
+        assert_same_chain(got, want)
+    return werr
+
+
+@pytest.mark.parametrize("field,value", BAD)
+def test_inputs_outside_the_nco_format(field, value):
+    """NaN / infinite / too fast Doppler, a phase outside [0, 1], and the edge cases that ARE in the format (zero and denormal
+    Doppler, phase 1.0): level 1 terminates whatever it is given, and level 2 reports exactly what the serial chain reports."""
+    fs, nsamp = 2.6e6, 260000
+    cin = spoiled(field, value)
+    errs = set()
+    for stretches in (1, 8, 32):
+        maps, _ = gpsiq.chain_maps(cin, fs, nsamp, max_stretches=stretches)
+        errs.add(assert_same_outcome(cin, maps, fs, nsamp))
+    assert len(errs) == 1
+    err = errs.pop()
+    in_format = (field == "f_carr" and abs(value) < 1e6) or (field == "carr_phase" and value == 1.0)
+    assert (err is None) == in_format, err
+    if err:
+        assert "block 70" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,value", BAD)
+def test_device_inputs_outside_the_nco_format(ctx, field, value):
+    fs, nsamp = 2.6e6, 260000
+    cin = spoiled(field, value)
+    for stretches in (4, 32):
+        maps, _, _ = gpsiq.chain_maps(cin, fs, nsamp, max_stretches=stretches, ctx=ctx)
+        assert_same_outcome(cin, maps, fs, nsamp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,value,at", [("f_carr", np.nan, 70), ("f_carr", 1.4e6, 5), ("carr_phase", 1.5, 119), ("f_code", 0.0, 100)])
+def test_a_batch_with_the_chain_on_the_device_and_a_descriptor_outside_the_format(ctx, oracle, monkeypatch, field, value, at):
+    """gpsiq_generate_batch in GPSIQ_NCO_REFERENCE with level 1 on the device (two launches, maps landing through callbacks) and
+    a descriptor the walk or the evaluation refuses: the call reports the block, drains both chain streams and the rendering
+    stream before it returns, and the context goes on working -- with the device chain -- bit-exactly."""
+    import torch
+    from gpsiq.abi import NCO_REFERENCE, SC08
+    from gpsiq.scenario import synth_blocks
+    monkeypatch.setenv("GPSIQ_CHAIN", "device")
+    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "8")
+    fs, ns, nb, nc = 2.6e6, 26000, 120, 6
+    d = synth_blocks(nb, nc, seed=17)
+    bad = d.copy()
+    bad[field][at, 2] = value
+    if field == "carr_phase":
+        bad["prn"][at:, 2] = 1 + bad["prn"][0, 2] % 32
+    buf = torch.zeros(nb * 2 * ns, dtype=torch.uint8, device="cuda")
+    ctx.set_nco_mode(NCO_REFERENCE)
+    try:
+        for _ in range(2):
+            with pytest.raises(gpsiq.GpsiqError) as ei:
+                ctx.generate_batch(bad, ns, fs, SC08, device_ptr=buf.data_ptr())
+            assert "block" in str(ei.value)
+        before = gpsiq.chain_stats()
+        ctx.generate_batch(d, ns, fs, SC08, device_ptr=buf.data_ptr())
+        torch.cuda.synchronize()
+        linked, walked = (a - b for a, b in zip(gpsiq.chain_stats(), before))
+        assert linked > 0.5 * nb * nc, (linked, walked)                     # the chain did run through the device's maps
+        got = buf.cpu().numpy().view(np.int8).reshape(nb, 2 * ns)
+        carr, prev = None, None
+        for b in range(nb):
+            db = d[b].copy()
+            if b:
+                db["carr_phase"] = np.where((prev == db["prn"]) & (db["prn"] > 0), carr, db["carr_phase"])
+            o, carr = oracle.block_float(db, ns, fs, SC08)
+            prev = db["prn"].copy()
+            if b in (0, 1, 7, 8, 60, 119):
+                assert np.array_equal(got[b], o), b
+    finally:
+        ctx.set_nco_mode(0)
