@@ -34,6 +34,7 @@ using namespace gpsiq;
 struct gpsiq_ctx {
     int           device = -1;
     hipStream_t   stream = nullptr;
+    hipStream_t   stream2 = nullptr;                     // every other piece of a batch in pieces (piece_stream below)
     DeviceTables *d_tab = nullptr;
     hipStream_t   copy_stream[2] = {nullptr, nullptr};   // device-to-host copies of the batch calls
     // resident descriptors, double-buffered: a new set is staged and uploaded into the buffer the
@@ -219,6 +220,7 @@ int gpsiq_create(gpsiq_ctx_t **out, int device)
     if (!h) { delete c; return fail(GPSIQ_E_NOMEM, "out of memory"); }
     build_device_tables(h);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
@@ -277,6 +279,7 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
     if (c->chain.back) (void) hipStreamDestroy(c->chain.back);
     if (c->chain.stream) (void) hipStreamDestroy(c->chain.stream);
     if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->stream2) (void) hipStreamDestroy(c->stream2);
     if (c->up_stream) (void) hipStreamDestroy(c->up_stream);
     delete c;
 }
@@ -622,6 +625,19 @@ static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nbloc
     return GPSIQ_OK;
 }
 
+// The stream of piece k of a batch worked through in pieces.  On ONE stream a piece's kernel starts when the last workgroup of
+// the piece before it has retired: every piece pays its own ramp-down (six pieces of a 2 000-block call: 1.75 ms of kernels
+// against 1.50 ms in one launch, profiles/r05_chain_ab.txt).  Pieces write disjoint blocks and read their own descriptor set
+// (two sets, reused by every other piece: piece k+2 follows piece k on the same stream), so consecutive pieces alternate
+// between two streams and the next piece's first workgroups fill the compute units the last ones of this piece leave.
+// GPSIQ_PIECE_STREAMS=1: one stream (A/B; read per call).
+static hipStream_t piece_stream(gpsiq_ctx *c, int k)
+{
+    if (!(k & 1)) return c->stream;
+    const char *e = std::getenv("GPSIQ_PIECE_STREAMS");
+    return e && std::atoi(e) == 1 ? c->stream : c->stream2;
+}
+
 // Blocks per piece of a long device-destination batch in the fixed-point model: ~1 ms of kernel, a few hundred microseconds of
 // host work per piece.  GPSIQ_BATCH_PIECE_BLOCKS overrides (read per call); <= 0: one piece.
 static int batch_piece_blocks(int nblocks, int nsamp)
@@ -666,11 +682,11 @@ struct RefRender {
     uint8_t *dst = nullptr;          // destination of the range's first block
     bool dst_is_device = false, direct = false;
     size_t blk_bytes = 0, stride = 0;
-    int k = 0;
+    int k = 0, npiece = 0;
 
     int begin(gpsiq_ctx *ctx, int range_blocks, int nchan_, int nsamp_, int ss_, void *dst_, int dst_is_device_)
     {
-        c = ctx; nchan = nchan_; nsamp = nsamp_; ss = ss_; dst = static_cast<uint8_t *>(dst_); dst_is_device = dst_is_device_ != 0; k = 0;
+        c = ctx; nchan = nchan_; nsamp = nsamp_; ss = ss_; dst = static_cast<uint8_t *>(dst_); dst_is_device = dst_is_device_ != 0; k = 0; npiece = 0;
         blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) ss;
         stride = (blk_bytes + 15) & ~(size_t) 15;
         direct = dst_is_device && stride == blk_bytes && !((uintptr_t) dst & 3);
@@ -686,10 +702,11 @@ struct RefRender {
         if (rc) return rc;
         if (!nb || !nsamp) return GPSIQ_OK;
         uint8_t *dev = direct ? dst + (size_t) b0 * blk_bytes : static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
-        rc = gpsiq_launch(c, 0, nb, nsamp, ss, dev, stride, c->stream, kAuto);
+        hipStream_t s = piece_stream(c, npiece++);
+        rc = gpsiq_launch(c, 0, nb, nsamp, ss, dev, stride, s, kAuto);
         if (rc || direct) return rc;
         hipStream_t cs = c->copy_stream[k & 1];
-        HIP_TRY(hipEventRecord(c->chunk_done[k & 1], c->stream));
+        HIP_TRY(hipEventRecord(c->chunk_done[k & 1], s));
         HIP_TRY(hipStreamWaitEvent(cs, c->chunk_done[k & 1], 0));
         const hipMemcpyKind kind = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         if (stride == blk_bytes)
@@ -707,7 +724,9 @@ struct RefRender {
         (void) hipSetDevice(c->device);
         const hipError_t s0 = hipStreamSynchronize(c->copy_stream[0]);
         const hipError_t s1 = hipStreamSynchronize(c->copy_stream[1]);
-        const hipError_t s2 = hipStreamSynchronize(c->stream);
+        hipError_t s2 = hipStreamSynchronize(c->stream);
+        const hipError_t s3 = hipStreamSynchronize(c->stream2);
+        if (s2 == hipSuccess) s2 = s3;
         if (s0 != hipSuccess || s1 != hipSuccess || s2 != hipSuccess)
             return fail(GPSIQ_E_DEVICE, "reference NCO pieces: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1 != hipSuccess ? s1 : s2));
         // every launch waited for its set's upload on the device and has finished: later launches on the resident set need not
@@ -1236,7 +1255,7 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
             const double tq1 = trace_pieces ? wall_ms() : 0.0;
             if (rc == GPSIQ_OK) rc = set_descriptors_impl(c, q.data(), nb, nchan, nullptr, 0, true);
             const double tq2 = trace_pieces ? wall_ms() : 0.0;
-            if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, c->stream, kAuto);
+            if (rc == GPSIQ_OK) rc = gpsiq_launch(c, 0, nb, nsamp, sample_size, static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, piece_stream(c, (int) k), kAuto);
             if (trace_pieces)
                 std::fprintf(stderr, "[gpsiq trace]   piece %zu, blocks [%d, %d): quantise from %.3f to %.3f ms, descriptors queued at %.3f, launched at %.3f\n",
                              k, b0, b0 + nb, tq0 - t0, tq1 - t0, tq2 - t0, wall_ms() - t0);
@@ -1249,7 +1268,9 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         }
         char err[400] = "";
         if (rc != GPSIQ_OK) std::snprintf(err, sizeof err, "%s", gpsiq_last_error());
-        const int src = gpsiq_synchronize(c, c->stream);              // on every path: the kernels write the caller's buffer
+        int src = gpsiq_synchronize(c, c->stream);                    // on every path: the kernels write the caller's buffer
+        const int src2 = gpsiq_synchronize(c, c->stream2);
+        if (src == GPSIQ_OK) src = src2;
         if (src == GPSIQ_OK) for (auto &b : c->buf) b.upload_pending = false;     // the uploads the launches waited for are done
         if (rc != GPSIQ_OK) return fail(rc, "%s", err);
         if (src != GPSIQ_OK) return src;

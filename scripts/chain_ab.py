@@ -1,5 +1,5 @@
 """A/B of the knobs of the device carrier chain inside gpsiq_generate_batch (GPSIQ_NCO_REFERENCE): GPSIQ_CHAIN_HEAD,
-GPSIQ_CHAIN_STRETCHES, GPSIQ_REF_CHUNK_BLOCKS, GPSIQ_CHAIN, and one GPSIQ_TRACE=2 timeline of the default.  Run on the GPU box."""
+GPSIQ_CHAIN_STRETCHES, GPSIQ_REF_CHUNK_BLOCKS, GPSIQ_CHAIN, GPSIQ_PIECE_STREAMS (also for the fixed-point batch), and one GPSIQ_TRACE=2 timeline of the default.  Run on the GPU box."""
 import os
 import sys
 import time
@@ -28,7 +28,8 @@ def main():
     pat = synth_blocks(64, 16)
     ctx = gpsiq.Context(0)
     ctx.set_nco_mode(NCO_REFERENCE)
-    for label, fs, ss, nb in (("2M6_int8", 2.6e6, 1, 2000), ("10M_int16", 10e6, 2, 536), ("25M_int16", 25e6, 2, 200)):
+    legs = (("2M6_int8", 2.6e6, 1, 2000), ("10M_int16", 10e6, 2, 536), ("25M_int16", 25e6, 2, 200))
+    for label, fs, ss, nb in (() if "fixed" in sys.argv[1:] else legs):
         ns = int(round(fs / 10))
         d = pat[np.arange(nb) % 64]
         call = lambda: ctx.generate_batch(d, ns, fs, ss, device_ptr=ring.data_ptr())  # noqa: E731
@@ -38,13 +39,25 @@ def main():
         del os.environ["GPSIQ_TRACE"]
         print(f"{label}: default {best(call) * 1e3:.3f} ms", flush=True)
         for knob, values in (("GPSIQ_CHAIN_HEAD", ("0", "128", "256", "400", "600", "900")), ("GPSIQ_CHAIN_STRETCHES", ("16", "32")),
-                             ("GPSIQ_REF_CHUNK_BLOCKS", ("128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device"))):
+                             ("GPSIQ_REF_CHUNK_BLOCKS", ("128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device")),
+                             ("GPSIQ_PIECE_STREAMS", ("1", "2", "1", "2"))):
             for v in values:
                 os.environ[knob] = v
                 call()
                 print(f"  {knob}={v}: {best(call) * 1e3:.3f} ms", flush=True)
             del os.environ[knob]
         print(f"{label}: default again {best(call) * 1e3:.3f} ms", flush=True)
+    ctx.set_nco_mode(0)
+    nb = min(4130, ring.numel() // (2 * 260000))             # never a byte beyond the ring
+    d = pat[np.arange(nb) % 64]
+    call = lambda: ctx.generate_batch(d, 260000, 2.6e6, 1, device_ptr=ring.data_ptr())  # noqa: E731
+    call()
+    for v in ("1", "2", "1", "2"):
+        os.environ["GPSIQ_PIECE_STREAMS"] = v
+        call()
+        t = best(call)
+        print(f"fixed-point batch, {nb} blocks at 2.6 Msps int8, GPSIQ_PIECE_STREAMS={v}: {t * 1e3:.3f} ms = {nb * 260000 / t / 1e9:.1f} G samples/s", flush=True)
+    del os.environ["GPSIQ_PIECE_STREAMS"]
     ctx.close()
 
 
