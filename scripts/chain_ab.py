@@ -38,7 +38,8 @@ def main():
         call()
         del os.environ["GPSIQ_TRACE"]
         print(f"{label}: default {best(call) * 1e3:.3f} ms", flush=True)
-        for knob, values in (("GPSIQ_CHAIN_HEAD", ("0", "128", "256", "400", "600", "900")), ("GPSIQ_CHAIN_STRETCHES", ("16", "32")),
+        knobs = (("GPSIQ_PIECE_STREAMS", ("1", "2", "1", "2")),) if "streams" in sys.argv[1:] else None
+        for knob, values in knobs or (("GPSIQ_CHAIN_HEAD", ("0", "128", "256", "400", "600", "900")), ("GPSIQ_CHAIN_STRETCHES", ("16", "32")),
                              ("GPSIQ_REF_CHUNK_BLOCKS", ("128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device")),
                              ("GPSIQ_PIECE_STREAMS", ("1", "2", "1", "2"))):
             for v in values:
