@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <time.h>
 
 using namespace gpsiq;
 
@@ -108,6 +109,54 @@ int main()
         }
         if (std::memcmp(qs.data(), q0.data(), qs.size() * sizeof(gpsiq_qchan_t)) != 0) { std::fprintf(stderr, "seeded: descriptors differ\n"); return 1; }
         if (all.size() != p0.size() || std::memcmp(all.data(), p0.data(), all.size() * sizeof(gpsiq_patch_t)) != 0) { std::fprintf(stderr, "seeded: patches differ: %zu vs %zu\n", all.size(), p0.size()); return 1; }
+    }
+    // the chain linked through certified maps that LAND LATE (generate_reference with level 1 on the device: a thread of the HIP
+    // runtime releases a range of blocks when its maps are in host memory): the walkers may not touch a map before it is
+    // released, the released ranges grow while they run, and the result is the single call's.  Then a walk that is aborted
+    // while maps are still pending: every task still finishes once the ranges are released (what the error path relies on).
+    {
+        std::vector<gpsiq_chain_in_t> cin((size_t) nb * nc);
+        gpsiq_chain_inputs(ch.data(), nb * nc, cin.data());
+        std::vector<gpsiq_chain_map_t> maps((size_t) nb * nc), late((size_t) nb * nc);
+        if (gpsiq_chain_maps(cin.data(), nb, nc, fs, ns, nullptr, 5, maps.data(), nullptr) != GPSIQ_OK) { std::fprintf(stderr, "maps: %s\n", gpsiq_last_error()); return 1; }
+        struct Lander { RefWalk *w; const gpsiq_chain_map_t *from; gpsiq_chain_map_t *to; int nc, cut, nb; };
+        auto land = [](void *arg) -> void * {
+            Lander &l = *static_cast<Lander *>(arg);
+            struct timespec ts = {0, 300000};
+            nanosleep(&ts, nullptr);
+            std::memcpy(l.to, l.from, (size_t) l.cut * l.nc * sizeof(gpsiq_chain_map_t));                  // the head's maps arrive ...
+            l.w->release_maps(l.cut);
+            nanosleep(&ts, nullptr);
+            std::memcpy(l.to + (size_t) l.cut * l.nc, l.from + (size_t) l.cut * l.nc, (size_t) (l.nb - l.cut) * l.nc * sizeof(gpsiq_chain_map_t));
+            l.w->release_maps(l.nb);                                                                       // ... then the rest
+            return nullptr;
+        };
+        uint64_t stats0[2], stats1[2];
+        gpsiq_chain_stats(stats0);
+        for (int rep = 0; rep < 3; ++rep) {
+            std::memset(late.data(), 0xff, late.size() * sizeof(gpsiq_chain_map_t));      // garbage until landed: must not be read early
+            std::vector<gpsiq_qchan_t> qm((size_t) nb * nc);
+            std::vector<double> st((size_t) nb * nc);
+            std::vector<int> ends = {7, 8, 31, 64, 65, nb};
+            RefWalk w(ch.data(), nb, nc, delt, ns, qm.data(), nullptr, nullptr, ends);
+            w.in = cin.data(); w.maps = late.data(); w.maps_upto.store(0); w.start_out = st.data();
+            Lander l = {&w, maps.data(), late.data(), nc, 31 - rep, nb};                   // the head ends on / before a piece boundary
+            pthread_t th, tl;
+            if (pthread_create(&th, nullptr, run_walk, &w) != 0 || pthread_create(&tl, nullptr, land, &l) != 0) return 1;
+            const bool aborted = rep == 2;
+            if (aborted) w.abort();
+            for (size_t k = 0; k < w.npieces(); ++k) {
+                if (w.wait_piece(k) != GPSIQ_OK) { std::fprintf(stderr, "late maps, piece %zu: %s\n", k, w.err); return 1; }
+                const int b0 = k ? w.ends[k - 1] : 0;
+                if (!aborted && std::memcmp(&qm[(size_t) b0 * nc], &q0[(size_t) b0 * nc], (size_t) (w.ends[k] - b0) * nc * sizeof(gpsiq_qchan_t)) != 0) { std::fprintf(stderr, "late maps, piece %zu: descriptors differ\n", k); return 1; }
+            }
+            pthread_join(tl, nullptr); pthread_join(th, nullptr);
+            if (aborted) continue;
+            for (int c = 0; c < nc; ++c)
+                if (w.carr_end[c] != carr0[c] || w.last_prn[c] != prn0[c]) { std::fprintf(stderr, "late maps: end state differs in slot %d\n", c); return 1; }
+        }
+        gpsiq_chain_stats(stats1);
+        if (stats1[0] - stats0[0] < (uint64_t) nb * nc) { std::fprintf(stderr, "late maps: only %llu blocks were linked through their map\n", (unsigned long long) (stats1[0] - stats0[0])); return 1; }
     }
     // the pool itself: thousands of tiny jobs from two submitting threads at once (a job wakes only as many workers as it wants
     // helpers and polls for the ones still inside before it sleeps; a job's record lives on its submitter's stack): every index

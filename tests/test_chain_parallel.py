@@ -110,6 +110,18 @@ def test_soak_program_random_and_adversarial_timelines(tmp_path):
         assert r.returncode == 0 and " bad=0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+
+def test_lane_code_under_asan_and_ubsan(tmp_path):
+    """The same program with -fsanitize=address,undefined (no recovery): the lanes' shifts, 128-bit arithmetic, bit casts and table
+    indices on random and adversarial timelines -- the code the kernels run, where a sanitizer can see it."""
+    csrc = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")
+    exe = str(tmp_path / "chain_parallel_san")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", exe,
+                    os.path.join(ROOT, "tests", "chain_parallel.cpp"), os.path.join(csrc, "gpsiq_host.cpp"), "-lpthread", "-lm"], check=True)
+    r = subprocess.run([exe, "5", "24"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " bad=0" in r.stdout and "runtime error" not in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
+
 # ---- on the GPU --------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def ctx():
