@@ -37,9 +37,11 @@ struct gpsiq_ctx {
     hipStream_t   stream2 = nullptr;                     // every other piece of a batch in pieces (piece_stream below)
     DeviceTables *d_tab = nullptr;
     hipStream_t   copy_stream[2] = {nullptr, nullptr};   // device-to-host copies of the batch calls
-    // resident descriptors, double-buffered: a new set is staged and uploaded into the buffer the
-    // last launch is NOT reading, so gpsiq_set_descriptors never waits for the device to go idle --
-    // only, if it is still in flight, for the launch from two sets ago that used the same buffer
+    // resident descriptors, kSets buffers taken in turn: a new set is staged and uploaded into a buffer the latest launches
+    // are NOT reading, so gpsiq_set_descriptors never waits for the device to go idle -- only, if it is still in flight, for the
+    // launch from kSets sets ago that used the same buffer.  Four: the pieces of a batch alternate between two streams and a
+    // piece's kernel shares the device with its neighbour's, so with two sets piece k+2 waited for a piece k that had been
+    // slowed down by piece k+1 (GPSIQ_DESC_SETS=2 for the A/B, read per set)
     struct DescBuf {
         gpsiq_qchan_t *d = nullptr;  size_t cap = 0;      // device copy, in descriptors
         gpsiq_qchan_t *h = nullptr;  size_t hcap = 0;     // page-locked staging of the compacted descriptors
@@ -61,7 +63,8 @@ struct gpsiq_ctx {
         // them, and every launch on the set waits for it on its own stream
         hipEvent_t     uploaded = nullptr;
         bool           upload_pending = false;
-    } buf[2];
+    } buf[4];
+    static constexpr int kSets = 4;
     hipStream_t    up_stream = nullptr;  // descriptor / patch uploads: never behind a running kernel
     int            cur = 0;             // buf[cur] holds the resident set
     gpsiq_qchan_t *d_desc = nullptr;    // == buf[cur].d
@@ -253,7 +256,7 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
         if (a.out) (void) hipFree(a.out);
         if (a.done) (void) hipEventDestroy(a.done);
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < gpsiq_ctx::kSets; ++i) {
         if (c->buf[i].d) (void) hipFree(c->buf[i].d);
         if (c->buf[i].h) (void) hipHostFree(c->buf[i].h);
         if (c->buf[i].d_patch) (void) hipFree(c->buf[i].d_patch);
@@ -261,6 +264,8 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
         if (c->buf[i].uploaded) (void) hipEventDestroy(c->buf[i].uploaded);
         for (auto &u : c->buf[i].use)
             if (u.ev) (void) hipEventDestroy(u.ev);
+    }
+    for (int i = 0; i < 2; ++i) {
         if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
         if (c->copy_stream[i]) (void) hipStreamDestroy(c->copy_stream[i]);
     }
@@ -324,8 +329,11 @@ static int set_descriptors_impl(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblo
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t) nblocks * (size_t) nchan;
-    gpsiq_ctx::DescBuf &nb = c->buf[c->cur ^ 1];        // the set not being read by the latest launches
-    // the launch from two sets ago may still be reading this buffer (and its staging may still be
+    int nsets = gpsiq_ctx::kSets;
+    if (const char *e = std::getenv("GPSIQ_DESC_SETS")) { const int v = std::atoi(e); if (v >= 2 && v <= gpsiq_ctx::kSets) nsets = v; }
+    const int next = (c->cur + 1) % nsets;
+    gpsiq_ctx::DescBuf &nb = c->buf[next];              // a set not being read by the latest launches
+    // the launch from kSets sets ago may still be reading this buffer (and its staging may still be
     // the source of an upload): wait for exactly that, not for the whole device
     { int wrc = wait_idle(nb); if (wrc) return wrc; }
     if (n > nb.hcap) {
@@ -419,7 +427,7 @@ static int set_descriptors_impl(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblo
             std::fprintf(stderr, "[gpsiq trace] descriptors %d blocks: validate+compact %.2f ms, upload %s %.2f ms\n",
                          nblocks, t1 - t0, no_wait ? "queued" : "done", wall_ms() - t1);
     }
-    c->cur ^= 1;
+    c->cur = next;
     c->d_desc = nb.d;
     c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = pj.mx; c->max_active = pj.max_active; c->max_amplitude = pj.max_amp;
     nb.npatch = n ? npatch : 0;

@@ -38,7 +38,7 @@ def main():
         call()
         del os.environ["GPSIQ_TRACE"]
         print(f"{label}: default {best(call) * 1e3:.3f} ms", flush=True)
-        knobs = (("GPSIQ_PIECE_STREAMS", ("1", "2", "1", "2")),) if "streams" in sys.argv[1:] else None
+        knobs = (("GPSIQ_PIECE_STREAMS", ("1", "2")), ("GPSIQ_DESC_SETS", ("2", "3", "4", "2", "4"))) if "streams" in sys.argv[1:] else None
         for knob, values in knobs or (("GPSIQ_CHAIN_HEAD", ("0", "128", "256", "400", "600", "900")), ("GPSIQ_CHAIN_STRETCHES", ("16", "32")),
                              ("GPSIQ_REF_CHUNK_BLOCKS", ("128", "256", "512")), ("GPSIQ_CHAIN", ("host", "device")),
                              ("GPSIQ_PIECE_STREAMS", ("1", "2", "1", "2"))):
@@ -53,12 +53,13 @@ def main():
     d = pat[np.arange(nb) % 64]
     call = lambda: ctx.generate_batch(d, 260000, 2.6e6, 1, device_ptr=ring.data_ptr())  # noqa: E731
     call()
-    for v in ("1", "2", "1", "2"):
-        os.environ["GPSIQ_PIECE_STREAMS"] = v
-        call()
-        t = best(call)
-        print(f"fixed-point batch, {nb} blocks at 2.6 Msps int8, GPSIQ_PIECE_STREAMS={v}: {t * 1e3:.3f} ms = {nb * 260000 / t / 1e9:.1f} G samples/s", flush=True)
-    del os.environ["GPSIQ_PIECE_STREAMS"]
+    for knob, values in (("GPSIQ_PIECE_STREAMS", ("1", "2", "1", "2")), ("GPSIQ_DESC_SETS", ("2", "4", "2", "4"))):
+        for v in values:
+            os.environ[knob] = v
+            call()
+            t = best(call)
+            print(f"fixed-point batch, {nb} blocks at 2.6 Msps int8, {knob}={v}: {t * 1e3:.3f} ms = {nb * 260000 / t / 1e9:.1f} G samples/s", flush=True)
+        del os.environ[knob]
     ctx.close()
 
 
