@@ -103,6 +103,27 @@ __global__ __launch_bounds__(256) void ub(uint32_t *out, int iters, uint64_t s0,
             : [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [sq] "s"(s1));
             SB(Q0) SB(Q1) SB(Q2) SB(Q3) SB(P0) SB(P1) SB(P2) SB(P3)
             acc += a;
+        } else if (MODE == 8) {    // round-4 verdict's experiment: TWO rows per trip; the even row is the plain-add core with its two
+            // 64-bit NCO adds (by two rows' worth), the odd row takes its phase words from hi + dhi with plain 32-bit VOP2 adds
+            // (per-channel steps held in VGPRs: an SGPR operand makes the add a 4.3-cycle form) and has no NCO add -- the carry
+            // out of the low words is dropped, so a sample whose field sits under a run of ones would have to go to a patch
+            // list.  One trip = 4 channels x 2 rows = 8 channel steps, as in the other modes.
+            uint32_t dph = (uint32_t) (s0 >> 32) + (threadIdx.x & 0u), dqh = (uint32_t) (s1 >> 32) + (threadIdx.x & 0u), tp, tq;
+#define ROW2(Pn, Qn, T) asm volatile( \
+            "v_lshrrev_b32_sdwa " T ", %[qh], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n" \
+            "v_lshl_add_u32 " T ", " T ", 26, %[ph]\n" \
+            "v_and_b32_sdwa " T ", " T ", %[mask] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n" \
+            "v_add_u32 %[tp], %[ph], %[dph]\n" \
+            "v_add_u32 %[tq], %[qh], %[dqh]\n" \
+            "v_lshl_add_u64 %[p], %[p], 0, %[sp]\n" \
+            "v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" \
+            "v_lshrrev_b32_sdwa %[tq], %[tq], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n" \
+            "v_lshl_add_u32 %[tq], %[tq], 26, %[tp]\n" \
+            "v_and_b32_sdwa %[tq], %[tq], %[mask] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n" \
+            "v_add3_u32 %[acc], %[acc], " T ", %[tq]\n" \
+            : [p] "+v"(Pn), [q] "+v"(Qn), [a] "+v"(a), [k] "+v"(k), [acc] "+v"(acc), [tp] "=&v"(tp), [tq] "=&v"(tq) \
+            : [ph] "v"((uint32_t) (Pn >> 32)), [qh] "v"((uint32_t) (Qn >> 32)), [w] "v"(w), [mask] "s"(mask), [sp] "s"(s0), [sq] "s"(s1), [dph] "v"(dph), [dqh] "v"(dqh));
+            ROW2(P0, Q0, "%[a]") ROW2(P1, Q1, "%[k]") ROW2(P2, Q2, "%[a]") ROW2(P3, Q3, "%[k]")
         } else if (MODE == 3) {    // NCO adds with VGPR steps instead of SGPR pairs
             uint64_t v0 = s0 + threadIdx.x, v1 = s1 + threadIdx.x;
 #define TWOV(Pn, Qn) asm volatile("v_lshl_add_u64 %[p], %[p], 0, %[sp]\n v_lshl_add_u64 %[q], %[q], 0, %[sq]\n" : [p] "+v"(Pn), [q] "+v"(Qn) : [sp] "v"(v0), [sq] "v"(v1));
@@ -148,6 +169,7 @@ int main()
         run<5>("lane = channel: the same core + LUT base + 4 DPP row adds per 4 samples", w, 11);
         run<6>("sign-word row loop: lshr const,lshl_add,sdwa and,1/2 add3,1x lshl_add_u64", w, 4);
         run<7>("sign-word builder: lshl_add_u64, sdwa lshr, alignbit", w, 3);
+        run<8>("two rows per trip: 64-bit NCO adds on even rows, hi + dhi (VOP2) on odd rows", w, 5);
     }
     return 0;
 }
