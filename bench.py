@@ -330,10 +330,13 @@ def main():
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a GPU (libgpsiq has no CPU path)")
         ndev = torch.cuda.device_count()
-        if local_rank >= ndev and os.environ.get("GPSIQ_BENCH_SHARE_GPU", "0") in ("", "0"):
+        # One visible device and a local rank beyond it: a launcher that gives every rank its own device through
+        # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES -- ordinal 0 is then this rank's GPU, and the PCI bus ids gathered below
+        # tell isolation (all different) from a box with too few GPUs (two ranks on one bus id: exit 5).
+        if local_rank >= ndev and ndev > 1 and os.environ.get("GPSIQ_BENCH_SHARE_GPU", "0") in ("", "0"):
             print(f"bench.py: rank {rank} (local {local_rank}) has no GPU of its own: {ndev} visible", file=sys.stderr)
             sys.exit(3)
-        dev = local_rank % ndev                       # the modulo only under GPSIQ_BENCH_SHARE_GPU=1 (scripts/gpu_validate.sh)
+        dev = local_rank % ndev                       # the modulo: per-rank visibility (above), or GPSIQ_BENCH_SHARE_GPU=1
         torch.cuda.set_device(dev)
     dist = None
     backend = "gloo" if dry else os.environ.get("GPSIQ_BENCH_BACKEND", "nccl")    # nccl == RCCL on ROCm
@@ -348,20 +351,23 @@ def main():
     variant = gpsiq.variants()[args.variant]
     placement = None
     if world > 1:
-        # Where every rank runs, before anything of libgpsiq touches a device: the first collective of the job is this 256-byte
+        # Where every rank runs, before anything of libgpsiq touches a device: the first collective of the job is this 512-byte
         # all-gather, so a broken RCCL / gloo shows up HERE, named, and not as a hang in the middle of the bench; two ranks that
         # resolved to one device (a launcher that did not set LOCAL_RANK, a box with fewer GPUs than ranks) fail the run.
         me = {"rank": rank, "local_rank": local_rank, "device": None if dry else dev,
-              "pci_bus_id": None if dry else pci_bus_id(torch, dev), "host": os.uname().nodename,
-              "cpus_granted": effective_cpus(), "GPSIQ_THREADS": os.environ.get("GPSIQ_THREADS")}
+              "pci_bus_id": None if dry else pci_bus_id(torch, dev), "host": os.uname().nodename[-64:],
+              "cpus_granted": effective_cpus(), "GPSIQ_THREADS": os.environ.get("GPSIQ_THREADS"),
+              "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")}
+        if me["visible"]:
+            me["visible"] = me["visible"][:64]           # every rank sends the same 512 bytes whatever the names are
         try:
-            placement = [json.loads(b.decode()) for b in gather(json.dumps(me).ljust(256).encode())]
+            placement = [json.loads(b.decode()) for b in gather(json.dumps(me).ljust(512).encode()[:512])]
         except Exception as ex:
             print(f"bench.py: rank {rank}: the first collective ({backend}) failed before libgpsiq was used: {type(ex).__name__}: {ex}", file=sys.stderr)
             sys.exit(4)
         seen = {}
         for pl in placement:
-            key = (pl["host"], pl["pci_bus_id"] if pl["pci_bus_id"] else pl["device"])
+            key = (pl["host"], pl["pci_bus_id"] if pl["pci_bus_id"] else (pl["device"], pl.get("visible")))
             if not dry and key in seen and os.environ.get("GPSIQ_BENCH_SHARE_GPU", "0") in ("", "0"):
                 if rank == 0:
                     print(f"bench.py: ranks {seen[key]} and {pl['rank']} resolve to the same device {key}: refusing to run", file=sys.stderr)
