@@ -401,3 +401,35 @@ print("RESULT", hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest(), best, t
     assert "piece-major" in out["2"][2] and "piece-major" not in out[None][2]
     print("reference-NCO batch, 600 blocks: %.2f ms with all host threads, %.2f ms with GPSIQ_THREADS=2" % (out[None][1] * 1e3, out["2"][1] * 1e3))
     assert out["2"][1] < 12.0 * out[None][1]
+
+
+@pytest.mark.parametrize("streams,sets", [("1", "2"), ("1", "4"), ("2", "2"), ("2", "3")])
+def test_pieces_on_one_or_two_streams_over_two_to_four_descriptor_sets(rctx, oracle, monkeypatch, streams, sets):
+    """The A/B switches of the piece scheduling (GPSIQ_PIECE_STREAMS, GPSIQ_DESC_SETS; default: two streams, four sets) change
+    nothing but the schedule: 21 blocks in pieces of 2, both NCO models, every element the oracle's / the float loop's."""
+    import torch
+    monkeypatch.setenv("GPSIQ_PIECE_STREAMS", streams)
+    monkeypatch.setenv("GPSIQ_DESC_SETS", sets)
+    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "2")
+    monkeypatch.setenv("GPSIQ_BATCH_PIECE_BLOCKS", "2")
+    fs, nb, nc = 2.6e6, 21, 7
+    ns = 26000
+    d = synth_blocks(nb, nc, seed=131)
+    want, carr_want = float_run_ns(oracle, d, fs, ns, SC08)
+    buf = torch.zeros(nb * 2 * ns, dtype=torch.uint8, device="cuda")
+    carr = np.zeros(nc)
+    rctx.generate_batch(d, ns, fs, SC08, device_ptr=buf.data_ptr(), carr_out=carr)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.int8).reshape(nb, 2 * ns), want)
+    assert np.array_equal(carr, carr_want)
+    rctx.set_nco_mode(0)
+    try:
+        qo = oracle.quantize_blocks(d, fs, ns)
+        buf.zero_()
+        rctx.generate_batch(d, ns, fs, SC08, device_ptr=buf.data_ptr())
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().view(np.int8).reshape(nb, 2 * ns)
+        for b in range(nb):
+            assert np.array_equal(got[b], oracle.block_fixed(qo[b], ns, SC08)), b
+    finally:
+        rctx.set_nco_mode(NCO_REFERENCE)
