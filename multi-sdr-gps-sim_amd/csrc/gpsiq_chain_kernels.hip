@@ -36,10 +36,12 @@ struct ScanD { double v; int flag; };
 
 // ---- prepare ---------------------------------------------------------------------------------------------------------
 // est layout as on the host: start[nchan] may be null (the timeline begins here).
-__global__ __launch_bounds__(kPrepThreads) void chain_prepare(const gpsiq_chain_in_t *__restrict__ in, int nblocks, int nchan, double delt, int nsamp,
+// in: rows of `stride` bytes that begin with a gpsiq_chain_in_t (24: the type itself; 64: ev::DChan, gpsiq_eval.h)
+__global__ __launch_bounds__(kPrepThreads) void chain_prepare(const char *__restrict__ in_rows, int stride, int nblocks, int nchan, double delt, int nsamp,
                                                               const gpsiq_chain_est_t *__restrict__ start, Prep *__restrict__ prep,
                                                               double *__restrict__ c_before, gpsiq_chain_est_t *__restrict__ end)
 {
+    auto in_at = [&](size_t k) -> gpsiq_chain_in_t { return *reinterpret_cast<const gpsiq_chain_in_t *>(in_rows + k * (size_t) stride); };
     __shared__ ScanR sr[kPrepThreads];
     __shared__ ScanD sd[kPrepThreads];
     __shared__ int s_any_seed;
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(kPrepThreads) void chain_prepare(const gpsiq_chain_
         gpsiq_chain_in_t d = {0.0, 0.0, 0, 0};
         int prev_prn = 0;
         if (live) {
-            d = in[(size_t) b * nchan + i];
-            prev_prn = b > 0 ? in[(size_t) (b - 1) * nchan + i].prn : prn0;
+            d = in_at((size_t) b * nchan + i);
+            prev_prn = b > 0 ? in_at((size_t) (b - 1) * nchan + i).prn : prn0;
             if (prev_prn < 0) prev_prn = 0;
         }
         const bool active = live && d.prn > 0;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kPrepThreads) void chain_prepare(const gpsiq_chain_
         Dc = ed.flag ? ed.v : Dc + ed.v;
         // the satellite and Doppler of the chunk's last block, for `end` (every thread reads them: two loads)
         {
-            const gpsiq_chain_in_t l = in[(size_t) (base + n_here - 1) * nchan + i];
+            const gpsiq_chain_in_t l = in_at((size_t) (base + n_here - 1) * nchan + i);
             last_prn = l.prn > 0 ? l.prn : 0;
             last_f = l.f_carr;
         }
@@ -210,13 +212,13 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     }
 }
 
-hipError_t launch_chain(const gpsiq_chain_in_t *d_in, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
+hipError_t launch_chain(const void *d_in, int in_stride, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
                         int max_seg, void *d_prep_, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream)
 {
     if (nblocks <= 0) return hipSuccess;
     Prep *d_prep = static_cast<Prep *>(d_prep_);
     Rec *d_rec = static_cast<Rec *>(d_maps);
-    hipLaunchKernelGGL(chain_prepare, dim3((unsigned) nchan), dim3(kPrepThreads), 0, stream, d_in, nblocks, nchan, delt, nsamp, d_start, d_prep, d_c_before, d_end);
+    hipLaunchKernelGGL(chain_prepare, dim3((unsigned) nchan), dim3(kPrepThreads), 0, stream, static_cast<const char *>(d_in), in_stride, nblocks, nchan, delt, nsamp, d_start, d_prep, d_c_before, d_end);
 #define GPSIQ_LANES(S)                                                                                                    \
     hipLaunchKernelGGL(chain_lanes<S>, dim3((unsigned) (nchan * ((nblocks + kLaneThreads / S - 1) / (kLaneThreads / S)))), dim3(kLaneThreads), 0, stream, \
                        d_prep, d_c_before, nblocks, nchan, nsamp, max_seg, d_rec)

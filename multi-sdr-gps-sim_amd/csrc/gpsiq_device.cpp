@@ -12,116 +12,9 @@
 #include <new>
 #include <vector>
 
-#include "gpsiq_internal.h"
-
-namespace gpsiq {
-hipError_t launch_variant(int variant, const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size,
-                          void *dst, size_t block_stride, int block0, int nblocks,
-                          const DeviceTables *tab, hipStream_t stream, int max_active, long max_amplitude, void *scratch);
-size_t variant_scratch_bytes(int variant, int nsamp, int nblocks);
-hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int sample_size, void *dst, size_t block_stride,
-                          int block0, int nblocks, const DeviceTables *tab, const gpsiq_patch_t *patches, int npatch,
-                          hipStream_t stream);
-// the time-parallel carrier chain (gpsiq_chain_kernels.hip; the buffers are opaque here: 32-byte Prep, 56-byte maps)
-hipError_t launch_chain(const gpsiq_chain_in_t *d_in, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
-                        int max_seg, void *d_prep, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream);
-int chain_link(const gpsiq_chain_in_t *in, const void *maps, int nblocks, int nchan, double delt, int nsamp,
-               const double *carr_in, const int32_t *prn_in, double *carr_start, double *carr_end, int32_t *last_prn);
-}
+#include "gpsiq_ctx.h"
 
 using namespace gpsiq;
-
-struct gpsiq_ctx {
-    int           device = -1;
-    hipStream_t   stream = nullptr;
-    hipStream_t   stream2 = nullptr;                     // every other piece of a batch in pieces (piece_stream below)
-    DeviceTables *d_tab = nullptr;
-    hipStream_t   copy_stream[2] = {nullptr, nullptr};   // device-to-host copies of the batch calls
-    // resident descriptors, kSets buffers taken in turn: a new set is staged and uploaded into a buffer the latest launches
-    // are NOT reading, so gpsiq_set_descriptors never waits for the device to go idle -- only, if it is still in flight, for the
-    // launch from kSets sets ago that used the same buffer.  Four: the pieces of a batch alternate between two streams and a
-    // piece's kernel shares the device with its neighbour's, so with two sets piece k+2 waited for a piece k that had been
-    // slowed down by piece k+1 (GPSIQ_DESC_SETS=2 for the A/B, read per set)
-    struct DescBuf {
-        gpsiq_qchan_t *d = nullptr;  size_t cap = 0;      // device copy, in descriptors
-        gpsiq_qchan_t *h = nullptr;  size_t hcap = 0;     // page-locked staging of the compacted descriptors
-        // one event per stream that has launched on this buffer since it was last known idle: a launch on stream B must
-        // not hide a longer one still running on stream A (when more than kUses streams are in play the extra ones
-        // are chained behind the first, which then covers them)
-        struct Use { hipStream_t s = nullptr; hipEvent_t ev = nullptr; bool active = false; };
-        static constexpr int kUses = 4;
-        Use            use[kUses];
-        bool           in_use = false;
-        std::vector<uint8_t> active_per_block;            // active channels of every resident block (patch validation)
-        // patches that go with this set (GPSIQ_NCO_REFERENCE): per buffer, so that the next set's list can be uploaded
-        // while launches of this one are still applying theirs
-        gpsiq_patch_t *d_patch = nullptr;
-        size_t         patch_cap = 0;
-        int            npatch = 0;
-        gpsiq_patch_t *h_patch = nullptr;  size_t h_patch_cap = 0;   // page-locked staging of the list (asynchronous sets)
-        // a set staged without waiting (the pieces of a batch): the uploads are on up_stream, `uploaded` is recorded behind
-        // them, and every launch on the set waits for it on its own stream
-        hipEvent_t     uploaded = nullptr;
-        bool           upload_pending = false;
-    } buf[4];
-    static constexpr int kSets = 4;
-    hipStream_t    up_stream = nullptr;  // descriptor / patch uploads: never behind a running kernel
-    int            cur = 0;             // buf[cur] holds the resident set
-    gpsiq_qchan_t *d_desc = nullptr;    // == buf[cur].d
-    int            nblocks = 0, nchan = 0;
-    uint64_t       max_code_step = 0;
-    int            max_active = 0;      // most active channels in any resident block
-    long           max_amplitude = 0;   // largest sum over a block's channels of (int)(250*|gain|): bound on |I|, |Q|
-    int            nco_mode = GPSIQ_NCO_FIXED;
-    // scratch of the kernel variants that need some (segm: the sign masks of one launch)
-    void          *d_scratch = nullptr;
-    size_t         scratch_cap = 0;
-    // staging for the synchronous entry points
-    void          *d_out = nullptr;
-    size_t         out_cap = 0;
-    hipEvent_t     chunk_done[2] = {nullptr, nullptr};
-    // gpsiq_generate_block_async: a small ring of per-block descriptor / output staging, each with the event that
-    // says its block has landed
-    struct AsyncSlot {
-        gpsiq_qchan_t *d = nullptr, *h = nullptr;
-        gpsiq_patch_t *d_patch = nullptr, *h_patch = nullptr;   // GPSIQ_NCO_REFERENCE: the block's patches, staged page-locked
-        size_t         patch_cap = 0;
-        void          *out = nullptr;
-        size_t         out_cap = 0;
-        hipEvent_t     done = nullptr;
-        bool           busy = false;
-    } aslot[4];
-    int anext = 0;
-    // carrier carry per slot (gpsiq_generate_block)
-    uint64_t carry[GPSIQ_MAX_CHAN] = {};
-    double   handed[GPSIQ_MAX_CHAN] = {};
-    int      carry_prn[GPSIQ_MAX_CHAN] = {};
-    // GPSIQ_NCO_REFERENCE batch calls: quantised descriptors and start states of the timeline being worked through, kept
-    // between calls (a fresh 1.5 MB per call is four hundred page faults on the thread everything else waits for)
-    std::vector<gpsiq_qchan_t> ref_q;
-    std::vector<double>        ref_start;
-    // the carrier chain of GPSIQ_NCO_REFERENCE on the device (gpsiq_chain_maps_device): inputs, estimates and maps of the
-    // timeline being worked through, device side and page-locked staging, kept between calls
-    struct Chain {
-        size_t             cap = 0;                    // blocks x channels all of these hold
-        gpsiq_chain_in_t  *d_in = nullptr, *h_in = nullptr;
-        void              *d_prep = nullptr;           // lane::Prep, 32 bytes each
-        gpsiq_chain_map_t *d_maps = nullptr, *h_maps = nullptr;
-        gpsiq_chain_est_t *d_est = nullptr, *h_est = nullptr;       // [3][GPSIQ_MAX_CHAN]: start, end of the first launch (= start of a second), end
-        double            *d_c_before = nullptr;
-        hipStream_t        stream = nullptr, back = nullptr;   // uploads + kernels; the maps' way back + the callbacks (never in the kernels' way)
-        hipEvent_t         t0 = nullptr, t1 = nullptr, landed = nullptr;   // landed: the maps of the last range queued are in h_maps
-        hipEvent_t         walked[2] = {nullptr, nullptr};     // a launch's kernels are done
-        float              last_ms = 0.0f;             // device time of the last call's two kernels
-    } chain;
-};
-
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(GPSIQ_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));             \
-    } while (0)
 
 // GPSIQ_TRACE=1 in the environment prints the host-side phase times of the batch call to stderr
 static double wall_ms()
@@ -269,6 +162,7 @@ void gpsiq_destroy(gpsiq_ctx_t *c)
         if (c->chunk_done[i]) (void) hipEventDestroy(c->chunk_done[i]);
         if (c->copy_stream[i]) (void) hipStreamDestroy(c->copy_stream[i]);
     }
+    gpsiq_evaldev_destroy(c);
     if (c->chain.d_in) (void) hipFree(c->chain.d_in);
     if (c->chain.h_in) (void) hipHostFree(c->chain.h_in);
     if (c->chain.d_prep) (void) hipFree(c->chain.d_prep);
@@ -825,9 +719,9 @@ static int chain_reserve(gpsiq_ctx *c, size_t n)
         HIP_TRY(hipEventCreate(&k.t0));
         HIP_TRY(hipEventCreate(&k.t1));
         HIP_TRY(hipEventCreateWithFlags(&k.landed, hipEventDisableTiming));
-        HIP_TRY(hipMalloc((void **) &k.d_est, 3 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t)));
-        HIP_TRY(hipHostMalloc((void **) &k.h_est, 3 * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t), hipHostMallocDefault));
-        HIP_TRY(hipMalloc((void **) &k.d_c_before, 2 * GPSIQ_MAX_CHAN * sizeof(double)));
+        HIP_TRY(hipMalloc((void **) &k.d_est, (kEvalMaxPieces + 1) * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t)));
+        HIP_TRY(hipHostMalloc((void **) &k.h_est, (kEvalMaxPieces + 1) * GPSIQ_MAX_CHAN * sizeof(gpsiq_chain_est_t), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &k.d_c_before, kEvalMaxPieces * GPSIQ_MAX_CHAN * sizeof(double)));
     }
     if (n <= k.cap) return GPSIQ_OK;
     if (k.d_in) (void) hipFree(k.d_in);
@@ -866,7 +760,7 @@ static int chain_queue(gpsiq_ctx *c, int part, int b0, int nb, int nchan, double
         d_start = k.d_est;
     }
     if (part == 0) HIP_TRY(hipEventRecord(k.t0, k.stream));
-    HIP_TRY(launch_chain(k.d_in + off, nb, nchan, 1.0 / fs, nsamp, d_start, max_stretches, static_cast<char *>(k.d_prep) + off * 32,
+    HIP_TRY(launch_chain(k.d_in + off, (int) sizeof(gpsiq_chain_in_t), nb, nchan, 1.0 / fs, nsamp, d_start, max_stretches, static_cast<char *>(k.d_prep) + off * 32,
                          k.d_c_before + part * GPSIQ_MAX_CHAN, k.d_est + (part + 1) * GPSIQ_MAX_CHAN, k.d_maps + off, k.stream));
     HIP_TRY(hipEventRecord(k.t1, k.stream));
     // the maps' way back on a stream of its own: the next launch's kernels follow these at once (a callback queued between
@@ -1222,6 +1116,11 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
     int rc = check_gen_args(c, ch, dst, nblocks, nchan, nsamp, fs, sample_size);
     if (rc) return rc;
     if (nblocks == 0) return GPSIQ_OK;                    // an empty batch leaves the carried phases alone
+    {   // descriptors quantised / evaluated on the device (gpsiq_evaldev.cpp) where that path takes the call
+        int handled = 0;
+        rc = gpsiq_generate_device(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out, nullptr, &handled);
+        if (handled) return rc;
+    }
     if (c->nco_mode == GPSIQ_NCO_REFERENCE)
         return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out);
     const char *trace_env = std::getenv("GPSIQ_TRACE");
@@ -1313,6 +1212,11 @@ int gpsiq_generate_seeded(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, i
     if (nblocks == 0) return GPSIQ_OK;
     for (size_t k = 0; k < (size_t) nblocks * (size_t) nchan; ++k)
         if (ch[k].prn > 0 && !(carr_start[k] >= 0.0 && carr_start[k] <= 1.0)) return fail(GPSIQ_E_RANGE, "start phase %zu outside [0, 1]", k);
+    {
+        int handled = 0;
+        rc = gpsiq_generate_device(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, nullptr, carr_start, &handled);
+        if (handled) return rc;
+    }
     return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, nullptr, carr_start);
 }
 
@@ -1508,3 +1412,17 @@ int gpsiq_generate_batch_multi(gpsiq_ctx_t *const *ctx, int ndev, const gpsiq_ch
 }
 
 }  // extern "C"
+
+// ---- what gpsiq_evaldev.cpp uses of this file ---------------------------------------------------------------------------------
+double gpsiq_wall_ms() { return wall_ms(); }
+int gpsiq_wait_idle(gpsiq_ctx::DescBuf &b) { return wait_idle(b); }
+int gpsiq_mark_use(gpsiq_ctx::DescBuf &b, hipStream_t s) { return mark_use(b, s); }
+int gpsiq_ensure_out(gpsiq_ctx *c, size_t bytes) { return ensure_out(c, bytes); }
+hipStream_t gpsiq_piece_stream(gpsiq_ctx *c, int k) { return piece_stream(c, k); }
+int gpsiq_chain_reserve(gpsiq_ctx *c, size_t n) { return chain_reserve(c, n); }
+double gpsiq_rate_kernel() { return rate_kernel(); }
+int gpsiq_generate_reference_host(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
+                                  int sample_size, void *dst, int dst_is_device, double *carr_phase_out, const double *seeds)
+{
+    return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out, seeds);
+}

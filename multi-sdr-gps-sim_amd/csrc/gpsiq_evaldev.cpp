@@ -1,0 +1,575 @@
+// gpsiq_evaldev.cpp -- gpsiq_generate_batch / gpsiq_generate_seeded with the descriptors quantised and, in GPSIQ_NCO_REFERENCE,
+// chained and evaluated ON THE DEVICE (kernels: gpsiq_chain_kernels.hip, gpsiq_eval_kernels.hip; the lane code: gpsiq_eval.h).
+//
+// What the reference's host code leaves per block and channel at gps.c:2766 (gpsiq_chan_t) goes in; per piece of the batch
+//     pack -> [chain_prepare -> chain_lanes -> chain_link_scan] -> eval_blocks | quantize_fixed -> synth_tile (-> apply_patches)
+// with no host stage between them.  What the host still does:
+//   * descriptors in PAGEABLE host memory are cut down to 64 bytes each on the pool (the device cannot read them; page-locked
+//     and device-resident descriptors are read where they lie);
+//   * it waits for each piece's link (an event, the device busy with the pieces behind) to learn the synthesis kernel's launch
+//     parameters and whether a slot has a block whose certified map does not apply -- then that slot's chain is walked by the host
+//     walker (lane::link_block + the true walk, as rounds 4-5 did for every slot) and its start states go back up;
+//   * the (block, channel) pairs whose candidates the drift enclosure cannot decide (1 in 10^4) get the host evaluation
+//     (eval_block) while the device renders, and the merged, sorted patch list goes up before apply_patches.
+// Results are those of the host path (gpsiq_generate_reference_host / the host quantiser) bit for bit: tests/eval_twin.cpp on
+// the CPU, tests/test_gpu_device_eval.py and every T2 = 0 test on the GPU.
+// Reference lines: gps.c:2033-2064 (what the quantiser takes in), 2775-2782 (index + truncation), 2789-2826 (the accumulators),
+// 2208-2214 (re-seeding a slot).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "gpsiq_ctx.h"
+#include "gpsiq_eval.h"
+
+using namespace gpsiq;
+
+namespace gpsiq {
+// gpsiq_exact.cpp: one channel of one block on the host (descriptor + patches from its start state)
+int eval_block_host(const gpsiq_chan_t &ch, double start, double delt, int nsamp, int block, int slot, gpsiq_qchan_t *q,
+                    std::vector<gpsiq_patch_t> *out);
+}
+
+namespace {
+
+enum SrcKind { kSrcPageable = 0, kSrcPinned = 1, kSrcDevice = 2 };
+
+SrcKind classify(const void *p, int device, const void **dev_ptr)
+{
+    *dev_ptr = nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return kSrcPageable; }
+    if (a.type == hipMemoryTypeDevice && a.device == device) { *dev_ptr = p; return kSrcDevice; }
+    if (a.type == hipMemoryTypeHost) return kSrcPinned;
+    return kSrcPageable;               // unregistered, managed, another device's: through the host
+}
+
+constexpr unsigned kPatchCap = 1u << 16, kHostCap = 1u << 13;
+
+int evd_reserve(gpsiq_ctx *c, size_t n, SrcKind kind, bool seeds)
+{
+    gpsiq_ctx::EvalDev &e = c->evd;
+    int rc = gpsiq_chain_reserve(c, n);
+    if (rc) return rc;
+    if (!e.eval_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e.eval_stream, hipStreamNonBlocking));
+        for (auto &ev_ : e.linked) HIP_TRY(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+        for (auto &ev_ : e.evaluated) HIP_TRY(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e.joined, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **) &e.d_ctrl, sizeof(EvalCtrl)));
+        HIP_TRY(hipHostMalloc((void **) &e.h_ctrl, (kEvalMaxPieces + 2) * sizeof(EvalCtrl), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &e.d_link, GPSIQ_MAX_CHAN * sizeof(LinkCarry)));
+        HIP_TRY(hipHostMalloc((void **) &e.h_link, GPSIQ_MAX_CHAN * sizeof(LinkCarry), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &e.d_fix, GPSIQ_MAX_CHAN * sizeof(FixedCarry)));
+        HIP_TRY(hipHostMalloc((void **) &e.h_fix, GPSIQ_MAX_CHAN * sizeof(FixedCarry), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &e.d_patches, kPatchCap * sizeof(gpsiq_patch_t)));
+        HIP_TRY(hipHostMalloc((void **) &e.h_patches, kPatchCap * sizeof(gpsiq_patch_t), hipHostMallocDefault));
+        e.patch_cap = kPatchCap;
+        HIP_TRY(hipMalloc((void **) &e.d_host, kHostCap * sizeof(EvalHostItem)));
+        HIP_TRY(hipHostMalloc((void **) &e.h_host, kHostCap * sizeof(EvalHostItem), hipHostMallocDefault));
+        e.host_cap = kHostCap;
+    }
+    if (n > e.cap) {
+        if (e.d_chan) (void) hipFree(e.d_chan);
+        if (e.h_chan) (void) hipHostFree(e.h_chan);
+        e.d_chan = nullptr; e.h_chan = nullptr; e.cap = 0;
+        const size_t cap = n + n / 4 + 256;
+        HIP_TRY(hipMalloc(&e.d_chan, cap * sizeof(ev::DChan)));
+        HIP_TRY(hipHostMalloc(&e.h_chan, cap * sizeof(ev::DChan), hipHostMallocDefault));
+        e.cap = cap;
+    }
+    if (kind == kSrcPinned && n > e.raw_cap) {
+        if (e.d_raw) (void) hipFree(e.d_raw);
+        e.d_raw = nullptr; e.raw_cap = 0;
+        HIP_TRY(hipMalloc((void **) &e.d_raw, (n + n / 4 + 16) * sizeof(gpsiq_chan_t)));
+        e.raw_cap = n + n / 4 + 16;
+    }
+    if (seeds && n > e.seeds_cap) {
+        if (e.d_seeds) (void) hipFree(e.d_seeds);
+        e.d_seeds = nullptr; e.seeds_cap = 0;
+        HIP_TRY(hipMalloc((void **) &e.d_seeds, (n + n / 4 + 16) * sizeof(double)));
+        e.seeds_cap = n + n / 4 + 16;
+    }
+    return GPSIQ_OK;
+}
+
+// Piece boundaries.  Nothing renders before the first piece is through pack, chain and evaluation (~0.15 ms of launches and
+// latencies however small it is), and its synthesis has to cover the chain kernels of what is left: a head worth ~0.35 ms of
+// synthesis, then pieces three times the one before.  GPSIQ_EVAL_HEAD (blocks; <= 0: one piece) for A/B, read per call.
+void device_piece_ends(int nblocks, int nsamp, int nchan, std::vector<int> *ends)
+{
+    const double t_block = (double) nsamp * (double) nchan / gpsiq_rate_kernel();
+    long head = (long) (0.35e-3 / (t_block > 0.0 ? t_block : 1e-6)) + 1;
+    if (head < 32) head = 32;
+    if (const char *e = std::getenv("GPSIQ_EVAL_HEAD")) head = std::atol(e);
+    if (head <= 0 || 2 * head > nblocks) { ends->push_back(nblocks); return; }
+    long b = head, size = 3 * head;
+    ends->push_back((int) b);
+    while (nblocks - b > size + size / 2 && (int) ends->size() < kEvalMaxPieces - 1) {
+        b += size;
+        ends->push_back((int) b);
+        size *= 3;
+    }
+    ends->push_back(nblocks);
+}
+
+// descriptors in pageable memory: cut down to ev::DChan on the pool, with the synthesis kernel's launch parameters on the way
+struct PackJob { const gpsiq_chan_t *ch; ev::DChan *out; const double *seeds; int nchan; double delt; uint64_t mx; int max_active; long max_amp; };
+void pack_host(PackJob *pj, int nblocks)
+{
+    parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
+        PackJob &j = *static_cast<PackJob *>(p);
+        uint64_t mx = 0;
+        int max_active = 0;
+        long max_amp = 0;
+        for (int b = b0; b < b1; ++b) {
+            int na = 0;
+            long amp = 0;
+            for (int i = 0; i < j.nchan; ++i) {
+                const size_t k = (size_t) b * j.nchan + i;
+                if (b + 1 < b1) __builtin_prefetch(reinterpret_cast<const char *>(&j.ch[k + j.nchan]));
+                ev::DChan d;
+                ev::pack_chan(j.ch[k], &d);
+                if (j.seeds) d.start = j.seeds[k];
+                j.out[k] = d;
+                const double code_inc = d.f_code * j.delt;
+                if (d.prn > 0 && d.prn <= 32 && code_inc > 0.0 && code_inc < 2.0 && d.gain > -ev::kEvMaxGain && d.gain < ev::kEvMaxGain) {
+                    const uint64_t cs = (uint64_t) (int64_t) __builtin_rint(code_inc * 0x1p56);
+                    if (cs > mx) mx = cs;
+                    amp += (long) (250.0 * std::fabs(d.gain));
+                    ++na;
+                }
+            }
+            if (na > max_active) max_active = na;
+            if (amp > max_amp) max_amp = amp;
+        }
+        for (uint64_t cur = j.mx; mx > cur && !__sync_bool_compare_and_swap(&j.mx, cur, mx); cur = j.mx) {}
+        for (int cur = j.max_active; max_active > cur && !__sync_bool_compare_and_swap(&j.max_active, cur, max_active); cur = j.max_active) {}
+        for (long cur = j.max_amp; max_amp > cur && !__sync_bool_compare_and_swap(&j.max_amp, cur, max_amp); cur = j.max_amp) {}
+    }, pj);
+}
+
+// one slot's chain on the host through the device's maps (link_slot of gpsiq_chain.cpp on the packed rows), blocks [b0, b1): every
+// start state -> start_col[b - b0]; *x / *pv: the accumulator and satellite before block b0 (b0 > 0), and after block b1 - 1 on
+// return.  in / rec: rows of these blocks (row 0 = block b0).  false: a state or Doppler outside the NCO format (*bad_block)
+bool link_slot_host(const ev::DChan *in, const lane::Rec *rec, int b0, int b1, int nchan, int i, double delt, int nsamp,
+                    double *x_io, int *pv_io, double *start_col, long *linked, long *walked, int *bad_block)
+{
+    double x = *x_io;
+    int pv = *pv_io;
+    for (int b = b0; b < b1; ++b) {
+        const size_t at = (size_t) (b - b0) * nchan + i;
+        const ev::DChan &d = in[at];
+        if (d.prn <= 0) { pv = 0; x = 0.0; start_col[b - b0] = 0.0; continue; }
+        if (b == 0 || pv != d.prn) x = d.carr_phase;
+        pv = d.prn;
+        start_col[b - b0] = x;
+        const double inc = d.f_carr * delt;
+        if (!(x >= 0.0 && x <= 1.0) || !(std::fabs(inc) < 0.5)) { *bad_block = b; return false; }
+        double y;
+        if (lane::link_block(rec[at], x, &y)) { x = y; ++*linked; }
+        else { x = chain_block_true(d.f_carr, delt, nsamp, x); ++*walked; }
+    }
+    *x_io = x; *pv_io = pv;
+    return true;
+}
+
+bool patch_before(const gpsiq_patch_t &a, const gpsiq_patch_t &b)
+{
+    if (a.block != b.block) return a.block < b.block;
+    if (a.sample != b.sample) return a.sample < b.sample;
+    return a.slot < b.slot;
+}
+
+}  // namespace
+
+namespace gpsiq { void chain_count(long linked, long walked); }
+
+static uint64_t g_evd_stats[6];       // calls, (block, channel) pairs evaluated on the device, handed to the host walker, slots repaired, patches, calls that fell back
+
+extern "C" void gpsiq_device_eval_stats(uint64_t out[6])
+{
+    if (!out) return;
+    for (int k = 0; k < 6; ++k) out[k] = __atomic_load_n(&g_evd_stats[k], __ATOMIC_RELAXED);
+}
+
+extern "C" double gpsiq_device_eval_host_ms(const gpsiq_ctx_t *c) { return c ? c->evd.host_ms : 0.0; }
+
+void gpsiq_evaldev_destroy(gpsiq_ctx *c)
+{
+    gpsiq_ctx::EvalDev &e = c->evd;
+    if (e.d_chan) (void) hipFree(e.d_chan);
+    if (e.h_chan) (void) hipHostFree(e.h_chan);
+    if (e.d_raw) (void) hipFree(e.d_raw);
+    if (e.d_seeds) (void) hipFree(e.d_seeds);
+    if (e.d_ctrl) (void) hipFree(e.d_ctrl);
+    if (e.h_ctrl) (void) hipHostFree(e.h_ctrl);
+    if (e.d_link) (void) hipFree(e.d_link);
+    if (e.h_link) (void) hipHostFree(e.h_link);
+    if (e.d_fix) (void) hipFree(e.d_fix);
+    if (e.h_fix) (void) hipHostFree(e.h_fix);
+    if (e.d_patches) (void) hipFree(e.d_patches);
+    if (e.h_patches) (void) hipHostFree(e.h_patches);
+    if (e.d_host) (void) hipFree(e.d_host);
+    if (e.h_host) (void) hipHostFree(e.h_host);
+    for (auto &ev_ : e.linked) if (ev_) (void) hipEventDestroy(ev_);
+    for (auto &ev_ : e.evaluated) if (ev_) (void) hipEventDestroy(ev_);
+    if (e.joined) (void) hipEventDestroy(e.joined);
+    if (e.eval_stream) (void) hipStreamDestroy(e.eval_stream);
+    e = gpsiq_ctx::EvalDev();
+}
+
+// Whether the device path takes a batch: long enough for its fixed costs (a dozen launches, two waits) to pay.
+// GPSIQ_EVAL=host / device decides by hand (read per call: A/B in one process).
+static bool device_path_wanted(const gpsiq_ctx *c, int nblocks)
+{
+    const char *e = std::getenv("GPSIQ_EVAL");
+    if (e && !std::strcmp(e, "host")) return false;
+    if (e && !std::strcmp(e, "device")) return nblocks >= 1;
+    return nblocks >= (c->nco_mode == GPSIQ_NCO_REFERENCE ? 48 : 64);
+}
+
+int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs, int sample_size,
+                          void *dst, int dst_is_device, double *carr_phase_out, const double *seeds, int *handled)
+{
+    *handled = 0;
+    if (!device_path_wanted(c, nblocks) || nsamp <= 0) return GPSIQ_OK;
+    const bool reference = c->nco_mode == GPSIQ_NCO_REFERENCE || seeds != nullptr;
+    const char *trace_env = std::getenv("GPSIQ_TRACE");
+    const bool trace = trace_env != nullptr;
+    const double t0 = gpsiq_wall_ms();
+    HIP_TRY(hipSetDevice(c->device));
+    gpsiq_ctx::EvalDev &e = c->evd;
+    const size_t n = (size_t) nblocks * (size_t) nchan;
+    const double delt = 1.0 / fs;
+    const void *dev_src = nullptr;
+    const SrcKind kind = classify(ch, c->device, &dev_src);
+    int rc = evd_reserve(c, n, kind, seeds != nullptr);
+    if (rc) return rc;
+    *handled = 1;
+    __atomic_fetch_add(&g_evd_stats[0], 1, __ATOMIC_RELAXED);
+    e.host_ms = 0.0; e.last_nhost = 0; e.last_npatch = 0; e.last_repaired = 0;
+
+    // the first and the last block's descriptors on the host: the continuation test of the fixed model, the phase handed out for
+    // a slot that ends unused
+    std::vector<gpsiq_chan_t> edge;
+    const gpsiq_chan_t *first = ch, *last = ch + (size_t) (nblocks - 1) * nchan;
+    if (kind == kSrcDevice) {
+        edge.resize((size_t) 2 * nchan);
+        HIP_TRY(hipMemcpy(edge.data(), ch, (size_t) nchan * sizeof(gpsiq_chan_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(edge.data() + nchan, last, (size_t) nchan * sizeof(gpsiq_chan_t), hipMemcpyDeviceToHost));
+        first = edge.data(); last = edge.data() + nchan;
+    }
+
+    // destination: straight into the caller's device memory where its rows are ours, else through the context's staging
+    const size_t blk_bytes = (size_t) 2 * (size_t) nsamp * (size_t) sample_size, stride = (blk_bytes + 15) & ~(size_t) 15;
+    const bool direct = dst_is_device && stride == blk_bytes && !((uintptr_t) dst & 3);
+    if (!direct) { rc = gpsiq_ensure_out(c, stride * (size_t) nblocks); if (rc) return rc; }
+
+    // the descriptor set the evaluation writes and the synthesis reads: one for the whole call
+    int nsets = gpsiq_ctx::kSets;
+    const int next = (c->cur + 1) % nsets;
+    gpsiq_ctx::DescBuf &nb_ = c->buf[next];
+    rc = gpsiq_wait_idle(nb_);
+    if (rc) return rc;
+    if (n > nb_.cap) {
+        if (nb_.d) HIP_TRY(hipFree(nb_.d));
+        nb_.d = nullptr; nb_.cap = 0;
+        HIP_TRY(hipMalloc((void **) &nb_.d, n * sizeof(gpsiq_qchan_t)));
+        nb_.cap = n;
+    }
+
+    std::vector<int> ends;
+    device_piece_ends(nblocks, nsamp, nchan, &ends);
+    const int npieces = (int) ends.size();
+    hipStream_t S = c->chain.stream, E = e.eval_stream;
+    ev::DChan *d_chan = static_cast<ev::DChan *>(e.d_chan), *h_chan = static_cast<ev::DChan *>(e.h_chan);
+
+    // ---- queue: control block, carries, then per piece pack (+ chain + link) and a snapshot of the control block -------------
+    EvalCtrl zero;
+    std::memset(&zero, 0, sizeof zero);
+    zero.err_key = ~0ull;
+    e.h_ctrl[kEvalMaxPieces + 1] = zero;
+    HIP_TRY(hipMemcpyAsync(e.d_ctrl, &e.h_ctrl[kEvalMaxPieces + 1], sizeof(EvalCtrl), hipMemcpyHostToDevice, S));
+    bool cont0[GPSIQ_MAX_CHAN] = {};
+    if (!reference) {
+        for (int i = 0; i < nchan; ++i) {
+            cont0[i] = first[i].prn > 0 && c->carry_prn[i] == first[i].prn && c->handed[i] == first[i].carr_phase;
+            e.h_fix[i].phase = c->carry[i]; e.h_fix[i].prn = c->carry_prn[i]; e.h_fix[i].cont = cont0[i] ? 1 : 0;
+        }
+        HIP_TRY(hipMemcpyAsync(e.d_fix, e.h_fix, (size_t) nchan * sizeof(FixedCarry), hipMemcpyHostToDevice, S));
+    }
+    if (seeds) HIP_TRY(hipMemcpyAsync(e.d_seeds, seeds, n * sizeof(double), hipMemcpyHostToDevice, S));
+    PackJob pj = {ch, h_chan, nullptr, nchan, delt, 0, 0, 0};
+    uint64_t host_mx[kEvalMaxPieces] = {};
+    int host_active[kEvalMaxPieces] = {};
+    long host_amp[kEvalMaxPieces] = {};
+    hipError_t he = hipSuccess;
+    for (int k = 0; k < npieces && he == hipSuccess; ++k) {
+        const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+        const size_t off = (size_t) b0 * nchan, cnt = (size_t) nb * nchan;
+        if (kind == kSrcDevice) he = launch_pack_raw(static_cast<const gpsiq_chan_t *>(dev_src) + off, nb, nchan, delt, d_chan + off, e.d_ctrl, S);
+        else if (kind == kSrcPinned) {
+            he = hipMemcpyAsync(e.d_raw + off, ch + off, cnt * sizeof(gpsiq_chan_t), hipMemcpyHostToDevice, S);
+            if (he == hipSuccess) he = launch_pack_raw(e.d_raw + off, nb, nchan, delt, d_chan + off, e.d_ctrl, S);
+        } else {
+            const double tp = gpsiq_wall_ms();
+            PackJob part = pj;
+            part.ch = ch + off; part.out = h_chan + off;
+            pack_host(&part, nb);
+            pj.mx = part.mx > pj.mx ? part.mx : pj.mx; pj.max_active = part.max_active > pj.max_active ? part.max_active : pj.max_active;
+            pj.max_amp = part.max_amp > pj.max_amp ? part.max_amp : pj.max_amp;
+            e.host_ms += gpsiq_wall_ms() - tp;
+            he = hipMemcpyAsync(d_chan + off, h_chan + off, cnt * sizeof(ev::DChan), hipMemcpyHostToDevice, S);
+        }
+        host_mx[k] = pj.mx; host_active[k] = pj.max_active; host_amp[k] = pj.max_amp;
+        if (he == hipSuccess && reference && !seeds) {
+            int max_seg = 32;
+            if (const char *s = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(s); if (v >= 1 && v <= 32) max_seg = v; }
+            he = launch_chain(d_chan + off, (int) sizeof(ev::DChan), nb, nchan, delt, nsamp, k ? c->chain.d_est + (size_t) k * GPSIQ_MAX_CHAN : nullptr, max_seg,
+                              static_cast<char *>(c->chain.d_prep) + off * 32, c->chain.d_c_before + (size_t) k * GPSIQ_MAX_CHAN,
+                              c->chain.d_est + (size_t) (k + 1) * GPSIQ_MAX_CHAN, c->chain.d_maps + off, S);
+            if (he == hipSuccess) he = launch_link_scan(d_chan, c->chain.d_maps, b0, nb, nchan, delt, e.d_link, e.d_ctrl, k, S);
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(&e.h_ctrl[k], e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, S);
+        if (he == hipSuccess) he = hipEventRecord(e.linked[k], S);
+    }
+    char err[400] = "";
+    if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, queueing: %s", hipGetErrorString(he)); }
+    const double t_queued = gpsiq_wall_ms();
+
+    // ---- per piece: wait for its link, repair, evaluate, render ---------------------------------------------------------------
+    bool host_owned[GPSIQ_MAX_CHAN] = {};
+    double host_end[GPSIQ_MAX_CHAN] = {};
+    int host_last_prn[GPSIQ_MAX_CHAN] = {};
+    int max_active = 0;
+    long max_amp = 0;
+    uint64_t max_step = 0;
+    int copies = 0;
+    double t_first_launch = 0.0;
+    for (int k = 0; k < npieces && rc == GPSIQ_OK; ++k) {
+        const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+        he = hipEventSynchronize(e.linked[k]);
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d: %s", k, hipGetErrorString(he)); break; }
+        const EvalCtrl &ck = e.h_ctrl[k];
+        if (reference && !seeds) {
+            bool need = false;
+            for (int i = 0; i < nchan; ++i) need = need || ck.unknown[k][i] > 0 || host_owned[i];
+            if (need) {
+                // A block whose certified map does not apply (a slow block, a sign change, a range the estimate missed): the host
+                // walker takes that slot from this piece on -- the piece's maps and rows come back, the slot is linked / walked from
+                // the state it enters the piece with (lane::link_block + the true walk, as rounds 4-5 did for every slot), and its
+                // start states go back up before the piece is evaluated.  The device's own scan goes on for the other slots.
+                const double tr = gpsiq_wall_ms();
+                const size_t off = (size_t) b0 * nchan, cnt = (size_t) nb * nchan;
+                const size_t lead = b0 > 0 ? (size_t) nchan : 0;                   // the row before the piece too: which satellite each slot had
+                he = hipMemcpyAsync(c->chain.h_maps + off, c->chain.d_maps + off, cnt * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, E);
+                if (he == hipSuccess) he = hipMemcpyAsync(h_chan + off - lead, d_chan + off - lead, (cnt + lead) * sizeof(ev::DChan), hipMemcpyDeviceToHost, E);   // (with the starts the scan wrote)
+                if (he == hipSuccess) he = hipStreamSynchronize(E);
+                if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, repair: %s", hipGetErrorString(he)); break; }
+                std::vector<double> col((size_t) nb);
+                for (int i = 0; i < nchan && rc == GPSIQ_OK; ++i) {
+                    if (!(ck.unknown[k][i] > 0 || host_owned[i])) continue;
+                    if (!host_owned[i]) {
+                        // the state the slot enters the piece with: the scan knew every start up to its first block that does not link
+                        host_last_prn[i] = b0 > 0 && h_chan[off - nchan + i].prn > 0 ? h_chan[off - nchan + i].prn : 0;      
+                        host_end[i] = h_chan[off + i].start;
+                    }
+                    long linked = 0, walked = 0;
+                    int bad = -1;
+                    if (!link_slot_host(h_chan + off, reinterpret_cast<const lane::Rec *>(c->chain.h_maps) + off, b0, b0 + nb, nchan, i, delt, nsamp,
+                                        &host_end[i], &host_last_prn[i], col.data(), &linked, &walked, &bad)) {
+                        rc = GPSIQ_E_RANGE; std::snprintf(err, sizeof err, "block %d: carrier phase or Doppler outside the NCO format", bad);
+                        break;
+                    }
+                    chain_count(linked, walked);
+                    he = hipMemcpy2DAsync(&d_chan[off + i].start, sizeof(ev::DChan) * (size_t) nchan, col.data(), sizeof(double), sizeof(double), (size_t) nb, hipMemcpyHostToDevice, E);
+                    if (he == hipSuccess) he = hipStreamSynchronize(E);                   // (col is reused for the next slot)
+                    if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, repair upload: %s", hipGetErrorString(he)); break; }
+                    if (!host_owned[i]) { host_owned[i] = true; ++e.last_repaired; }
+                }
+                e.host_ms += gpsiq_wall_ms() - tr;
+                if (rc != GPSIQ_OK) break;
+            }
+        }
+        // launch parameters: everything packed up to and including this piece
+        max_step = std::max<uint64_t>(max_step, std::max<uint64_t>(ck.max_code_step, host_mx[k]));
+        max_active = std::max(max_active, std::max(ck.max_active, host_active[k]));
+        max_amp = std::max(max_amp, std::max<long>((long) ck.max_amp, host_amp[k]));
+        he = hipStreamWaitEvent(E, e.linked[k], 0);
+        if (he == hipSuccess) {
+            if (reference) he = launch_eval(d_chan, b0, nb, nchan, delt, nsamp, c->d_tab, nb_.d, e.d_patches, e.patch_cap, e.d_host, e.host_cap, e.d_ctrl,
+                                            seeds ? e.d_seeds : nullptr, E);
+            else he = launch_quantize_fixed(d_chan, b0, nb, nchan, delt, nsamp, nb_.d, e.d_fix, e.d_ctrl, E);
+        }
+        if (he == hipSuccess) he = hipEventRecord(e.evaluated[k], E);
+        hipStream_t s = gpsiq_piece_stream(c, k);
+        if (he == hipSuccess) he = hipStreamWaitEvent(s, e.evaluated[k], 0);
+        if (he == hipSuccess) {
+            const int v = max_step <= kRowsMaxCodeStep ? kSeg : max_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
+            uint8_t *dev = direct ? static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes : static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
+            he = launch_variant(v, nb_.d, nchan, nsamp, sample_size, dev, stride, b0, nb, c->d_tab, s, max_active > 0 ? max_active : 1, max_amp, nullptr);
+            if (trace && k == 0) t_first_launch = gpsiq_wall_ms() - t0;
+            if (he == hipSuccess && !direct && !reference) {
+                // (reference mode copies out after the patches; the fixed model's pieces are final as rendered)
+                hipStream_t cs = c->copy_stream[copies & 1];
+                he = hipEventRecord(c->chunk_done[copies & 1], s);
+                if (he == hipSuccess) he = hipStreamWaitEvent(cs, c->chunk_done[copies & 1], 0);
+                const hipMemcpyKind kd = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+                if (he == hipSuccess) {
+                    if (stride == blk_bytes) he = hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, dev, blk_bytes * (size_t) nb, kd, cs);
+                    else he = hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, dev, stride, blk_bytes, (size_t) nb, kd, cs);
+                }
+                ++copies;
+            }
+        }
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d launch: %s", k, hipGetErrorString(he)); }
+    }
+
+    // ---- the end of the evaluation: errors, the host walker's share, the patches -----------------------------------------------
+    EvalCtrl &fin = e.h_ctrl[kEvalMaxPieces];
+    fin = zero;
+    size_t npatch_total = 0;
+    bool fall_back = false;
+    if (rc == GPSIQ_OK) {
+        he = hipMemcpyAsync(&fin, e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, E);
+        if (he == hipSuccess && reference) {
+            // the first entries of both lists ride along (nearly always all there are)
+            he = hipMemcpyAsync(e.h_patches, e.d_patches, 1024 * sizeof(gpsiq_patch_t), hipMemcpyDeviceToHost, E);
+            if (he == hipSuccess) he = hipMemcpyAsync(e.h_host, e.d_host, 256 * sizeof(EvalHostItem), hipMemcpyDeviceToHost, E);
+            if (he == hipSuccess && !seeds) he = hipMemcpyAsync(e.h_link, e.d_link, (size_t) nchan * sizeof(LinkCarry), hipMemcpyDeviceToHost, E);
+        }
+        if (he == hipSuccess && !reference) he = hipMemcpyAsync(e.h_fix, e.d_fix, (size_t) nchan * sizeof(FixedCarry), hipMemcpyDeviceToHost, E);
+        if (he == hipSuccess) he = hipStreamSynchronize(E);
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, results: %s", hipGetErrorString(he)); }
+    }
+    if (rc == GPSIQ_OK && fin.err_key != ~0ull) {
+        // the descriptor the device quantiser refused, in the host quantiser's words
+        const size_t flat = (size_t) (fin.err_key >> 8);
+        const int status = (int) (fin.err_key & 0xff);
+        gpsiq_chan_t bad;
+        if (kind == kSrcDevice) (void) hipMemcpy(&bad, ch + flat, sizeof bad, hipMemcpyDeviceToHost);
+        else bad = ch[flat];
+        gpsiq_qchan_t tmp;
+        if (status == ev::kQStart) {
+            rc = GPSIQ_E_RANGE;
+            std::snprintf(err, sizeof err, "block %d: prn %d: start phase outside [0, 1]", (int) (flat / nchan), bad.prn);
+        } else {
+            if (reference && !(bad.carr_phase >= 0.0 && bad.carr_phase < 1.0)) bad.carr_phase = 0.0;       // (not the evaluation's business: eval_block)
+            const int qrc = quantize_one(bad, delt, nsamp, nullptr, &tmp, nullptr);
+            rc = qrc != GPSIQ_OK ? qrc : ev::qstatus_code(status);
+            if (qrc != GPSIQ_OK) std::snprintf(err, sizeof err, "block %d: %.280s", (int) (flat / nchan), gpsiq_last_error());
+            else std::snprintf(err, sizeof err, "block %d: descriptor refused by the device quantiser (status %d)", (int) (flat / nchan), status);
+        }
+    }
+    std::vector<gpsiq_patch_t> patches;
+    if (rc == GPSIQ_OK && reference) {
+        if (fin.npatch > e.patch_cap || fin.nhost > e.host_cap) fall_back = true;       // more than the lists hold (a rate far outside the design range)
+        else {
+            if (fin.npatch > 1024) he = hipMemcpy(e.h_patches + 1024, e.d_patches + 1024, (size_t) (fin.npatch - 1024) * sizeof(gpsiq_patch_t), hipMemcpyDeviceToHost);
+            if (he == hipSuccess && fin.nhost > 256) he = hipMemcpy(e.h_host + 256, e.d_host + 256, (size_t) (fin.nhost - 256) * sizeof(EvalHostItem), hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, lists: %s", hipGetErrorString(he)); }
+        }
+        if (rc == GPSIQ_OK && !fall_back) {
+            const double th = gpsiq_wall_ms();
+            patches.assign(e.h_patches, e.h_patches + fin.npatch);
+            if (fin.nhost) {
+                // what the device left to the host walker: those channels' patches from eval_block, in place of whatever the device
+                // had emitted for them before it gave up
+                std::vector<uint64_t> keys;
+                for (unsigned k = 0; k < fin.nhost; ++k) keys.push_back((uint64_t) e.h_host[k].block << 8 | e.h_host[k].slot);
+                std::sort(keys.begin(), keys.end());
+                patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const gpsiq_patch_t &p) {
+                    return std::binary_search(keys.begin(), keys.end(), (uint64_t) p.block << 8 | p.slot); }), patches.end());
+                for (unsigned k = 0; k < fin.nhost && rc == GPSIQ_OK; ++k) {
+                    const EvalHostItem &h = e.h_host[k];
+                    gpsiq_chan_t one;
+                    const size_t flat = (size_t) h.block * nchan + h.chan;
+                    if (kind == kSrcDevice) (void) hipMemcpy(&one, ch + flat, sizeof one, hipMemcpyDeviceToHost);
+                    else one = ch[flat];
+                    gpsiq_qchan_t q;
+                    const int erc = eval_block_host(one, h.start, delt, nsamp, (int) h.block, (int) h.slot, &q, &patches);
+                    if (erc != GPSIQ_OK) { rc = erc; std::snprintf(err, sizeof err, "block %u: %.280s", h.block, gpsiq_last_error()); }
+                }
+            }
+            std::sort(patches.begin(), patches.end(), patch_before);
+            npatch_total = patches.size();
+            e.host_ms += gpsiq_wall_ms() - th;
+        }
+    }
+    // the patches go behind the synthesis of every piece: join the two piece streams on the first
+    if (rc == GPSIQ_OK && reference && !fall_back) {
+        he = hipSuccess;
+        if (npieces > 1) { he = hipEventRecord(e.joined, c->stream2); if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, e.joined, 0); }
+        if (he == hipSuccess && npatch_total) {
+            if (npatch_total > nb_.patch_cap) {
+                if (nb_.d_patch) (void) hipFree(nb_.d_patch);
+                nb_.d_patch = nullptr; nb_.patch_cap = 0;
+                const size_t cap = npatch_total < 256 ? 256 : npatch_total;
+                he = hipMalloc((void **) &nb_.d_patch, cap * sizeof(gpsiq_patch_t));
+                if (he == hipSuccess) nb_.patch_cap = cap;
+            }
+            if (he == hipSuccess) {
+                std::memcpy(e.h_patches, patches.data(), npatch_total * sizeof(gpsiq_patch_t));
+                he = hipMemcpyAsync(nb_.d_patch, e.h_patches, npatch_total * sizeof(gpsiq_patch_t), hipMemcpyHostToDevice, c->stream);
+            }
+            uint8_t *dev = direct ? static_cast<uint8_t *>(dst) : static_cast<uint8_t *>(c->d_out);
+            if (he == hipSuccess) he = launch_patches(nb_.d, nchan, nsamp, sample_size, dev, stride, 0, nblocks, c->d_tab, nb_.d_patch, (int) npatch_total, c->stream);
+        }
+        if (he == hipSuccess && !direct) {
+            const hipMemcpyKind kd = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+            if (stride == blk_bytes) he = hipMemcpyAsync(dst, c->d_out, blk_bytes * (size_t) nblocks, kd, c->stream);
+            else he = hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks, kd, c->stream);
+        }
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, patches: %s", hipGetErrorString(he)); }
+    }
+
+    // ---- drain: on every path nothing may still be writing the caller's buffer or reading our staging -------------------------
+    const double t_drain = gpsiq_wall_ms();
+    const hipError_t d0 = hipStreamSynchronize(S), d1 = hipStreamSynchronize(E), d2 = hipStreamSynchronize(c->stream), d3 = hipStreamSynchronize(c->stream2);
+    const hipError_t d4 = hipStreamSynchronize(c->copy_stream[0]), d5 = hipStreamSynchronize(c->copy_stream[1]);
+    if (rc == GPSIQ_OK)
+        for (hipError_t d : {d0, d1, d2, d3, d4, d5})
+            if (d != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation: %s", hipGetErrorString(d)); break; }
+    if (rc != GPSIQ_OK) return fail(rc, "%s", err);
+    if (fall_back) {
+        // the lists overflowed: the host path does the whole call again (dst is rewritten)
+        __atomic_fetch_add(&g_evd_stats[5], 1, __ATOMIC_RELAXED);
+        return gpsiq_generate_reference_host(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out, seeds);
+    }
+
+    // ---- the resident set and the carried state ------------------------------------------------------------------------------
+    c->cur = next;
+    c->d_desc = nb_.d;
+    c->nblocks = nblocks; c->nchan = nchan; c->max_code_step = max_step; c->max_active = max_active > 0 ? max_active : 1; c->max_amplitude = max_amp;
+    nb_.npatch = (int) npatch_total;
+    nb_.active_per_block.assign((size_t) nblocks, (uint8_t) nchan);
+    nb_.upload_pending = false;
+    if (reference) {
+        if (carr_phase_out && !seeds)
+            for (int i = 0; i < nchan; ++i) {
+                if (host_owned[i]) carr_phase_out[i] = host_last_prn[i] ? host_end[i] : last[i].carr_phase;
+                else carr_phase_out[i] = e.h_link[i].prn > 0 ? e.h_link[i].y : last[i].carr_phase;
+            }
+        chain_count((long) fin.linked, 0);
+    } else {
+        for (int i = 0; i < nchan; ++i) {
+            c->carry_prn[i] = e.h_fix[i].prn;
+            c->carry[i] = e.h_fix[i].prn ? e.h_fix[i].phase : 0;
+            c->handed[i] = e.h_fix[i].prn ? carr_phase_to_double(c->carry[i]) : 0.0;
+            if (carr_phase_out) carr_phase_out[i] = c->handed[i];
+        }
+    }
+    e.last_nhost = fin.nhost; e.last_npatch = (unsigned) npatch_total;
+    __atomic_fetch_add(&g_evd_stats[1], (uint64_t) n, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_evd_stats[2], (uint64_t) fin.nhost, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_evd_stats[3], (uint64_t) e.last_repaired, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_evd_stats[4], (uint64_t) npatch_total, __ATOMIC_RELAXED);
+    if (trace)
+        std::fprintf(stderr, "[gpsiq trace] device evaluation (%s, descriptors %s), %d blocks in %d pieces (head %d): queued by %.3f ms, first synthesis launched at %.3f ms, "
+                             "draining from %.3f ms, whole call %.3f ms; host stages %.3f ms; %u patches, %u channels to the host walker, %u slots repaired\n",
+                     reference ? "reference NCO" : "fixed-point NCO", kind == kSrcDevice ? "in device memory" : kind == kSrcPinned ? "page-locked" : "pageable (packed by the pool)",
+                     nblocks, npieces, ends[0], t_queued - t0, t_first_launch, t_drain - t0, gpsiq_wall_ms() - t0, e.host_ms, (unsigned) npatch_total, fin.nhost, e.last_repaired);
+    return GPSIQ_OK;
+}

@@ -1001,6 +1001,14 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
 
 double chain_block_true(double f_carr, double delt, int nsamp, double start) { return chain_block(f_carr, delt, nsamp, start); }
 
+// one channel of one block for the device path (gpsiq_evaldev.cpp): the (block, channel) pairs its enclosure cannot decide
+int eval_block_host(const gpsiq_chan_t &ch, double start, double delt, int nsamp, int block, int slot, gpsiq_qchan_t *q,
+                    std::vector<gpsiq_patch_t> *out)
+{
+    CodeCache codes;
+    return eval_block(ch, start, delt, nsamp, block, slot, &codes, q, out);
+}
+
 // ---- the host side of GPSIQ_NCO_REFERENCE as tasks ---------------------------------------------------------------
 // Only the carrier chain is serial: block b of a channel starts where the double accumulator left block b-1 (gps.c:2821
 // carries chan[i].carr_phase; allocateChannel re-initialises it when the slot gets another satellite, gps.c:2208-2214).

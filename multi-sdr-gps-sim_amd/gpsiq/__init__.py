@@ -120,6 +120,8 @@ _nav_message = _sig("gpsiq_nav_message", _i, _vp, _i, _d, _i, _vp)
 _nav_roll = _sig("gpsiq_nav_roll", _i, _vp, _i, _i, _d, _vp)
 _rinex_read = _sig("gpsiq_rinex_read", _i, C.c_char_p, _i, _vp, _vp)
 _rinex_select = _sig("gpsiq_rinex_select", _i, _vp, _i, _i, _d)
+_device_eval_stats = _sig("gpsiq_device_eval_stats", None, _vp)
+_device_eval_host_ms = _sig("gpsiq_device_eval_host_ms", _d, _vp)
 _num_variants = _sig("gpsiq_num_variants", _i)
 _variant_name = _sig("gpsiq_variant_name", C.c_char_p, _i)
 
@@ -314,6 +316,14 @@ def reference_stats():
     """gpsiq_reference_stats: (states needed, decided from the start state, carrier walks, code walks) since the process started."""
     out = np.zeros(4, dtype=np.uint64)
     _reference_stats(_p(out))
+    return tuple(int(v) for v in out)
+
+
+def device_eval_stats():
+    """Since the process started: batch calls taken by the device evaluation, (block, channel) pairs it evaluated, pairs handed
+    to the host walker, slots whose chain the host repaired, patches, calls that fell back to the host path."""
+    out = np.zeros(6, dtype=np.uint64)
+    _device_eval_stats(_p(out))
     return tuple(int(v) for v in out)
 
 
@@ -594,19 +604,29 @@ class Context:
 
     def generate_batch(self, desc, nsamp, fs, sample_size, device_ptr=None, host_ptr=None, carr_out=None):
         """carr_out: optional float64[nchan] array that receives the carrier phase after the
-        last block (hand it back as block 0's carr_phase of the next batch to continue exactly)."""
-        desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
-        nb, nc = desc.shape
+        last block (hand it back as block 0's carr_phase of the next batch to continue exactly).
+        desc: a CHAN_DTYPE array [nblocks][nchan] (pageable or page-locked: a view is passed as it is), or a tuple
+        (pointer, nblocks, nchan) for gpsiq_chan_t rows that lie in device or page-locked memory."""
+        if isinstance(desc, tuple):
+            dp, nb, nc = _vp(desc[0]), int(desc[1]), int(desc[2])
+        else:
+            desc = np.ascontiguousarray(desc, dtype=CHAN_DTYPE)
+            nb, nc = desc.shape
+            dp = _p(desc)
         co = None if carr_out is None else _p(carr_out)
         if host_ptr is not None:      # caller-owned host buffer (e.g. pinned), nb*2*nsamp elements
-            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(host_ptr), 0, co))
+            _check(_generate_batch(self._h, dp, nb, nc, int(nsamp), float(fs), int(sample_size), _vp(host_ptr), 0, co))
             return None
         if device_ptr is not None:
-            _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _vp(device_ptr), 1, co))
+            _check(_generate_batch(self._h, dp, nb, nc, int(nsamp), float(fs), int(sample_size), _vp(device_ptr), 1, co))
             return None
         out = np.zeros((nb, 2 * nsamp), dtype=elem_dtype(sample_size))
-        _check(_generate_batch(self._h, _p(desc), nb, nc, int(nsamp), float(fs), int(sample_size), _p(out), 0, co))
+        _check(_generate_batch(self._h, dp, nb, nc, int(nsamp), float(fs), int(sample_size), _p(out), 0, co))
         return out
+
+    def device_eval_host_ms(self):
+        """Host time the last device-evaluated batch spent on descriptors (pack of pageable rows, repair, the host walker's share)."""
+        return float(_device_eval_host_ms(self._h))
 
     def generate_quantized(self, q, nsamp, sample_size, device_ptr=None, host_ptr=None):
         """One shard of a time-sharded run: a slice of quantize_blocks()' output -> IQ elements."""

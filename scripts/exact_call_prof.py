@@ -1,0 +1,38 @@
+"""One GPSIQ_NCO_REFERENCE gpsiq_generate_batch call after another into device memory, for rocprofv3 passes (kernel trace; PMC):
+2.6 Msps int8 16 ch, 2 000 and 4 130 blocks, descriptors in pageable memory (the device evaluation packs them on the pool).
+No torch (a profiled interpreter with torch loaded has been seen to hang in teardown: run it under `timeout`); the output ring
+comes from hipMalloc through ctypes.
+   python scripts/exact_call_prof.py [calls per size]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multi-sdr-gps-sim_amd"))
+import gpsiq  # noqa: E402
+from gpsiq.abi import NCO_REFERENCE  # noqa: E402
+from gpsiq.scenario import synth_blocks  # noqa: E402
+
+calls = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+ctx = gpsiq.Context(0)
+hip = C.CDLL("libamdhip64.so")            # the runtime the binding has loaded
+ring = C.c_void_p()
+assert hip.hipMalloc(C.byref(ring), C.c_size_t(2 << 30)) == 0
+pat = synth_blocks(64, 16)
+ctx.set_nco_mode(NCO_REFERENCE)
+for nb in (2000, 4129):
+    fs, ss = 2.6e6, 1
+    ns = 260000
+    d = pat[np.arange(nb) % 64]
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        ctx.generate_batch(d, ns, fs, ss, device_ptr=ring.value)
+        ts.append(time.perf_counter() - t0)
+    print(f"2.6 Msps int8, {nb} blocks: calls of {', '.join(f'{t * 1e3:.3f}' for t in ts)} ms", flush=True)
+print("device evaluation statistics:", gpsiq.device_eval_stats(), flush=True)
+sys.stdout.flush()
+ctx.close()

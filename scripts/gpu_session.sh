@@ -1,4 +1,4 @@
-# One GPU-box session:   gpurun -- 'bash scripts/gpu_session.sh STEP [STEP ...]'      (TAG=r05 by default)
+# One GPU-box session:   gpurun -- 'bash scripts/gpu_session.sh STEP [STEP ...]'      (TAG=r06 by default)
 # Every step writes under gpurun_out/<TAG>_*; profiles are summarised into profiles/<TAG>_* by scripts/prof_summary.py.
 #   tests    pytest -m gpu, the whole suite                      refnco   the reference-NCO GPU tests only
 #   chain    device carrier chain: its tests, scripts/chain_timing.py   chainab  scripts/chain_ab.py (knobs + piece timelines)
@@ -8,7 +8,9 @@
 #   2rank    bench.py --gpus 2 over gloo on the box's one GPU (the N > 1 code path; GPSIQ_BENCH_SHARE_GPU=1)
 #   prof     rocprofv3 passes of the default bench (scripts/gpu_prof.sh)        profcfg  the same for configs 3 and 5
 #   rates    throughput over the BASELINE / front-end sample rates
-TAG=${TAG:-r05}
+#   exactprof rocprofv3 kernel trace + HBM traffic of the GPSIQ_NCO_REFERENCE batch call (scripts/exact_call_prof.py)
+#   eval     the device evaluation: tests/test_gpu_device_eval.py, scripts/eval_timing.py (all threads, then GPSIQ_THREADS=2)
+TAG=${TAG:-r06}
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 for step in "$@"; do
@@ -22,6 +24,19 @@ for step in "$@"; do
       ( cd /tmp && export TMPDIR=/tmp && O=$GRAFT_REPO_ROOT/gpurun_out/chain_pmc && mkdir -p $O &&
         timeout 150 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
           -d $O/a -o pmc -- python $GRAFT_REPO_ROOT/scripts/chain_pmc.py > $O/a.log 2>&1; grep Msps $O/a.log ) ;;
+    eval)
+      ( timeout 1500 python -m pytest tests/test_gpu_device_eval.py -m gpu -x -q 2>&1 | tail -40 ) > gpurun_out/${TAG}_eval_tests.log 2>&1; tail -25 gpurun_out/${TAG}_eval_tests.log
+      ( timeout 600 python scripts/eval_timing.py ) > gpurun_out/${TAG}_eval_timing.log 2>&1; grep -v "trace\] descriptors" gpurun_out/${TAG}_eval_timing.log
+      ( timeout 600 python scripts/eval_timing.py 2 ) > gpurun_out/${TAG}_eval_timing_2threads.log 2>&1; grep -v "trace\] " gpurun_out/${TAG}_eval_timing_2threads.log ;;
+    exactprof)
+      ( cd /tmp && export TMPDIR=/tmp && O=$GRAFT_REPO_ROOT/gpurun_out/exact_prof && rm -rf $O && mkdir -p $O &&
+        echo '{"calls": 6, "blocks": [2000, 4129], "nsamp": 260000, "ss": 1}' > $O/meta.json &&
+        timeout 200 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $GRAFT_REPO_ROOT/scripts/exact_call_prof.py 6 > $O/kt.log 2>&1; tail -3 $O/kt.log
+        timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o pmc -- python $GRAFT_REPO_ROOT/scripts/exact_call_prof.py 6 > $O/pmc_write.log 2>&1
+        timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/scripts/exact_call_prof.py 6 > $O/pmc_fetch.log 2>&1
+        cd $GRAFT_REPO_ROOT && python scripts/exact_call_summary.py gpurun_out/exact_prof $TAG > $O/summary.log 2>&1; tail -60 $O/summary.log
+        find $O -name "*.db" -size +8M -delete
+        mkdir -p gpurun_out/profiles_out; cp profiles/${TAG}_exact_call_* profiles/pmc_traffic.json gpurun_out/profiles_out/ ) ;;
     refnco)
       ( timeout 1500 python -m pytest tests/test_gpu_reference_nco.py tests/test_config5_shares.py -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${TAG}_refnco_tests.log 2>&1; tail -4 gpurun_out/${TAG}_refnco_tests.log ;;
     soak)

@@ -12,11 +12,13 @@ os.makedirs("profiles", exist_ok=True)
 
 def kernels_id():
     """What libgpsiq's gpsiq_kernels_id() returns for a library built from the tree these profiles were taken in: the
-    first 16 hex digits of the SHA-256 of csrc/gpsiq_kernels.hip (csrc/Makefile).  Stored next to every replayed counter so
-    that bench.py can tell a profile of another kernel from one of the library it has loaded."""
+    first 16 hex digits of the SHA-256 over the device sources (DEVSRC of csrc/Makefile, in that order).  Stored next to every
+    replayed counter so that bench.py can tell a profile of another kernel from one of the library it has loaded."""
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return hashlib.sha256(open(os.path.join(root, "multi-sdr-gps-sim_amd", "csrc", "gpsiq_kernels.hip"), "rb").read()).hexdigest()[:16]
+    csrc = os.path.join(root, "multi-sdr-gps-sim_amd", "csrc")
+    devsrc = [l for l in open(os.path.join(csrc, "Makefile")) if l.startswith("DEVSRC")][0].split(":=")[1].split()
+    return hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in devsrc)).hexdigest()[:16]
 
 
 def q(db, sql):

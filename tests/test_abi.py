@@ -103,13 +103,16 @@ def test_product_does_not_import_the_oracle():
 def test_replayed_counters_are_bound_to_the_loaded_kernel(tmp_path, monkeypatch):
     """bench.py's `counters` / `roofline.traffic` are rocprofv3 counts committed under profiles/, divided by the live
     launch time: they may only be replayed next to the library they were taken from.  gpsiq_kernels_id() is the SHA-256
-    of the kernel source the loaded library was built from; scripts/prof_summary.py stores the same id with every
+    of the device sources (every .hip file and the headers the kernels share with the host) the loaded library was built from; scripts/prof_summary.py stores the same id with every
     profile; a profile of any other kernel is reported as {"stale_profile": true} and its counts are withheld."""
     import hashlib
     import json
     import sys
-    src = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc", "gpsiq_kernels.hip")
-    assert gpsiq.kernels_id() == hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "libgpsiq.so is older than gpsiq_kernels.hip: rebuild"
+    csrc = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc")
+    devsrc = [l for l in open(os.path.join(csrc, "Makefile")) if l.startswith("DEVSRC")][0].split(":=")[1].split()     # every device source
+    assert "gpsiq_kernels.hip" in devsrc and "gpsiq_chain_kernels.hip" in devsrc and "gpsiq_eval_kernels.hip" in devsrc and "gpsiq_lane.h" in devsrc
+    blob = b"".join(open(os.path.join(csrc, f), "rb").read() for f in devsrc)
+    assert gpsiq.kernels_id() == hashlib.sha256(blob).hexdigest()[:16], "libgpsiq.so is older than its device sources: rebuild"
     sys.path.insert(0, ROOT)
     import bench
     prof = tmp_path / "profiles"
