@@ -813,9 +813,9 @@ def extra_legs(ctx, ring, stream, args, first):
     pinned = torch.empty(nb_h * blk, dtype=torch.uint8).pin_memory()
     for label, chunk in (("host_dst_batch", None), ("host_dst_batch_unchunked", "0")):
         if chunk is None:
-            os.environ.pop("GPSIQ_D2H_CHUNK_BLOCKS", None)
+            os.environ.pop("GPSIQ_PIECE_BLOCKS", None)
         else:
-            os.environ["GPSIQ_D2H_CHUNK_BLOCKS"] = chunk
+            os.environ["GPSIQ_PIECE_BLOCKS"] = chunk
         ctx.generate_batch(d_h, nsamp, fs, ss, host_ptr=pinned.data_ptr())
         dt = float("inf")
         for _ in range(3):
@@ -825,7 +825,7 @@ def extra_legs(ctx, ring, stream, args, first):
         ex[label] = {"what": f"gpsiq_generate_batch -> page-locked host memory, {nb_h} blocks ({'kernel of piece k+1 overlaps the copy of piece k' if chunk is None else 'one kernel, then one copy'})",
                      "value": round(nb_h * nsamp / dt / 1e6, 1), "unit": "Msamples/s", "pcie_GBps": round(nb_h * blk / dt / 1e9, 2),
                      "x_realtime": round(nb_h * 0.1 / dt, 1)}
-    os.environ.pop("GPSIQ_D2H_CHUNK_BLOCKS", None)
+    os.environ.pop("GPSIQ_PIECE_BLOCKS", None)
     # what "PCIe-bound" means on this box: the same bytes as ONE plain device-to-host copy into the same page-locked buffer
     nbytes_h = nb_h * blk
     raw = float("inf")

@@ -81,6 +81,8 @@ extern "C" {
 #define GPSIQ_E_DEVICE      -3   /* HIP runtime error, see gpsiq_last_error() */
 #define GPSIQ_E_NOMEM       -4
 #define GPSIQ_E_STATE       -5   /* call order (e.g. launch before descriptors are resident) */
+#define GPSIQ_E_VERIFY      -6   /* GPSIQ_CHAIN_VERIFY: a block linked through its certified map ended on another state than the serial walk
+                                    (gps.c:2821-2826) from the same start: the output of this call is not to be trusted; block and slot in gpsiq_last_error() */
 
 /* Per-channel block descriptor: exactly the channel_t fields (gps.h:213-236) plus
  * gain[i] (gps.c:2300, 2756-2763) that the sample loop reads, with the state the
@@ -266,7 +268,7 @@ int gpsiq_chain_summary(const gpsiq_chain_in_t *in, int nblocks, int nchan, doub
 int gpsiq_chain_fold(const gpsiq_chain_est_t *sums /* [nranges][nchan] */, int nranges, int nchan, gpsiq_chain_est_t *out);
 /* out[0] blocks linked through their map, out[1] blocks walked from their true start, since the process started */
 void gpsiq_chain_stats(uint64_t out[2]);
-/* gpsiq_chain_maps on the context's device: one lane per stretch of a block (max_stretches <= 0: 16), `in` and `maps` host
+/* gpsiq_chain_maps on the context's device: one lane per stretch of a block (max_stretches <= 0: 32, or GPSIQ_CHAIN_STRETCHES), `in` and `maps` host
  * memory; kernel_ms (may be NULL): device time of the two kernels.  Synchronous.  In GPSIQ_NCO_REFERENCE gpsiq_generate_batch
  * walks the chain of a batch this way itself (48 blocks or more; GPSIQ_CHAIN=host keeps the serial walk on host threads). */
 int gpsiq_chain_maps_device(gpsiq_ctx_t *ctx, const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,

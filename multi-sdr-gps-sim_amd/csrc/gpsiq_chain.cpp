@@ -9,6 +9,7 @@
 #include "gpsiq_lane.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace gpsiq {
@@ -82,6 +83,9 @@ bool chain_scan_slot(const gpsiq_chain_in_t *in, int nblocks, int nchan, int i, 
     return reseeded;
 }
 
+#ifdef GPSIQ_JOIN_CHECK
+std::atomic<long> g_join_mismatch{0}, g_join_checked{0};
+#endif
 // level 1 on the host: the map of block b of slot i.  W / Wp: scratch walkers (Wp holds the previous block's addend when
 // wp_c says so: a thread walks the blocks of a slot in order and sets every walker up once)
 static void map_block(const Prep *prep, int nchan, int i, int b, double c_before, int nsamp, int max_seg,
@@ -110,6 +114,13 @@ static void map_block(const Prep *prep, int nchan, int i, int b, double c_before
         for (int k = 0; k < lane::kEntriesHost; ++k) lane::build_cycle(*W, k, lane::kEntriesHost, &tab[k]);
     for (int t = 0; t < nseg; ++t) lane::walk_stretch(*W, prev, p, nsamp, t, nseg, use_tab ? tab : nullptr, lane::kEntriesHost, &st[t]);
     lane::join_stretches(st, nseg, W->neg, rec);
+#ifdef GPSIQ_JOIN_CHECK            // tests/chain_parallel.cpp: the join as a scan (what the device runs) against the loop, block for block
+    Rec scanned;
+    std::memset(&scanned, 0, sizeof scanned);
+    lane::join_stretches_scan(st, nseg, W->neg, &scanned);
+    if (std::memcmp(&scanned, rec, sizeof scanned)) g_join_mismatch.fetch_add(1);
+    g_join_checked.fetch_add(1);
+#endif
 }
 
 struct MapsJob {
@@ -180,7 +191,14 @@ static void link_slot(LinkJob &j, int i)
 
 static std::atomic<uint64_t> g_chain_stats[2];          // blocks linked through their map / walked from their true start
 
-bool chain_step_mapped(const void *maps, size_t at, double x, double *next) { return lane::link_block(static_cast<const Rec *>(maps)[at], x, next); }
+bool chain_step_mapped(const void *maps, size_t at, double x, double *next)
+{
+#ifdef GPSIQ_TEST_HOOKS          // fault injection: GPSIQ_TEST_CORRUPT_MAP_AT=<flat index> gives that block's map another end offset
+    if (const char *e = std::getenv("GPSIQ_TEST_CORRUPT_MAP_AT"))
+        if ((size_t) std::atol(e) == at) { Rec r = static_cast<const Rec *>(maps)[at]; r.cum[0] += 4; r.cum[1] += 4; return lane::link_block(r, x, next); }
+#endif
+    return lane::link_block(static_cast<const Rec *>(maps)[at], x, next);
+}
 void chain_prefetch_map(const void *maps, size_t at) { __builtin_prefetch(&static_cast<const Rec *>(maps)[at]); }
 void chain_count(long linked, long walked)
 {

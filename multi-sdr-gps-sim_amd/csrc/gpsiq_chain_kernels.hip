@@ -194,35 +194,75 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     }
     __syncthreads();
     int nseg = 0;
+    Stretch st;
+    st.r_in = 0.0; st.x_out = 0.0; st.x_end = 0.0; st.lo = 0; st.hi = 0; st.n_in = -1; st.n_out = -1; st.ok = 0; st.why = lane::kWhyAddend; st.sigma = 0; st.pad = 0;
     if (live) {
         nseg = lane::stretches(p.c, nsamp, max_seg < kSeg ? max_seg : kSeg);
         if (t < nseg) {
             const Walker *prev = (!(p.flags & lane::kSeed) && usable[blk]) ? &walker[blk] : nullptr;
-            Stretch st;
             lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, use_tab ? &cycles[kSeg >= 32 ? blk * kSeg : 0] : nullptr, kSeg, &st);
             stretch[tid] = st;
         }
     }
     __syncthreads();
+    // The stretches of a block joined into its map: a scan over the block's kSeg lanes (gpsiq_lane.h, "the join as a scan") --
+    // every lane takes part in the cross-lane moves, lanes without a stretch as identities.
+    const bool mine = live && t < nseg;
+    const bool neg = walker[blk + 1].neg;
+    const int64_t grid = neg ? 1 : 2;
+    lane::JoinLane jl;
+    jl.el = lane::join_identity(); jl.D = 0; jl.fail = 0; jl.pad = 0;
+    if (mine) jl = lane::join_lane(stretch[t > 0 ? tid - 1 : tid], st, t, grid);
+    lane::JoinMap inc = jl.el;
+    for (int off = 1; off < kSeg; off <<= 1) {
+        lane::JoinMap o;
+        o.t0 = __shfl_up(inc.t0, off, kSeg); o.t1 = __shfl_up(inc.t1, off, kSeg);
+        if (t >= off) inc = lane::join_compose(o, inc);
+    }
+    lane::JoinMap exc;
+    exc.t0 = __shfl_up(inc.t0, 1, kSeg); exc.t1 = __shfl_up(inc.t1, 1, kSeg);
+    if (t == 0) exc = lane::join_identity();
+    lane::JoinTerm q;
+    q.l = INT64_MIN; q.h = INT64_MAX; q.mask = 3; q.pad = 0;
+    if (mine) q = lane::join_term(exc, jl, st, t, grid);
+    int closed = q.mask;                                       // both branches closed from this stretch on: the prefix AND of the masks
+    for (int off = 1; off < kSeg; off <<= 1) {
+        const int o = __shfl_up(closed, off, kSeg);
+        if (t >= off) closed &= o;
+    }
+    int64_t lo = q.l, hi = q.h;
+    int mask = q.mask, first_fail = mine && jl.fail ? (t << 8 | jl.fail) : INT32_MAX, first_closed = mine && !closed ? t : INT32_MAX;
+    for (int off = kSeg / 2; off >= 1; off >>= 1) {
+        const int64_t ol = __shfl_xor(lo, off, kSeg), oh = __shfl_xor(hi, off, kSeg);
+        const int om = __shfl_xor(mask, off, kSeg), of = __shfl_xor(first_fail, off, kSeg), oc = __shfl_xor(first_closed, off, kSeg);
+        lo = ol > lo ? ol : lo; hi = oh < hi ? oh : hi; mask &= om;
+        first_fail = of < first_fail ? of : first_fail; first_closed = oc < first_closed ? oc : first_closed;
+    }
+    const int last = nseg > 0 ? nseg - 1 : 0;
+    lane::JoinMap all;
+    all.t0 = __shfl(inc.t0, last, kSeg); all.t1 = __shfl(inc.t1, last, kSeg);
+    const double x_end = __shfl(st.x_end, last, kSeg);
     if (b < nblocks && t == 0) {
         Rec r;
         r.xs = 0.0; r.e = 0.0; r.cum[0] = 0; r.cum[1] = 0; r.lo = 0; r.hi = 0; r.ok = 0; r.info = 0;
-        if (nseg > 0) lane::join_stretches(&stretch[blk * kSeg], nseg, walker[blk + 1].neg, &r);
+        if (nseg > 0) lane::join_finish(st, x_end, neg, all, lo, hi, mask, first_fail, first_closed, &r);
         rec[(size_t) b * nchan + i] = r;
     }
 }
 
+// which = 1: chain_prepare only, 2: chain_lanes only, 3: both
 hipError_t launch_chain(const void *d_in, int in_stride, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
-                        int max_seg, void *d_prep_, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream)
+                        int max_seg, void *d_prep_, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream, int which)
 {
     if (nblocks <= 0) return hipSuccess;
     Prep *d_prep = static_cast<Prep *>(d_prep_);
     Rec *d_rec = static_cast<Rec *>(d_maps);
-    hipLaunchKernelGGL(chain_prepare, dim3((unsigned) nchan), dim3(kPrepThreads), 0, stream, static_cast<const char *>(d_in), in_stride, nblocks, nchan, delt, nsamp, d_start, d_prep, d_c_before, d_end);
+    if (which & 1) hipLaunchKernelGGL(chain_prepare, dim3((unsigned) nchan), dim3(kPrepThreads), 0, stream, static_cast<const char *>(d_in), in_stride, nblocks, nchan, delt, nsamp, d_start, d_prep, d_c_before, d_end);
 #define GPSIQ_LANES(S)                                                                                                    \
     hipLaunchKernelGGL(chain_lanes<S>, dim3((unsigned) (nchan * ((nblocks + kLaneThreads / S - 1) / (kLaneThreads / S)))), dim3(kLaneThreads), 0, stream, \
                        d_prep, d_c_before, nblocks, nchan, nsamp, max_seg, d_rec)
     if (max_seg < 1) max_seg = 1;
+    if (!(which & 2)) return hipGetLastError();
     if (max_seg > 16) GPSIQ_LANES(32);
     else if (max_seg > 8) GPSIQ_LANES(16);
     else if (max_seg > 4) GPSIQ_LANES(8);

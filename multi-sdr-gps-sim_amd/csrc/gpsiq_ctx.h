@@ -105,8 +105,8 @@ struct gpsiq_ctx {
         gpsiq::FixedCarry *d_fix = nullptr, *h_fix = nullptr;
         gpsiq_patch_t  *d_patches = nullptr, *h_patches = nullptr;  unsigned patch_cap = 0;
         gpsiq::EvalHostItem *d_host = nullptr, *h_host = nullptr;   unsigned host_cap = 0;
-        hipStream_t     eval_stream = nullptr;
-        hipEvent_t      linked[gpsiq::kEvalMaxPieces] = {}, evaluated[gpsiq::kEvalMaxPieces] = {}, joined = nullptr;
+        hipStream_t     eval_stream = nullptr, chain_stream = nullptr;   // highest priority: beside the synthesis, ahead of its workgroups
+        hipEvent_t      linked[gpsiq::kEvalMaxPieces] = {}, evaluated[gpsiq::kEvalMaxPieces] = {}, joined = nullptr, t_synth0 = nullptr, t_synth1 = nullptr;
         // statistics of the last call (gpsiq_evaldev_stats)
         double          host_ms = 0.0;                 // host thread-time spent on the call's descriptors (pack, repair, walker)
         unsigned        last_nhost = 0, last_npatch = 0, last_repaired = 0;
@@ -129,6 +129,7 @@ int gpsiq_ensure_out(gpsiq_ctx *c, size_t bytes);
 hipStream_t gpsiq_piece_stream(gpsiq_ctx *c, int k);
 int gpsiq_chain_reserve(gpsiq_ctx *c, size_t n);
 double gpsiq_rate_kernel();
+void gpsiq_note_kernel_rate(double channel_samples_per_s);      // a measured rate of the synthesis kernel (running mean)
 // GPSIQ_NCO_REFERENCE batch with chain link and evaluation on host threads (the path of rounds 4-5; fallback of the device path)
 int gpsiq_generate_reference_host(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
                                   int sample_size, void *dst, int dst_is_device, double *carr_phase_out, const double *seeds);
@@ -147,7 +148,7 @@ hipError_t launch_patches(const gpsiq_qchan_t *desc, int nchan, int nsamp, int s
                           int block0, int nblocks, const DeviceTables *tab, const gpsiq_patch_t *patches, int npatch,
                           hipStream_t stream);
 hipError_t launch_chain(const void *d_in, int in_stride, int nblocks, int nchan, double delt, int nsamp, const gpsiq_chain_est_t *d_start,
-                        int max_seg, void *d_prep, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream);
+                        int max_seg, void *d_prep, double *d_c_before, gpsiq_chain_est_t *d_end, void *d_maps, hipStream_t stream, int which = 3);
 int chain_link(const gpsiq_chain_in_t *in, const void *maps, int nblocks, int nchan, double delt, int nsamp,
                const double *carr_in, const int32_t *prn_in, double *carr_start, double *carr_end, int32_t *last_prn);
 double chain_block_true(double f_carr, double delt, int nsamp, double start);

@@ -223,9 +223,7 @@ static int set_descriptors_impl(gpsiq_ctx_t *c, const gpsiq_qchan_t *q, int nblo
     if (nblocks < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad nblocks %d / nchan %d", nblocks, nchan);
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t) nblocks * (size_t) nchan;
-    int nsets = gpsiq_ctx::kSets;
-    if (const char *e = std::getenv("GPSIQ_DESC_SETS")) { const int v = std::atoi(e); if (v >= 2 && v <= gpsiq_ctx::kSets) nsets = v; }
-    const int next = (c->cur + 1) % nsets;
+    const int next = (c->cur + 1) % gpsiq_ctx::kSets;
     gpsiq_ctx::DescBuf &nb = c->buf[next];              // a set not being read by the latest launches
     // the launch from kSets sets ago may still be reading this buffer (and its staging may still be
     // the source of an upload): wait for exactly that, not for the whole device
@@ -457,11 +455,11 @@ const char *gpsiq_variant_name(int v)
 // ---- synchronous drop-in entry points ---------------------------------------
 
 // Blocks per piece of a host-destination batch: the kernel of piece k+1 runs while piece k crosses
-// PCIe (two copy streams, so consecutive copies queue back to back).  GPSIQ_D2H_CHUNK_BLOCKS overrides;
+// PCIe (two copy streams, so consecutive copies queue back to back).  GPSIQ_PIECE_BLOCKS overrides;
 // 0 = one kernel, then one copy (the round-1 behaviour, kept for A/B measurements).
 static int d2h_chunk_blocks(size_t stride)
 {
-    if (const char *e = std::getenv("GPSIQ_D2H_CHUNK_BLOCKS")) return std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: A/B in one process
+    if (const char *e = std::getenv("GPSIQ_PIECE_BLOCKS")) return std::atoi(e) > 0 ? std::atoi(e) : 0;   // read per call: A/B in one process
     const size_t target = (size_t) 32 << 20;                 // ~32 MiB per piece: >= 0.5 ms on the link, a few hundred workgroups
     const size_t n = (target + stride - 1) / stride;
     return (int) (n < 8 ? 8 : n);
@@ -530,24 +528,22 @@ static int run_to_host_or_device(gpsiq_ctx *c, const gpsiq_qchan_t *q, int nbloc
 // The stream of piece k of a batch worked through in pieces.  On ONE stream a piece's kernel starts when the last workgroup of
 // the piece before it has retired: every piece pays its own ramp-down (six pieces of a 2 000-block call: 1.75 ms of kernels
 // against 1.50 ms in one launch, profiles/r05_chain_ab.txt).  Pieces write disjoint blocks and read their own descriptor set
-// (two sets, reused by every other piece: piece k+2 follows piece k on the same stream), so consecutive pieces alternate
+// (four sets taken in turn; piece k+2 follows piece k on the same stream), so consecutive pieces alternate
 // between two streams and the next piece's first workgroups fill the compute units the last ones of this piece leave.
-// GPSIQ_PIECE_STREAMS=1: one stream (A/B; read per call).
+// (One stream against two: profiles/r05_chain_ab.txt.)
 static hipStream_t piece_stream(gpsiq_ctx *c, int k)
 {
-    if (!(k & 1)) return c->stream;
-    const char *e = std::getenv("GPSIQ_PIECE_STREAMS");
-    return e && std::atoi(e) == 1 ? c->stream : c->stream2;
+    return (k & 1) ? c->stream2 : c->stream;
 }
 
 // Blocks per piece of a long device-destination batch in the fixed-point model: ~1 ms of kernel, a few hundred microseconds of
-// host work per piece.  GPSIQ_BATCH_PIECE_BLOCKS overrides (read per call); <= 0: one piece.
+// host work per piece.  GPSIQ_PIECE_BLOCKS overrides (read per call); <= 0: one piece.
 static int batch_piece_blocks(int nblocks, int nsamp)
 {
     long n = nsamp > 0 ? ((long) 1024 * 260000) / nsamp : 1024;
     if (n > 1024) n = 1024;
     if (n < 32) n = 32;
-    if (const char *e = std::getenv("GPSIQ_BATCH_PIECE_BLOCKS")) n = std::atoi(e);
+    if (const char *e = std::getenv("GPSIQ_PIECE_BLOCKS")) n = std::atoi(e);
     return n > 0 && 2 * n <= nblocks ? (int) n : nblocks;            // fewer than two pieces' worth: one piece
 }
 
@@ -574,7 +570,7 @@ static int ref_chunk_blocks(int nblocks, int nsamp)
     long n = nsamp > 0 ? ((long) 256 * 260000) / nsamp : 256;
     if (n > 256) n = 256;
     if (n < 16) n = 16;
-    if (const char *e = std::getenv("GPSIQ_REF_CHUNK_BLOCKS")) n = std::atoi(e);       // read per call: A/B in one process; <= 0: one piece
+    if (const char *e = std::getenv("GPSIQ_PIECE_BLOCKS")) n = std::atoi(e);       // read per call: A/B in one process; <= 0: one piece
     return n > 0 && n < nblocks ? (int) n : nblocks;
 }
 
@@ -631,8 +627,9 @@ struct RefRender {
         if (s2 == hipSuccess) s2 = s3;
         if (s0 != hipSuccess || s1 != hipSuccess || s2 != hipSuccess)
             return fail(GPSIQ_E_DEVICE, "reference NCO pieces: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1 != hipSuccess ? s1 : s2));
-        // every launch waited for its set's upload on the device and has finished: later launches on the resident set need not
-        // wait for that (long completed) event again
+        // every launch waited for its set's upload on the device and has finished; a set that was staged but never launched
+        // (an error in between) may still be uploading: the upload stream is drained too before the flags are dropped
+        if (hipStreamSynchronize(c->up_stream) != hipSuccess) return fail(GPSIQ_E_DEVICE, "reference NCO pieces: descriptor upload");
         for (auto &b : c->buf) b.upload_pending = false;
         return GPSIQ_OK;
     }
@@ -645,20 +642,16 @@ struct RefRender {
 // is 6.7 us of device work against ~3 us of host work per thread): every launch costs ~30 us beyond its share of one big
 // launch (a 26-block piece is a single round of workgroups: 215 us measured against 183 us), so as few pieces as the host can
 // keep ahead of -- each 2.2 x the one before (the host has piece k+1 ready before the kernel of piece k ends), no small tail.
-// GPSIQ_REF_CHUNK_RAMP=0: equal pieces (A/B).
 static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool kernel_bound = false)
 {
-    const char *ramp_env = std::getenv("GPSIQ_REF_CHUNK_RAMP");              // read per call, like GPSIQ_PIECE_GROWTH below
-    const bool ramp = !ramp_env || std::atoi(ramp_env) != 0;
     const int half = chunk > 1 ? chunk / 2 : 1;
-    if (!ramp || n <= 4 * chunk) {
+    if (n <= 4 * chunk) {
         for (int b = chunk; b < n; b += chunk) ends->push_back(first + b);
         ends->push_back(first + n);
         return;
     }
     if (kernel_bound) {
-        int growth = 220;                                 // per cent; GPSIQ_PIECE_GROWTH (read per call) for A/B
-        if (const char *e = std::getenv("GPSIQ_PIECE_GROWTH")) { const int g = std::atoi(e); if (g >= 100 && g <= 1000) growth = g; }
+        const int growth = 220;                           // per cent
         int b = 0, size = half;
         while (n - b > size + half) {                // what is left after this piece is worth a piece of its own
             b += size;
@@ -685,18 +678,16 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool
 // threads (2.7 us at 2.6 Msps, 4.5 us at 25 Msps, in the call).  At 25 Msps on sixteen threads the two sides are within 1.5 x of
 // each other and the symmetric ramp measured better (1.77 against 1.91 ms per 200 blocks): only a clear case takes the few
 // growing pieces.
-// The two rates: MI355X + EPYC 9575F as measured; another GPU or host names its own (read per call, like every other knob here):
-// GPSIQ_RATE_KERNEL in channel-samples per second, GPSIQ_RATE_CHAIN_US in microseconds per block and channel of the serial walk.
+// The kernel's rate is MEASURED: every batch call that renders through the device evaluation times its last piece's synthesis
+// with events and keeps a running mean in the context (gpsiq_evaldev.cpp); until the first such call, and for the host rate, the
+// figures of MI355X + EPYC 9575F stand in.  GPSIQ_RATE_KERNEL (channel-samples per second, read per call) overrides both.
+static double g_rate_kernel_measured = 0.0;        // the last context's running mean (the placement rules below have no context at hand)
 static double rate_kernel()
 {
     if (const char *e = std::getenv("GPSIQ_RATE_KERNEL")) { const double v = std::atof(e); if (v > 1e9) return v; }
-    return 6.0e12;
+    return g_rate_kernel_measured > 0.0 ? g_rate_kernel_measured : 6.0e12;
 }
-static double rate_chain_us()
-{
-    if (const char *e = std::getenv("GPSIQ_RATE_CHAIN_US")) { const double v = std::atof(e); if (v > 0.01) return v; }
-    return 2.2;
-}
+static double rate_chain_us() { return 2.2; }      // microseconds per block and channel of the serial walk on one host thread
 
 static bool ref_kernel_bound(int nsamp, int nchan)
 {
@@ -889,7 +880,6 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
         // the head: pieces worth ~0.4 ms of synthesis (the second launch's latency + its first piece's evaluation)
         const double t_block = (double) nsamp * (double) nchan / rate_kernel();
         int want = (int) (0.4e-3 / t_block) + 1;
-        if (const char *e = std::getenv("GPSIQ_CHAIN_HEAD")) want = std::atoi(e);            // blocks; <= 0: one launch (A/B)
         if (want > 0 && 2 * want < nblocks)                    // the first piece end at or beyond that (a bigger head measured better than a
             for (size_t k = 0; k < ends.size(); ++k)           // smaller one: 2.35 ms per call at 900 blocks, 2.49 at 256, 2.55 at 128)
                 if (ends[k] >= want) { head = ends[k]; break; }
@@ -943,7 +933,16 @@ static int generate_reference(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks,
     }
     char err[400] = "";
     if (rc != GPSIQ_OK) { std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); w.abort(); }     // nothing further is walked for a call that has failed
-    if (dev_chain) (void) chain_drain(c);                             // the callbacks have run: every chain task is runnable, also of an aborted walk
+    if (dev_chain) {
+        // the callbacks have run when the chain's streams have drained -- unless the device reported an error, in which case the
+        // walkers must not be left waiting for maps that never land (and must not link through whatever h_maps held before)
+        const int crc = chain_drain(c);
+        if (crc != GPSIQ_OK) {
+            if (rc == GPSIQ_OK) { rc = crc; std::snprintf(err, sizeof err, "%s", gpsiq_last_error()); }
+            w.abort();
+        }
+        w.release_maps(nblocks);
+    }
     if (threaded) pthread_join(th, nullptr);                 // the walkers read ch and write q: never leave them running
     const double tf = trace ? wall_ms() : 0.0;
     const int frc = r.finish();
@@ -1178,7 +1177,8 @@ int gpsiq_generate_batch(gpsiq_ctx_t *c, const gpsiq_chan_t *ch, int nblocks, in
         int src = gpsiq_synchronize(c, c->stream);                    // on every path: the kernels write the caller's buffer
         const int src2 = gpsiq_synchronize(c, c->stream2);
         if (src == GPSIQ_OK) src = src2;
-        if (src == GPSIQ_OK) for (auto &b : c->buf) b.upload_pending = false;     // the uploads the launches waited for are done
+        if (src == GPSIQ_OK && hipStreamSynchronize(c->up_stream) != hipSuccess) src = fail(GPSIQ_E_DEVICE, "batch pieces: descriptor upload");
+        if (src == GPSIQ_OK) for (auto &b : c->buf) b.upload_pending = false;     // the uploads (also of a set never launched on) are done
         if (rc != GPSIQ_OK) return fail(rc, "%s", err);
         if (src != GPSIQ_OK) return src;
         if (trace) std::fprintf(stderr, "[gpsiq trace] batch %d blocks in pieces of %d: whole call %.2f ms\n", nblocks, piece, wall_ms() - t0);
@@ -1421,6 +1421,12 @@ int gpsiq_ensure_out(gpsiq_ctx *c, size_t bytes) { return ensure_out(c, bytes); 
 hipStream_t gpsiq_piece_stream(gpsiq_ctx *c, int k) { return piece_stream(c, k); }
 int gpsiq_chain_reserve(gpsiq_ctx *c, size_t n) { return chain_reserve(c, n); }
 double gpsiq_rate_kernel() { return rate_kernel(); }
+void gpsiq_note_kernel_rate(double channel_samples_per_s)
+{
+    if (!(channel_samples_per_s > 1e10 && channel_samples_per_s < 1e15)) return;
+    const double old = g_rate_kernel_measured;
+    g_rate_kernel_measured = old > 0.0 ? 0.75 * old + 0.25 * channel_samples_per_s : channel_samples_per_s;
+}
 int gpsiq_generate_reference_host(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
                                   int sample_size, void *dst, int dst_is_device, double *carr_phase_out, const double *seeds)
 {

@@ -313,27 +313,37 @@ constexpr int kCandCap = 256;            // candidates per accumulator and block
 
 // chips(prn, i): chip i (0 / 1) of the satellite's C/A code; emit(sample, lut, neg): one patch of this channel.
 // q receives the descriptor seeded from `start` (also when the host is asked to redo the patches: the descriptor is the same).
-// the descriptor of a channel seeded from `start`, the accumulator at the block's first sample: kQOk or the QStatus that refuses it
-GPSIQ_HD inline int eval_quantize(const DChan &d, double start, double delt, int nsamp, gpsiq_qchan_t *q)
+// The descriptor of a channel with the carrier seeded from `phase`: the accumulator at the block's first sample where it is known
+// (the host path; the caller's start states), else the ESTIMATE of it that chain_prepare gives -- the device renders from the
+// estimate at once and learns the true state when the chain has been linked (eval_candidates then works with the difference).
+// kQOk or the QStatus that refuses it.
+GPSIQ_HD inline int eval_quantize(const DChan &d, double phase, double delt, int nsamp, gpsiq_qchan_t *q)
 {
-    // a start of exactly 1.0 (a wrap that rounded up to one) is phase 0 of the closed form; the reference goes on from 1.0 and
-    // indexes its table at 512 for sample 0: undecided by construction (the enclosure refuses x0 = 1.0), the host walks it
-    if (d.prn > 0 && !(start >= 0.0 && start <= 1.0)) { gpsiq_qchan_t z; z.carr_phase = 0; z.carr_step = 0; z.code_frac = 0; z.code_step = 0; z.gain = 0.0; z.nav_bits = 0; z.chip0 = 0; z.icode = 0; z.prn = 0; *q = z; return kQStart; }
-    const uint64_t seeded = phase_to_fixed(start == 1.0 ? 0.0 : start);
+    // a phase of exactly 1.0 (a wrap that rounded up to one) is phase 0 of the closed form
+    if (d.prn > 0 && !(phase >= 0.0 && phase <= 1.0)) { gpsiq_qchan_t z; z.carr_phase = 0; z.carr_step = 0; z.code_frac = 0; z.code_step = 0; z.gain = 0.0; z.nav_bits = 0; z.chip0 = 0; z.icode = 0; z.prn = 0; *q = z; return kQStart; }
+    const uint64_t seeded = phase_to_fixed(phase == 1.0 ? 0.0 : phase);
     return quantize_dchan(d, delt, nsamp, &seeded, q);
 }
 
-// the patches of a channel whose descriptor qq eval_quantize has accepted: kEvalOk, or kEvalHost
+// The patches of a channel whose descriptor qq eval_quantize has accepted, given the TRUE accumulator `start` at the block's first
+// sample: the samples where the double path from `start` takes another LUT entry or sign than the closed form of qq -- whose
+// carrier may have been seeded from an estimate: it then runs |qq.carr_phase - fixed(start)| units beside the closed form seeded
+// from the truth, and the candidate window is that much wider (eval_block, gpsiq_exact.cpp, with a seed override).
+// kEvalOk, kEvalHost, or -kQStart (a start outside [0, 1]).  A start of exactly 1.0: the reference goes on from 1.0 and indexes
+// its table at 512 for sample 0 -- undecided by construction (the enclosure refuses x0 = 1.0), the host walks it.
 template <class Chips, class Emit>
 GPSIQ_HD inline int eval_candidates(const DChan &d, const gpsiq_qchan_t &qq, double start, double delt, int nsamp, const Chips &chips, Emit &emit)
 {
     const long ns = nsamp;
     if (ns <= 0 || d.prn <= 0) return kEvalOk;
+    if (!(start >= 0.0 && start <= 1.0)) return -kQStart;
     const double carr_inc = d.f_carr * delt, code_inc = d.f_code * delt;
+    uint64_t seed_off = (phase_to_fixed(start == 1.0 ? 0.0 : start) - qq.carr_phase) & kEvCarrMask;
+    if (seed_off > (UINT64_C(1) << (GPSIQ_CARR_FRAC_BITS - 1))) seed_off = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - seed_off;
     // drift bounds at the end of the block, in units of the fixed-point formats (gpsiq_exact.cpp)
-    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
+    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4 + seed_off;
     const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
-    const bool want_c = carr_inc != 0.0;          // a zero addend leaves both paths constant and equal
+    const bool want_c = carr_inc != 0.0 || seed_off != 0;          // a zero addend leaves both paths constant, and equal when seeded alike
     if ((want_c && 2 * w_carr + 1 >= (UINT64_C(1) << (GPSIQ_CARR_FRAC_BITS - 9))) || 2 * w_code + 1 >= (UINT64_C(1) << GPSIQ_CODE_FRAC_BITS)) return kEvalHost;
     uint64_t nc = want_c ? next_candidate(qq.carr_phase, (uint64_t) qq.carr_step, GPSIQ_CARR_FRAC_BITS - 9, w_carr, ns, 0) : kNoHit;
     uint64_t nk = next_candidate(qq.code_frac, qq.code_step, GPSIQ_CODE_FRAC_BITS, w_code, ns, 0);
@@ -379,10 +389,11 @@ GPSIQ_HD inline int eval_candidates(const DChan &d, const gpsiq_qchan_t &qq, dou
 
 // chips(prn, i): chip i (0 / 1) of the satellite's C/A code; emit(sample, lut, neg): one patch of this channel.
 // q receives the descriptor seeded from `start` (also when the host is asked to redo the patches: the descriptor is the same).
+// est: what the descriptor is seeded from (== start on the host path)
 template <class Chips, class Emit>
-GPSIQ_HD inline int eval_chan(const DChan &d, double start, double delt, int nsamp, const Chips &chips, Emit &emit, gpsiq_qchan_t *q)
+GPSIQ_HD inline int eval_chan(const DChan &d, double start, double est, double delt, int nsamp, const Chips &chips, Emit &emit, gpsiq_qchan_t *q)
 {
-    const int qs = eval_quantize(d, start, delt, nsamp, q);
+    const int qs = eval_quantize(d, est, delt, nsamp, q);
     if (qs != kQOk) return -qs;
     return eval_candidates(d, *q, start, delt, nsamp, chips, emit);
 }

@@ -9,15 +9,20 @@
 //                   offset mod 4 only (gpsiq_eval.h, Link), so the chain that the host walked block after block is three LDS scans
 //                   per 256 blocks.  Writes every block's start state into its DChan; a slot with a block whose map does not
 //                   apply is counted, and the host walker takes that slot (gpsiq_device.cpp).
-//   eval_blocks     one lane per (block, channel): eval_chan of gpsiq_eval.h -- the quantiser seeded from the start state
-//                   (gps.c:2033-2064 outputs as inputs), the Euclid descent for the candidate samples, the drift enclosure --, the
-//                   descriptors compacted per block (active channels first) straight into the set the synthesis kernel reads, the
-//                   patches appended to the call's list, what the enclosure cannot decide appended to the host walker's list.
+//   quantize_est    one lane per (block, channel): the quantiser (gps.c:2033-2064 outputs as inputs) with the carrier seeded from
+//                   chain_prepare's ESTIMATE of the block's start state; the descriptors compacted per block (active channels first)
+//                   straight into the set the synthesis kernel reads -- which starts behind this kernel, not behind the chain.
+//   eval_blocks     when the chain has been linked: from the TRUE start states the Euclid descent for the candidate samples (window
+//                   widened by estimate - truth), the drift enclosure, the patches appended to the call's list; what the enclosure
+//                   cannot decide appended to the host walker's list (eval_chan of gpsiq_eval.h).
 //   quantize_fixed  GPSIQ_NCO_FIXED: the quantiser from each block's own carr_phase, then the exact carrier prefix
 //   carry_prefix    p_{k+1} = p_k + nsamp*step_k (mod 2^59) down each slot as a segmented scan (what chain_carrier does on the host).
 // No MFMA (no contraction), nothing HBM-bound: 64 bytes in and 48 out per block and channel; the work is 64/128-bit integer and
 // FP64 scalar-style arithmetic, one lane per channel, sixteen lanes per block so that a block's channels compact with one ballot.
 #include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
 
 #include "gpsiq_internal.h"
 #include "gpsiq_eval.h"
@@ -220,9 +225,39 @@ __device__ inline int store_compacted(gpsiq_qchan_t *__restrict__ qout, size_t r
     return slot;
 }
 
-// blocks [b0, b0 + nb) of the timeline; qout: the whole timeline's descriptor set [nblocks][nchan]
+// The phase a block's descriptor is seeded from: est_rows + k * est_stride bytes holds a double per (block, channel) -- the
+// estimate of the accumulator at the block's first sample (lane::Prep::est, 32-byte rows, written by chain_prepare), or the
+// caller's start states (gpsiq_generate_seeded: 8-byte rows).
+__device__ inline double seed_phase(const char *__restrict__ est_rows, int est_stride, size_t k)
+{
+    return *reinterpret_cast<const double *>(est_rows + k * (size_t) est_stride);
+}
+
+// GPSIQ_NCO_REFERENCE, first half: the descriptors of blocks [b0, b0 + nb), quantised with the carrier seeded from the ESTIMATE
+// of each block's start state, compacted per block into the set the synthesis kernel reads.  The synthesis starts behind this
+// kernel; the chain that gives the TRUE start states (chain_lanes, chain_link_scan) and the evaluation run beside it.
+__global__ __launch_bounds__(kEvalThreads) void quantize_est(const DChan *__restrict__ chan, int b0, int nb, int nchan, double delt, int nsamp,
+                                                             const char *__restrict__ est_rows, int est_stride,
+                                                             gpsiq_qchan_t *__restrict__ qout, EvalCtrl *__restrict__ ctrl)
+{
+    const long gid = (long) blockIdx.x * kEvalThreads + threadIdx.x;
+    const int b = b0 + (int) (gid >> 4), i = (int) (gid & 15);
+    const bool live = b < b0 + nb && i < nchan;
+    DChan d;
+    d.f_carr = 0.0; d.carr_phase = 0.0; d.prn = 0; d.pos = 0; d.f_code = 0.0; d.code_phase = 0.0; d.gain = 0.0; d.nav = 0; d.start = 0.0;
+    double est = 0.0;
+    if (live) { d = chan[(size_t) b * nchan + i]; est = seed_phase(est_rows, est_stride, (size_t) b * nchan + i); }
+    gpsiq_qchan_t q;
+    const int qs = ev::eval_quantize(d, est, delt, nsamp, &q);
+    if (live && qs != ev::kQOk) report_error(ctrl, (size_t) b * nchan + i, qs);
+    (void) store_compacted(qout, (size_t) b * nchan, i, b < b0 + nb ? nchan : 0, live && d.prn > 0 && qs == ev::kQOk, q);
+}
+
+// Second half, when the chain has been linked: the TRUE start state of every block is in its DChan (or in starts[], the caller's).
+// One lane per (block, channel) recomputes the descriptor quantize_est wrote (same arithmetic: no dependence on the compacted
+// set), finds the samples where the double path from the true start leaves that closed form, and appends the patches.
 __global__ __launch_bounds__(kEvalThreads) void eval_blocks(const DChan *__restrict__ chan, int b0, int nb, int nchan, double delt, int nsamp,
-                                                            const DeviceTables *__restrict__ tab, gpsiq_qchan_t *__restrict__ qout,
+                                                            const DeviceTables *__restrict__ tab, const char *__restrict__ est_rows, int est_stride,
                                                             gpsiq_patch_t *__restrict__ patches, unsigned patch_cap,
                                                             EvalHostItem *__restrict__ hostlist, unsigned host_cap, EvalCtrl *__restrict__ ctrl,
                                                             const double *__restrict__ starts)
@@ -232,20 +267,24 @@ __global__ __launch_bounds__(kEvalThreads) void eval_blocks(const DChan *__restr
     const bool live = b < b0 + nb && i < nchan;
     DChan d;
     d.f_carr = 0.0; d.carr_phase = 0.0; d.prn = 0; d.pos = 0; d.f_code = 0.0; d.code_phase = 0.0; d.gain = 0.0; d.nav = 0; d.start = 0.0;
-    if (live) d = chan[(size_t) b * nchan + i];
+    double est = 0.0;
+    if (live) { d = chan[(size_t) b * nchan + i]; est = seed_phase(est_rows, est_stride, (size_t) b * nchan + i); }
     const double start = live && starts ? starts[(size_t) b * nchan + i] : d.start;     // starts: the caller's (gpsiq_generate_seeded)
     gpsiq_qchan_t q;
-    const int qs = ev::eval_quantize(d, start, delt, nsamp, &q);
-    if (live && qs != ev::kQOk) report_error(ctrl, (size_t) b * nchan + i, qs);
+    const int qs = ev::eval_quantize(d, est, delt, nsamp, &q);                          // (refusals were reported by quantize_est)
     const bool active = live && d.prn > 0 && qs == ev::kQOk;
-    const int slot = store_compacted(qout, (size_t) b * nchan, i, b < b0 + nb ? nchan : 0, active, q);
+    // the channel's place among the block's active ones, as quantize_est compacted them
+    const unsigned long long m = __ballot(active);
+    const unsigned bits = (unsigned) (m >> (threadIdx.x & 48)) & 0xffffu;
+    const int slot = __popc(bits & ((1u << i) - 1u));
     if (!active) return;
     DevChips chips = {tab};
     DevEmit emit = {patches, patch_cap, ctrl, (uint32_t) b, (uint8_t) slot};
     const int st = ev::eval_candidates(d, q, start, delt, nsamp, chips, emit);
+    if (st < 0) report_error(ctrl, (size_t) b * nchan + i, -st);
     if (st == ev::kEvalHost) {
         const unsigned k = atomicAdd(&ctrl->nhost, 1u);
-        if (k < host_cap) { EvalHostItem h; h.block = (uint32_t) b; h.chan = (uint16_t) i; h.slot = (uint16_t) slot; h.start = start; hostlist[k] = h; }
+        if (k < host_cap) { EvalHostItem h; h.block = (uint32_t) b; h.chan = (uint16_t) i; h.slot = (uint16_t) slot; h.start = start; h.seed = q.carr_phase; hostlist[k] = h; }
     }
 }
 
@@ -362,14 +401,24 @@ hipError_t launch_link_scan(void *d_chan, const void *d_maps, int b0, int nb, in
     return hipGetLastError();
 }
 
-hipError_t launch_eval(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, const DeviceTables *tab, gpsiq_qchan_t *d_q,
+hipError_t launch_quantize_est(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, const void *est_rows, int est_stride,
+                               gpsiq_qchan_t *d_q, EvalCtrl *d_ctrl, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    const long threads = (long) nb * 16;
+    hipLaunchKernelGGL(quantize_est, dim3((unsigned) ((threads + kEvalThreads - 1) / kEvalThreads)), dim3(kEvalThreads), 0, s, static_cast<const DChan *>(d_chan),
+                       b0, nb, nchan, delt, nsamp, static_cast<const char *>(est_rows), est_stride, d_q, d_ctrl);
+    return hipGetLastError();
+}
+
+hipError_t launch_eval(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, const DeviceTables *tab, const void *est_rows, int est_stride,
                        gpsiq_patch_t *d_patches, unsigned patch_cap, EvalHostItem *d_host, unsigned host_cap, EvalCtrl *d_ctrl, const double *d_starts,
                        hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
     const long threads = (long) nb * 16;
     hipLaunchKernelGGL(eval_blocks, dim3((unsigned) ((threads + kEvalThreads - 1) / kEvalThreads)), dim3(kEvalThreads), 0, s, static_cast<const DChan *>(d_chan),
-                       b0, nb, nchan, delt, nsamp, tab, d_q, d_patches, patch_cap, d_host, host_cap, d_ctrl, d_starts);
+                       b0, nb, nchan, delt, nsamp, tab, static_cast<const char *>(est_rows), est_stride, d_patches, patch_cap, d_host, host_cap, d_ctrl, d_starts);
     return hipGetLastError();
 }
 
@@ -384,5 +433,17 @@ hipError_t launch_quantize_fixed(const void *d_chan, int b0, int nb, int nchan, 
     hipLaunchKernelGGL(compact_blocks, grid, block, 0, s, d_q, b0, nb, nchan, d_ctrl);
     return hipGetLastError();
 }
+
+#ifdef GPSIQ_TEST_HOOKS
+__global__ void test_corrupt_map(Rec *rec, size_t at) { rec[at].cum[0] += 4; rec[at].cum[1] += 4; }
+hipError_t launch_test_corrupt_map(void *d_maps, int b0, int nb, int nchan, hipStream_t s)
+{
+    const char *e = std::getenv("GPSIQ_TEST_CORRUPT_MAP");
+    int b = -1, i = -1;
+    if (!e || std::sscanf(e, "%d,%d", &b, &i) != 2 || b < b0 || b >= b0 + nb || i < 0 || i >= nchan) return hipSuccess;
+    hipLaunchKernelGGL(test_corrupt_map, dim3(1), dim3(1), 0, s, static_cast<Rec *>(d_maps), (size_t) b * nchan + i);
+    return hipGetLastError();
+}
+#endif
 
 }  // namespace gpsiq

@@ -27,16 +27,23 @@ struct EvalCtrl {
 
 struct LinkCarry { int64_t d; double y; int32_t prn; int32_t known; };     // GPSIQ_NCO_REFERENCE: offset, accumulator after the last block
 struct FixedCarry { uint64_t phase; int32_t prn; int32_t cont; };          // GPSIQ_NCO_FIXED: exact carrier phase after the last block
-struct EvalHostItem { uint32_t block; uint16_t chan, slot; double start; }; // slot: the channel's place among the block's active ones; start: its accumulator
+struct EvalHostItem { uint32_t block; uint16_t chan, slot; double start; uint64_t seed; };   // slot: the channel's place among the block's active ones; start: its accumulator; seed: the carrier phase its descriptor was seeded with
 
 hipError_t launch_pack_raw(const gpsiq_chan_t *d_ch, int nblocks, int nchan, double delt, void *d_chan, EvalCtrl *d_ctrl, hipStream_t s);
 hipError_t launch_link_scan(void *d_chan, const void *d_maps, int b0, int nb, int nchan, double delt, LinkCarry *d_carry, EvalCtrl *d_ctrl, int piece,
                             hipStream_t s);
-hipError_t launch_eval(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, const DeviceTables *tab, gpsiq_qchan_t *d_q,
+hipError_t launch_quantize_est(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, const void *est_rows, int est_stride,
+                               gpsiq_qchan_t *d_q, EvalCtrl *d_ctrl, hipStream_t s);
+hipError_t launch_eval(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, const DeviceTables *tab, const void *est_rows, int est_stride,
                        gpsiq_patch_t *d_patches, unsigned patch_cap, EvalHostItem *d_host, unsigned host_cap, EvalCtrl *d_ctrl, const double *d_starts,
                        hipStream_t s);
 hipError_t launch_quantize_fixed(const void *d_chan, int b0, int nb, int nchan, double delt, int nsamp, gpsiq_qchan_t *d_q, FixedCarry *d_carry,
                                  EvalCtrl *d_ctrl, hipStream_t s);
+
+#ifdef GPSIQ_TEST_HOOKS
+// GPSIQ_TEST_CORRUPT_MAP="block,slot" in the environment: that block's map gets another end offset (both parity branches)
+hipError_t launch_test_corrupt_map(void *d_maps, int b0, int nb, int nchan, hipStream_t s);
+#endif
 
 }  // namespace gpsiq
 #endif

@@ -27,7 +27,7 @@ using namespace gpsiq;
 
 namespace gpsiq {
 // gpsiq_exact.cpp: one channel of one block on the host (descriptor + patches from its start state)
-int eval_block_host(const gpsiq_chan_t &ch, double start, double delt, int nsamp, int block, int slot, gpsiq_qchan_t *q,
+int eval_block_host(const gpsiq_chan_t &ch, double start, const uint64_t *seed, double delt, int nsamp, int block, int slot, gpsiq_qchan_t *q,
                     std::vector<gpsiq_patch_t> *out);
 }
 
@@ -53,7 +53,16 @@ int evd_reserve(gpsiq_ctx *c, size_t n, SrcKind kind, bool seeds)
     int rc = gpsiq_chain_reserve(c, n);
     if (rc) return rc;
     if (!e.eval_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&e.eval_stream, hipStreamNonBlocking));
+        // Chain and evaluation run BESIDE the synthesis, which floods the device with workgroups: their streams get the highest
+        // priority, so that the few workgroups of prepare / lanes / link / evaluation are dispatched as synthesis workgroups retire
+        // instead of behind all of them (the patches have to be there when the synthesis ends, not some time after it).
+        int least = 0, greatest = 0;
+        (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+        // (MI355X, 2.6 Msps, 2 000 blocks: 1.82 ms per call against 2.20 at equal priorities; 25 Msps: 1.54 against 2.61)
+        HIP_TRY(hipStreamCreateWithPriority(&e.eval_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e.chain_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreate(&e.t_synth0));
+        HIP_TRY(hipEventCreate(&e.t_synth1));
         for (auto &ev_ : e.linked) HIP_TRY(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
         for (auto &ev_ : e.evaluated) HIP_TRY(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e.joined, hipEventDisableTiming));
@@ -96,13 +105,13 @@ int evd_reserve(gpsiq_ctx *c, size_t n, SrcKind kind, bool seeds)
 
 // Piece boundaries.  Nothing renders before the first piece is through pack, chain and evaluation (~0.15 ms of launches and
 // latencies however small it is), and its synthesis has to cover the chain kernels of what is left: a head worth ~0.35 ms of
-// synthesis, then pieces three times the one before.  GPSIQ_EVAL_HEAD (blocks; <= 0: one piece) for A/B, read per call.
+// synthesis, then pieces three times the one before.  GPSIQ_PIECE_BLOCKS (blocks of the first piece; <= 0: one piece) for A/B, read per call.
 void device_piece_ends(int nblocks, int nsamp, int nchan, std::vector<int> *ends)
 {
     const double t_block = (double) nsamp * (double) nchan / gpsiq_rate_kernel();
     long head = (long) (0.35e-3 / (t_block > 0.0 ? t_block : 1e-6)) + 1;
     if (head < 32) head = 32;
-    if (const char *e = std::getenv("GPSIQ_EVAL_HEAD")) head = std::atol(e);
+    if (const char *e = std::getenv("GPSIQ_PIECE_BLOCKS")) head = std::atol(e);
     if (head <= 0 || 2 * head > nblocks) { ends->push_back(nblocks); return; }
     long b = head, size = 3 * head;
     ends->push_back((int) b);
@@ -216,7 +225,10 @@ void gpsiq_evaldev_destroy(gpsiq_ctx *c)
     for (auto &ev_ : e.linked) if (ev_) (void) hipEventDestroy(ev_);
     for (auto &ev_ : e.evaluated) if (ev_) (void) hipEventDestroy(ev_);
     if (e.joined) (void) hipEventDestroy(e.joined);
+    if (e.t_synth0) (void) hipEventDestroy(e.t_synth0);
+    if (e.t_synth1) (void) hipEventDestroy(e.t_synth1);
     if (e.eval_stream) (void) hipStreamDestroy(e.eval_stream);
+    if (e.chain_stream) (void) hipStreamDestroy(e.chain_stream);
     e = gpsiq_ctx::EvalDev();
 }
 
@@ -227,6 +239,7 @@ static bool device_path_wanted(const gpsiq_ctx *c, int nblocks)
     const char *e = std::getenv("GPSIQ_EVAL");
     if (e && !std::strcmp(e, "host")) return false;
     if (e && !std::strcmp(e, "device")) return nblocks >= 1;
+    if (std::getenv("GPSIQ_CHAIN")) return false;          // where level 1 of the chain runs WITHIN the host evaluation: asks for that path
     return nblocks >= (c->nco_mode == GPSIQ_NCO_REFERENCE ? 48 : 64);
 }
 
@@ -283,10 +296,13 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
     std::vector<int> ends;
     device_piece_ends(nblocks, nsamp, nchan, &ends);
     const int npieces = (int) ends.size();
-    hipStream_t S = c->chain.stream, E = e.eval_stream;
+    hipStream_t S = e.chain_stream, E = e.eval_stream;
     ev::DChan *d_chan = static_cast<ev::DChan *>(e.d_chan), *h_chan = static_cast<ev::DChan *>(e.h_chan);
 
-    // ---- queue: control block, carries, then per piece pack (+ chain + link) and a snapshot of the control block -------------
+    // ---- phase A: per piece stage the rows, estimate (chain_prepare), quantise from the estimate, render ------------------------
+    // The synthesis of a piece waits for nothing but its own descriptors: in GPSIQ_NCO_REFERENCE they are seeded from
+    // chain_prepare's ESTIMATE of every block's start state (good to ~1e-11 cycle), and what the double path from the TRUE start
+    // state does differently goes into the patch list when the chain has been linked (phase B), beside the running synthesis.
     EvalCtrl zero;
     std::memset(&zero, 0, sizeof zero);
     zero.err_key = ~0ull;
@@ -301,12 +317,21 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
         HIP_TRY(hipMemcpyAsync(e.d_fix, e.h_fix, (size_t) nchan * sizeof(FixedCarry), hipMemcpyHostToDevice, S));
     }
     if (seeds) HIP_TRY(hipMemcpyAsync(e.d_seeds, seeds, n * sizeof(double), hipMemcpyHostToDevice, S));
+    const bool chained = reference && !seeds;
+    // where a block's descriptor takes its carrier phase from: Prep::est (32-byte rows, the double at offset 8), or the caller's states
+    const char *est_rows = seeds ? reinterpret_cast<const char *>(e.d_seeds) : static_cast<const char *>(c->chain.d_prep) + 8;
+    const int est_stride = seeds ? 8 : 32;
     PackJob pj = {ch, h_chan, nullptr, nchan, delt, 0, 0, 0};
-    uint64_t host_mx[kEvalMaxPieces] = {};
-    int host_active[kEvalMaxPieces] = {};
-    long host_amp[kEvalMaxPieces] = {};
     hipError_t he = hipSuccess;
-    for (int k = 0; k < npieces && he == hipSuccess; ++k) {
+    char err[400] = "";
+    int max_active = 0;
+    long max_amp = 0;
+    uint64_t max_step = 0;
+    int copies = 0;
+    double t_first_launch = 0.0;
+    int timed_blocks = 0;
+    hipEvent_t *staged = e.evaluated;                       // [k]: piece k's descriptors are in the set (and a snapshot of the control block behind them)
+    for (int k = 0; k < npieces && rc == GPSIQ_OK; ++k) {
         const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
         const size_t off = (size_t) b0 * nchan, cnt = (size_t) nb * nchan;
         if (kind == kSrcDevice) he = launch_pack_raw(static_cast<const gpsiq_chan_t *>(dev_src) + off, nb, nchan, delt, d_chan + off, e.d_ctrl, S);
@@ -323,44 +348,86 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
             e.host_ms += gpsiq_wall_ms() - tp;
             he = hipMemcpyAsync(d_chan + off, h_chan + off, cnt * sizeof(ev::DChan), hipMemcpyHostToDevice, S);
         }
-        host_mx[k] = pj.mx; host_active[k] = pj.max_active; host_amp[k] = pj.max_amp;
-        if (he == hipSuccess && reference && !seeds) {
-            int max_seg = 32;
-            if (const char *s = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(s); if (v >= 1 && v <= 32) max_seg = v; }
-            he = launch_chain(d_chan + off, (int) sizeof(ev::DChan), nb, nchan, delt, nsamp, k ? c->chain.d_est + (size_t) k * GPSIQ_MAX_CHAN : nullptr, max_seg,
+        if (he == hipSuccess && chained)
+            he = launch_chain(d_chan + off, (int) sizeof(ev::DChan), nb, nchan, delt, nsamp, k ? c->chain.d_est + (size_t) k * GPSIQ_MAX_CHAN : nullptr, 0,
                               static_cast<char *>(c->chain.d_prep) + off * 32, c->chain.d_c_before + (size_t) k * GPSIQ_MAX_CHAN,
-                              c->chain.d_est + (size_t) (k + 1) * GPSIQ_MAX_CHAN, c->chain.d_maps + off, S);
-            if (he == hipSuccess) he = launch_link_scan(d_chan, c->chain.d_maps, b0, nb, nchan, delt, e.d_link, e.d_ctrl, k, S);
+                              c->chain.d_est + (size_t) (k + 1) * GPSIQ_MAX_CHAN, c->chain.d_maps + off, S, 1);
+        if (he == hipSuccess) {
+            if (reference) he = launch_quantize_est(d_chan, b0, nb, nchan, delt, nsamp, est_rows, est_stride, nb_.d, e.d_ctrl, S);
+            else he = launch_quantize_fixed(d_chan, b0, nb, nchan, delt, nsamp, nb_.d, e.d_fix, e.d_ctrl, S);
         }
-        if (he == hipSuccess) he = hipMemcpyAsync(&e.h_ctrl[k], e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, S);
-        if (he == hipSuccess) he = hipEventRecord(e.linked[k], S);
+        if (he == hipSuccess && kind != kSrcPageable) he = hipMemcpyAsync(&e.h_ctrl[k], e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, S);
+        if (he == hipSuccess) he = hipEventRecord(staged[k], S);
+        // the launch parameters of the synthesis kernel: from the pool's pack at once, from the device's pack behind the event
+        if (he == hipSuccess && kind != kSrcPageable) he = hipEventSynchronize(staged[k]);
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d: %s", k, hipGetErrorString(he)); break; }
+        if (kind == kSrcPageable) { max_step = pj.mx; max_active = pj.max_active; max_amp = pj.max_amp; }
+        else {
+            const EvalCtrl &ck = e.h_ctrl[k];
+            max_step = std::max<uint64_t>(max_step, ck.max_code_step); max_active = std::max(max_active, ck.max_active); max_amp = std::max<long>(max_amp, (long) ck.max_amp);
+        }
+        hipStream_t s = gpsiq_piece_stream(c, k);
+        he = hipStreamWaitEvent(s, staged[k], 0);
+        if (he == hipSuccess) {
+            const int v = max_step <= kRowsMaxCodeStep ? kSeg : max_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
+            uint8_t *dev = direct ? static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes : static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
+            // the last piece's synthesis is timed: the rate the piece sizes are planned with is a measured one (gpsiq_note_kernel_rate)
+            if (k == npieces - 1) (void) hipEventRecord(e.t_synth0, s);
+            he = launch_variant(v, nb_.d, nchan, nsamp, sample_size, dev, stride, b0, nb, c->d_tab, s, max_active > 0 ? max_active : 1, max_amp, nullptr);
+            if (k == npieces - 1) { (void) hipEventRecord(e.t_synth1, s); timed_blocks = nb; }
+            if (trace && k == 0) t_first_launch = gpsiq_wall_ms() - t0;
+            if (he == hipSuccess && !direct && !reference) {
+                // (reference mode copies out after the patches; the fixed model's pieces are final as rendered)
+                hipStream_t cs = c->copy_stream[copies & 1];
+                he = hipEventRecord(c->chunk_done[copies & 1], s);
+                if (he == hipSuccess) he = hipStreamWaitEvent(cs, c->chunk_done[copies & 1], 0);
+                const hipMemcpyKind kd = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+                if (he == hipSuccess) {
+                    if (stride == blk_bytes) he = hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, dev, blk_bytes * (size_t) nb, kd, cs);
+                    else he = hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, dev, stride, blk_bytes, (size_t) nb, kd, cs);
+                }
+                ++copies;
+            }
+        }
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d launch: %s", k, hipGetErrorString(he)); }
     }
-    char err[400] = "";
-    if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, queueing: %s", hipGetErrorString(he)); }
     const double t_queued = gpsiq_wall_ms();
 
-    // ---- per piece: wait for its link, repair, evaluate, render ---------------------------------------------------------------
+    // ---- phase B (GPSIQ_NCO_REFERENCE): the chain, piece by piece behind the descriptors; repair; the evaluation --------------------
     bool host_owned[GPSIQ_MAX_CHAN] = {};
     double host_end[GPSIQ_MAX_CHAN] = {};
     int host_last_prn[GPSIQ_MAX_CHAN] = {};
-    int max_active = 0;
-    long max_amp = 0;
-    uint64_t max_step = 0;
-    int copies = 0;
-    double t_first_launch = 0.0;
-    for (int k = 0; k < npieces && rc == GPSIQ_OK; ++k) {
+    if (rc == GPSIQ_OK && chained) {
+        int max_seg = 32;
+        if (const char *sv = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(sv); if (v >= 1 && v <= 32) max_seg = v; }
+        for (int k = 0; k < npieces && he == hipSuccess; ++k) {
+            const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+            const size_t off = (size_t) b0 * nchan;
+            he = launch_chain(d_chan + off, (int) sizeof(ev::DChan), nb, nchan, delt, nsamp, nullptr, max_seg, static_cast<char *>(c->chain.d_prep) + off * 32,
+                              c->chain.d_c_before + (size_t) k * GPSIQ_MAX_CHAN, nullptr, c->chain.d_maps + off, S, 2);
+#ifdef GPSIQ_TEST_HOOKS          // fault injection (tests/test_gpu_verify.py builds a library with it): one map made wrong without making it unusable
+            if (he == hipSuccess) he = launch_test_corrupt_map(c->chain.d_maps, b0, nb, nchan, S);
+#endif
+            if (he == hipSuccess) he = launch_link_scan(d_chan, c->chain.d_maps, b0, nb, nchan, delt, e.d_link, e.d_ctrl, k, S);
+            if (he == hipSuccess) he = hipMemcpyAsync(&e.h_ctrl[k], e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, S);
+            if (he == hipSuccess) he = hipEventRecord(e.linked[k], S);
+        }
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, chain: %s", hipGetErrorString(he)); }
+    }
+    for (int k = 0; k < npieces && rc == GPSIQ_OK && reference; ++k) {
         const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
-        he = hipEventSynchronize(e.linked[k]);
-        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d: %s", k, hipGetErrorString(he)); break; }
-        const EvalCtrl &ck = e.h_ctrl[k];
-        if (reference && !seeds) {
+        if (chained) {
+            he = hipEventSynchronize(e.linked[k]);
+            if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d: %s", k, hipGetErrorString(he)); break; }
+            const EvalCtrl &ck = e.h_ctrl[k];
             bool need = false;
             for (int i = 0; i < nchan; ++i) need = need || ck.unknown[k][i] > 0 || host_owned[i];
             if (need) {
                 // A block whose certified map does not apply (a slow block, a sign change, a range the estimate missed): the host
                 // walker takes that slot from this piece on -- the piece's maps and rows come back, the slot is linked / walked from
                 // the state it enters the piece with (lane::link_block + the true walk, as rounds 4-5 did for every slot), and its
-                // start states go back up before the piece is evaluated.  The device's own scan goes on for the other slots.
+                // start states go back up before the piece is evaluated.  The device's own scan goes on for the other slots, and
+                // the synthesis is not held up: it runs from the estimates.
                 const double tr = gpsiq_wall_ms();
                 const size_t off = (size_t) b0 * nchan, cnt = (size_t) nb * nchan;
                 const size_t lead = b0 > 0 ? (size_t) nchan : 0;                   // the row before the piece too: which satellite each slot had
@@ -373,7 +440,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
                     if (!(ck.unknown[k][i] > 0 || host_owned[i])) continue;
                     if (!host_owned[i]) {
                         // the state the slot enters the piece with: the scan knew every start up to its first block that does not link
-                        host_last_prn[i] = b0 > 0 && h_chan[off - nchan + i].prn > 0 ? h_chan[off - nchan + i].prn : 0;      
+                        host_last_prn[i] = b0 > 0 && h_chan[off - nchan + i].prn > 0 ? h_chan[off - nchan + i].prn : 0;
                         host_end[i] = h_chan[off + i].start;
                     }
                     long linked = 0, walked = 0;
@@ -393,38 +460,55 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
                 if (rc != GPSIQ_OK) break;
             }
         }
-        // launch parameters: everything packed up to and including this piece
-        max_step = std::max<uint64_t>(max_step, std::max<uint64_t>(ck.max_code_step, host_mx[k]));
-        max_active = std::max(max_active, std::max(ck.max_active, host_active[k]));
-        max_amp = std::max(max_amp, std::max<long>((long) ck.max_amp, host_amp[k]));
-        he = hipStreamWaitEvent(E, e.linked[k], 0);
-        if (he == hipSuccess) {
-            if (reference) he = launch_eval(d_chan, b0, nb, nchan, delt, nsamp, c->d_tab, nb_.d, e.d_patches, e.patch_cap, e.d_host, e.host_cap, e.d_ctrl,
-                                            seeds ? e.d_seeds : nullptr, E);
-            else he = launch_quantize_fixed(d_chan, b0, nb, nchan, delt, nsamp, nb_.d, e.d_fix, e.d_ctrl, E);
-        }
-        if (he == hipSuccess) he = hipEventRecord(e.evaluated[k], E);
-        hipStream_t s = gpsiq_piece_stream(c, k);
-        if (he == hipSuccess) he = hipStreamWaitEvent(s, e.evaluated[k], 0);
-        if (he == hipSuccess) {
-            const int v = max_step <= kRowsMaxCodeStep ? kSeg : max_step <= kHalfRowsMaxCodeStep ? kSegHalf : kGeneric;
-            uint8_t *dev = direct ? static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes : static_cast<uint8_t *>(c->d_out) + (size_t) b0 * stride;
-            he = launch_variant(v, nb_.d, nchan, nsamp, sample_size, dev, stride, b0, nb, c->d_tab, s, max_active > 0 ? max_active : 1, max_amp, nullptr);
-            if (trace && k == 0) t_first_launch = gpsiq_wall_ms() - t0;
-            if (he == hipSuccess && !direct && !reference) {
-                // (reference mode copies out after the patches; the fixed model's pieces are final as rendered)
-                hipStream_t cs = c->copy_stream[copies & 1];
-                he = hipEventRecord(c->chunk_done[copies & 1], s);
-                if (he == hipSuccess) he = hipStreamWaitEvent(cs, c->chunk_done[copies & 1], 0);
-                const hipMemcpyKind kd = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-                if (he == hipSuccess) {
-                    if (stride == blk_bytes) he = hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, dev, blk_bytes * (size_t) nb, kd, cs);
-                    else he = hipMemcpy2DAsync(static_cast<uint8_t *>(dst) + (size_t) b0 * blk_bytes, blk_bytes, dev, stride, blk_bytes, (size_t) nb, kd, cs);
-                }
-                ++copies;
+        he = hipStreamWaitEvent(E, chained ? e.linked[k] : staged[k], 0);
+        if (he == hipSuccess)
+            he = launch_eval(d_chan, b0, nb, nchan, delt, nsamp, c->d_tab, est_rows, est_stride, e.d_patches, e.patch_cap, e.d_host, e.host_cap, e.d_ctrl,
+                             seeds ? e.d_seeds : nullptr, E);
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d evaluation: %s", k, hipGetErrorString(he)); }
+    }
+
+    // ---- GPSIQ_CHAIN_VERIFY=N: every N-th block that went through its certified map is also walked serially ---------------------
+    // (on host threads, from the start state the scan gave it, while the device renders: gps.c:2821-2826 is the judge)
+    const int verify_n = reference && !seeds ? chain_verify_every() : 0;
+    unsigned verified = 0;
+    if (rc == GPSIQ_OK && verify_n > 0) {
+        const double tv = gpsiq_wall_ms();
+        he = hipMemcpyAsync(h_chan, d_chan, n * sizeof(ev::DChan), hipMemcpyDeviceToHost, E);
+        if (he == hipSuccess) he = hipMemcpyAsync(e.h_link, e.d_link, (size_t) nchan * sizeof(LinkCarry), hipMemcpyDeviceToHost, E);
+        if (he == hipSuccess) he = hipStreamSynchronize(E);
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, verify: %s", hipGetErrorString(he)); }
+        else {
+            struct VJob { const ev::DChan *ch; const LinkCarry *end; const bool *skip; int nblocks, nchan, nsamp, every; double delt; long bad; unsigned count; };
+            VJob vj = {h_chan, e.h_link, host_owned, nblocks, nchan, nsamp, verify_n, delt, -1, 0};
+            parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
+                VJob &j = *static_cast<VJob *>(p);
+                unsigned count = 0;
+                for (int b = b0; b < b1; ++b)
+                    for (int i = 0; i < j.nchan; ++i) {
+                        if ((b + i) % j.every || j.skip[i]) continue;
+                        const ev::DChan &d = j.ch[(size_t) b * j.nchan + i];
+                        if (d.prn <= 0 || !(d.start >= 0.0 && d.start <= 1.0) || !(std::fabs(d.f_carr * j.delt) < 0.5)) continue;
+                        double want;
+                        if (b + 1 < j.nblocks) {
+                            const ev::DChan &nx = j.ch[(size_t) (b + 1) * j.nchan + i];
+                            if (nx.prn != d.prn) continue;                       // the slot ends or is re-seeded: nobody reads this block's end
+                            want = nx.start;
+                        } else if (j.end[i].known) want = j.end[i].y;
+                        else continue;
+                        const double got = chain_block_true(d.f_carr, j.delt, j.nsamp, d.start);
+                        ++count;
+                        if (bits_of(got) != bits_of(want)) __sync_val_compare_and_swap(&j.bad, -1L, (long) b * j.nchan + i);
+                    }
+                __sync_fetch_and_add(&j.count, count);
+            }, &vj);
+            verified = vj.count;
+            if (vj.bad >= 0) {
+                rc = GPSIQ_E_VERIFY;
+                std::snprintf(err, sizeof err, "block %ld slot %ld: the state after the block through its certified map is not the serial walk's (GPSIQ_CHAIN_VERIFY=%d)",
+                              vj.bad / nchan, vj.bad % nchan, verify_n);
             }
         }
-        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d launch: %s", k, hipGetErrorString(he)); }
+        e.host_ms += gpsiq_wall_ms() - tv;
     }
 
     // ---- the end of the evaluation: errors, the host walker's share, the patches -----------------------------------------------
@@ -489,7 +573,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
                     if (kind == kSrcDevice) (void) hipMemcpy(&one, ch + flat, sizeof one, hipMemcpyDeviceToHost);
                     else one = ch[flat];
                     gpsiq_qchan_t q;
-                    const int erc = eval_block_host(one, h.start, delt, nsamp, (int) h.block, (int) h.slot, &q, &patches);
+                    const int erc = eval_block_host(one, h.start, &h.seed, delt, nsamp, (int) h.block, (int) h.slot, &q, &patches);
                     if (erc != GPSIQ_OK) { rc = erc; std::snprintf(err, sizeof err, "block %u: %.280s", h.block, gpsiq_last_error()); }
                 }
             }
@@ -533,6 +617,11 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
         for (hipError_t d : {d0, d1, d2, d3, d4, d5})
             if (d != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation: %s", hipGetErrorString(d)); break; }
     if (rc != GPSIQ_OK) return fail(rc, "%s", err);
+    if (timed_blocks > 0) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.t_synth0, e.t_synth1) == hipSuccess && ms > 0.02f)
+            gpsiq_note_kernel_rate((double) timed_blocks * (double) nsamp * (double) nchan / (ms * 1e-3));
+    }
     if (fall_back) {
         // the lists overflowed: the host path does the whole call again (dst is rewritten)
         __atomic_fetch_add(&g_evd_stats[5], 1, __ATOMIC_RELAXED);
@@ -568,8 +657,8 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
     __atomic_fetch_add(&g_evd_stats[4], (uint64_t) npatch_total, __ATOMIC_RELAXED);
     if (trace)
         std::fprintf(stderr, "[gpsiq trace] device evaluation (%s, descriptors %s), %d blocks in %d pieces (head %d): queued by %.3f ms, first synthesis launched at %.3f ms, "
-                             "draining from %.3f ms, whole call %.3f ms; host stages %.3f ms; %u patches, %u channels to the host walker, %u slots repaired\n",
+                             "draining from %.3f ms, whole call %.3f ms; host stages %.3f ms; %u patches, %u channels to the host walker, %u slots repaired, %u blocks verified\n",
                      reference ? "reference NCO" : "fixed-point NCO", kind == kSrcDevice ? "in device memory" : kind == kSrcPinned ? "page-locked" : "pageable (packed by the pool)",
-                     nblocks, npieces, ends[0], t_queued - t0, t_first_launch, t_drain - t0, gpsiq_wall_ms() - t0, e.host_ms, (unsigned) npatch_total, fin.nhost, e.last_repaired);
+                     nblocks, npieces, ends[0], t_queued - t0, t_first_launch, t_drain - t0, gpsiq_wall_ms() - t0, e.host_ms, (unsigned) npatch_total, fin.nhost, e.last_repaired, verified);
     return GPSIQ_OK;
 }

@@ -558,9 +558,8 @@ struct NcoWalk : WalkCore<64> {
             }
         };
         // few cycles in the block: the table would never be read
-        static const bool no_map = std::getenv("GPSIQ_WALK_NOMAP") != nullptr;      // A/B knob: every cycle walked
         const double span = kind == 0 ? (double) GPSIQ_CA_SEQ_LEN : 1.0;
-        const bool use_map = !no_map && std::fabs(c) * (double) ns > 24.0 * span;
+        const bool use_map = std::fabs(c) * (double) ns > 24.0 * span;
         if (!use_map) {
             visit(x, n, ns);
             while (n < ns && cycle(x, n, ns)) {}
@@ -588,7 +587,7 @@ struct NcoWalk : WalkCore<64> {
         long min_steps = ns;                                          // shortest cycle seen
         int64_t m = (int64_t) (x * scale);                            // exact: the state is a multiple of the unit
 #if defined(__x86_64__)
-        static const bool wide = __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512f") && !std::getenv("GPSIQ_WALK_NOBATCH");
+        static const bool wide = __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512f");
 #endif
         // an entry for the cycle walked from state ms to state m2 in ne samples, valid for start states ms + [lo, hi]
         auto add_entry = [&](int64_t ms, int64_t m2, long ne, int64_t elo, int64_t ehi) {
@@ -872,16 +871,23 @@ static inline double chain_block(double f_carr, double delt, int nsamp, double s
 // walked (from the block's start, to the last undecided sample).
 // slot_of: the block's descriptors up to this channel (blk[0 .. i]), or null with `slot` given: the device order counts the
 // active channels before this one (gpsiq_set_descriptors), which is only looked up when a patch is written.
+// seed_override: the fixed-point carrier phase the descriptor is seeded with instead of the one cut from `start` (the device
+// renders from an ESTIMATE of the start state and learns the true one later, gpsiq_evaldev.cpp): the closed form then runs
+// |seed - fixed(start)| units beside the one seeded from the truth, the candidate window is that much wider, and the patches are
+// what the double path from the TRUE start takes against that closed form.
 static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int nsamp, int block, int slot,
                       CodeCache *codes, gpsiq_qchan_t *qq, std::vector<gpsiq_patch_t> *out, bool no_drift = false,
-                      const gpsiq_chan_t *blk = nullptr, int i_in_blk = 0)
+                      const gpsiq_chan_t *blk = nullptr, int i_in_blk = 0, const uint64_t *seed_override = nullptr)
 {
     const gpsiq_chan_t &ch = ch_in;
     // a start of exactly 1.0 (a wrap of the block before that rounded up to one) is phase 0 of the closed form (mod 1); the
     // reference goes on from 1.0, and sample 0, where it indexes its table at 512, is patched.  The start state replaces the
     // descriptor's own carr_phase (handed to the quantiser as the carried phase: the 296-byte descriptor is not copied)
     if (!(start >= 0.0 && start <= 1.0)) return fail(GPSIQ_E_RANGE, "prn %d: start phase %g outside [0, 1]", ch.prn, start);
-    const uint64_t seeded = carr_phase_to_fixed(start == 1.0 ? 0.0 : start);
+    const uint64_t seeded_true = carr_phase_to_fixed(start == 1.0 ? 0.0 : start);
+    const uint64_t seeded = seed_override ? (*seed_override & ((UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1)) : seeded_true;
+    uint64_t seed_off = (seeded_true - seeded) & ((UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - 1);       // |difference| mod 2^59
+    if (seed_off > (UINT64_C(1) << (GPSIQ_CARR_FRAC_BITS - 1))) seed_off = (UINT64_C(1) << GPSIQ_CARR_FRAC_BITS) - seed_off;
     int qrc;
     if (ch.carr_phase >= 0.0 && ch.carr_phase < 1.0) qrc = quantize_one(ch, delt, nsamp, &seeded, qq, nullptr);
     else {                         // the descriptor's own phase is the 1.0 the reference handed back (or garbage): not the quantiser's business here
@@ -895,7 +901,7 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
     if (ns <= 0) return GPSIQ_OK;
     const double carr_inc = ch.f_carr * delt, code_inc = ch.f_code * delt;
     // drift bounds at the end of the block, in units of the fixed-point formats (see the header)
-    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4;
+    const uint64_t w_carr = ((uint64_t) ns << (GPSIQ_CARR_FRAC_BITS - 54)) + (uint64_t) ns / 2 + 4 + seed_off;
     const uint64_t w_code = ((uint64_t) ns << (GPSIQ_CODE_FRAC_BITS - 44)) + (uint64_t) ns / 2 + 4;
     // scratch that keeps its capacity from block to block (an evaluation task runs thousands of these back to back)
     static thread_local std::vector<long> t_carr, t_code, open_c, open_k;
@@ -904,7 +910,7 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
     t_carr.clear(); t_code.clear(); open_c.clear(); open_k.clear();
     constexpr size_t kCap = 256;
     bool every = false;
-    if (carr_inc != 0.0)          // a zero addend leaves both paths constant and equal
+    if (carr_inc != 0.0 || seed_off != 0)          // a zero addend leaves both paths constant, and equal when seeded alike
         every |= !candidates(q.carr_phase, (uint64_t) q.carr_step, GPSIQ_CARR_FRAC_BITS - 9, w_carr, ns, kCap, &t_carr);
     every |= !candidates(q.code_frac, q.code_step, GPSIQ_CODE_FRAC_BITS, w_code, ns, kCap, &t_code);
     if (every) {                  // too many to list (a sample rate far outside the format's design range): every sample, both accumulators
@@ -1001,12 +1007,21 @@ static int eval_block(const gpsiq_chan_t &ch_in, double start, double delt, int 
 
 double chain_block_true(double f_carr, double delt, int nsamp, double start) { return chain_block(f_carr, delt, nsamp, start); }
 
+// GPSIQ_CHAIN_VERIFY=N (read per call): every N-th block linked through its certified map is also walked serially from the same
+// start state and must end on the same double; 0 / unset: off
+int chain_verify_every()
+{
+    const char *e = std::getenv("GPSIQ_CHAIN_VERIFY");
+    const int n = e ? std::atoi(e) : 0;
+    return n > 0 ? n : 0;
+}
+
 // one channel of one block for the device path (gpsiq_evaldev.cpp): the (block, channel) pairs its enclosure cannot decide
-int eval_block_host(const gpsiq_chan_t &ch, double start, double delt, int nsamp, int block, int slot, gpsiq_qchan_t *q,
+int eval_block_host(const gpsiq_chan_t &ch, double start, const uint64_t *seed, double delt, int nsamp, int block, int slot, gpsiq_qchan_t *q,
                     std::vector<gpsiq_patch_t> *out)
 {
     CodeCache codes;
-    return eval_block(ch, start, delt, nsamp, block, slot, &codes, q, out);
+    return eval_block(ch, start, delt, nsamp, block, slot, &codes, q, out, false, nullptr, 0, seed);
 }
 
 // ---- the host side of GPSIQ_NCO_REFERENCE as tasks ---------------------------------------------------------------
@@ -1088,8 +1103,18 @@ void RefWalk::chain_task(int i, size_t k)
             continue;
         }
         double y;
-        if (maps && chain_step_mapped(maps, at, c, &y)) { c = y; ++linked; }
-        else { c = chain_block(f_carr, delt, nsamp, c); ++walked; }
+        if (maps && chain_step_mapped(maps, at, c, &y)) {
+            // GPSIQ_CHAIN_VERIFY=N: every N-th block that went through its map is also walked from the same start state
+            if (verify_every > 0 && (b + i) % verify_every == 0) {
+                const double yw = chain_block(f_carr, delt, nsamp, c);
+                if (bits_of(yw) != bits_of(y)) {
+                    char msg[160];
+                    std::snprintf(msg, sizeof msg, "slot %d: the certified map ends on %.17g, the serial walk on %.17g", i, y, yw);
+                    set_error(GPSIQ_E_VERIFY, msg, b);
+                }
+            }
+            c = y; ++linked;
+        } else { c = chain_block(f_carr, delt, nsamp, c); ++walked; }
     }
     carr[i] = c; prev[i] = pv;
     if (maps) chain_count(linked, walked);
@@ -1202,6 +1227,7 @@ void RefWalk::run()
     // a block or two (the drop-in block call): 16 channels x a few microseconds cost less than waking the pool
     const int want = nblocks <= 2 ? 1 : (chain_only || seeds ? nchan : 2 * nchan);
     no_drift = std::getenv("GPSIQ_NO_DRIFT") != nullptr;      // A/B + test knob, read per call: every candidate walked
+    verify_every = chain_verify_every();
     const bool trace = std::getenv("GPSIQ_TRACE") != nullptr;
     if (trace && want > 1 && host_threads() < nchan)
         std::fprintf(stderr, "[gpsiq trace] reference NCO: %d host threads for %d channels: pieces are worked through piece-major\n", host_threads(), nchan);

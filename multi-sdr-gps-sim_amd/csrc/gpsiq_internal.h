@@ -87,6 +87,7 @@ private:
     std::unique_ptr<std::atomic<int>[]> done;
     std::atomic<bool> abort_flag{false};
     bool no_drift = false;                        // GPSIQ_NO_DRIFT: walk every candidate (A/B and tests)
+    int  verify_every = 0;                        // GPSIQ_CHAIN_VERIFY
     // scheduler state, under mu
     size_t chain_next[GPSIQ_MAX_CHAN], eval_next[GPSIQ_MAX_CHAN];
     bool   chain_busy[GPSIQ_MAX_CHAN];
@@ -100,6 +101,7 @@ private:
 bool chain_step_mapped(const void *maps, size_t at, double x, double *next);
 void chain_prefetch_map(const void *maps, size_t at);
 void chain_count(long linked, long walked);
+int  chain_verify_every();                        // GPSIQ_CHAIN_VERIFY=N: every N-th linked block is also walked; 0: off
 
 // Host threads this process may use: online CPUs, capped by GPSIQ_THREADS (read once).
 int host_threads();

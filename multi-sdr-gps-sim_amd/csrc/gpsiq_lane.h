@@ -236,10 +236,10 @@ GPSIQ_HD inline void build_cycle(const Walker &W, int k, int nent, Cycle *out)
 }
 
 // the entry that holds post-wrap state x, or null: the entry sampled nearest to x first, then its neighbours
-GPSIQ_HD inline const Cycle *find_cycle(const Cycle *tab, int nent, const Walker &W, double x)
+// (scale = nent / |c|, base = the lower end of the post-wrap states: once per stretch, a division costs the device thirty instructions)
+GPSIQ_HD inline const Cycle *find_cycle(const Cycle *tab, int nent, double base, double scale, double x)
 {
-    const double a = __builtin_fabs(W.c);
-    int k0 = (int) ((x - (W.neg ? 1.0 - a : 0.0)) / a * (double) nent);
+    int k0 = (int) ((x - base) * scale);
     if (k0 < 0) k0 = 0;
     if (k0 >= nent) k0 = nent - 1;
     for (int d = 0; d < nent; ++d) {
@@ -300,10 +300,11 @@ GPSIQ_HD inline void walk_stretch(const Walker &W, const Walker *Wp, const Prep 
     // Two loops, for the device's sake: inside, a lane looks up cycle after cycle for as long as the table knows them (a dozen
     // instructions each); outside, ONE cycle is walked (a thousand instructions) by the lanes that met a state no entry covers
     // -- 2 % of the look-ups, so with one loop every round of a 64-lane wave would have a lane walking and 63 waiting for it.
+    const double tab_a = __builtin_fabs(W.c), tab_base = W.neg ? 1.0 - tab_a : 0.0, tab_scale = tab ? (double) nent / tab_a : 0.0;
     bool done = false;
     while (!done) {
         while (at_wrap && tab && n < a1) {
-            const Cycle *e = find_cycle(tab, nent, W, x);
+            const Cycle *e = find_cycle(tab, nent, tab_base, tab_scale, x);
             if (!e) break;
             sl.room_below(x - e->first);             // this state is one the entry holds for; how far it may move
             sl.room_above(e->last - x);
@@ -365,8 +366,96 @@ GPSIQ_HD inline void join_stretches(const Stretch *st, int nseg, bool neg, Rec *
     }
     if (r.ok && st[0].sigma) { r.lo += grid; r.hi -= grid; }
     if (r.ok && r.lo > r.hi) { r.ok = 0; why = kWhyRange; }
+    if (!r.ok) { r.cum[0] = 0; r.cum[1] = 0; r.lo = 0; r.hi = 0; }      // (nobody reads them: the same bytes whoever joined)
     r.info = (int32_t) grid | (r.ok ? 0 : why << 8);
     *rec = r;
+}
+
+// ---- the join as a scan: what join_stretches does stretch after stretch, for one lane per stretch ---------------------------
+// In steps of the wrap's grid a stretch moves the offset o of its start to that of the next stretch's: o -> o + D, and an odd
+// offset goes sigma steps aside where the stretch met an exact tie -- a translation that depends on the parity of o only, so the
+// stretches compose as pairs (the translation for an even / an odd offset before them) and every stretch learns both branches'
+// offsets from an exclusive scan.  Ranges, closed branches and the first thing that stood in the way are reductions over the
+// stretches.  The device runs scan and reductions with cross-lane moves (gpsiq_chain_kernels.hip); join_stretches_scan below is
+// the same arithmetic in a loop, held against join_stretches block for block by tests/chain_parallel.cpp.
+struct JoinMap { int64_t t0, t1; };
+GPSIQ_HD inline JoinMap join_identity() { JoinMap m; m.t0 = 0; m.t1 = 0; return m; }
+GPSIQ_HD inline JoinMap join_compose(const JoinMap &a, const JoinMap &b)      // first a, then b
+{
+    JoinMap o;
+    o.t0 = a.t0 + ((a.t0 & 1) ? b.t1 : b.t0);
+    o.t1 = a.t1 + (((1 + a.t1) & 1) ? b.t1 : b.t0);
+    return o;
+}
+struct JoinLane { JoinMap el; int64_t D; int32_t fail, pad; };
+// stretch t (cur) after stretch t - 1 (prev; unused for t == 0); grid: units of U per step of the wrap's grid
+GPSIQ_HD inline JoinLane join_lane(const Stretch &prev, const Stretch &cur, int t, int64_t grid)
+{
+    JoinLane j;
+    j.D = 0; j.fail = 0; j.pad = 0;
+    if (!cur.ok) j.fail = cur.why ? (int32_t) cur.why : (int32_t) kWhyEdge;
+    else if (t > 0) {
+        int64_t d = 0;
+        if (prev.n_out != cur.n_in) j.fail = kWhyJoin;
+        else if (!exact_units(prev.x_out, cur.r_in, &d) || (d & (grid - 1))) j.fail = kWhyUnits;
+        else j.D = grid == 2 ? d >> 1 : d;              // (d is a multiple of the grid)
+    }
+    const int64_t sg = cur.sigma > 0 ? 1 : cur.sigma < 0 ? -1 : 0;
+    j.el.t0 = j.D + ((j.D & 1) ? sg : 0);
+    j.el.t1 = j.D + (((1 + j.D) & 1) ? sg : 0);
+    return j;
+}
+struct JoinTerm { int64_t l, h; int32_t mask, pad; };
+// excl: the stretches before t composed (identity for t == 0)
+GPSIQ_HD inline JoinTerm join_term(const JoinMap &excl, const JoinLane &j, const Stretch &cur, int t, int64_t grid)
+{
+    JoinTerm o;
+    const int64_t m0 = excl.t0 + j.D, m1 = 1 + excl.t1 + j.D;                   // the stretch's offset in either branch, in grid steps
+    o.mask = 3; o.pad = 0;
+    if (cur.ok == 2) { if (m0 & 1) o.mask &= ~1; if (m1 & 1) o.mask &= ~2; }
+    if (t == 0) { o.l = cur.lo; o.h = cur.hi; }
+    else {
+        const int64_t c0 = m0 * grid, c1 = (m1 - 1) * grid;                     // cum[0], cum[1] of join_stretches at this point
+        const int64_t cmin = c0 < c1 ? c0 : c1, cmax = c0 < c1 ? c1 : c0;
+        o.l = cur.lo - cmin + grid; o.h = cur.hi - cmax - grid;
+    }
+    return o;
+}
+// the reductions' results -> the map.  incl: all stretches composed; first_fail: the smallest (t << 8 | fail) of a stretch with
+// fail != 0 (or INT32_MAX); first_closed: the first stretch at which both branches are closed (or INT32_MAX)
+GPSIQ_HD inline void join_finish(const Stretch &st0, double x_end, bool neg, const JoinMap &incl, int64_t lo, int64_t hi, int mask,
+                                 int32_t first_fail, int32_t first_closed, Rec *rec)
+{
+    Rec r;
+    const int64_t grid = neg ? 1 : 2;
+    r.xs = st0.r_in; r.e = x_end; r.cum[0] = incl.t0 * grid; r.cum[1] = incl.t1 * grid; r.lo = lo; r.hi = hi; r.ok = mask;
+    int why = kWhyNone;
+    const int32_t t_fail = first_fail == INT32_MAX ? INT32_MAX : first_fail >> 8;
+    if (t_fail != INT32_MAX && t_fail <= first_closed) { r.ok = 0; why = first_fail & 0xff; }     // (a stretch is looked at before its ties are)
+    else if (first_closed != INT32_MAX) { r.ok = 0; why = kWhyParity; }
+    if (r.ok && st0.sigma) { r.lo += grid; r.hi -= grid; }
+    if (r.ok && r.lo > r.hi) { r.ok = 0; why = kWhyRange; }
+    if (!r.ok) { r.cum[0] = 0; r.cum[1] = 0; r.lo = 0; r.hi = 0; }
+    r.info = (int32_t) grid | (r.ok ? 0 : why << 8);
+    *rec = r;
+}
+GPSIQ_HD inline void join_stretches_scan(const Stretch *st, int nseg, bool neg, Rec *rec)
+{
+    const int64_t grid = neg ? 1 : 2;
+    JoinMap pre = join_identity();
+    int64_t lo = INT64_MIN, hi = INT64_MAX;
+    int mask = 3;
+    int32_t first_fail = INT32_MAX, first_closed = INT32_MAX;
+    for (int t = 0; t < nseg; ++t) {
+        const JoinLane j = join_lane(st[t > 0 ? t - 1 : 0], st[t], t, grid);
+        const JoinTerm q = join_term(pre, j, st[t], t, grid);
+        if (j.fail && first_fail == INT32_MAX) first_fail = t << 8 | j.fail;
+        lo = q.l > lo ? q.l : lo; hi = q.h < hi ? q.h : hi;
+        mask &= q.mask;
+        if (!mask && first_closed == INT32_MAX) first_closed = t;
+        pre = join_compose(pre, j.el);
+    }
+    join_finish(st[0], st[nseg - 1].x_end, neg, pre, lo, hi, mask, first_fail, first_closed, rec);
 }
 
 // level 2, one block: the accumulator after the block from its true start state x through the block's map; false: the map

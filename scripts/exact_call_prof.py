@@ -23,16 +23,15 @@ ring = C.c_void_p()
 assert hip.hipMalloc(C.byref(ring), C.c_size_t(2 << 30)) == 0
 pat = synth_blocks(64, 16)
 ctx.set_nco_mode(NCO_REFERENCE)
-for nb in (2000, 4129):
-    fs, ss = 2.6e6, 1
-    ns = 260000
+for fs, ss, nb in ((2.6e6, 1, 2000), (2.6e6, 1, 4129)) + (((25e6, 2, 200),) if os.environ.get("EXACT_PROF_25M") else ()):
+    ns = int(round(fs / 10))
     d = pat[np.arange(nb) % 64]
     ts = []
     for _ in range(calls):
         t0 = time.perf_counter()
         ctx.generate_batch(d, ns, fs, ss, device_ptr=ring.value)
         ts.append(time.perf_counter() - t0)
-    print(f"2.6 Msps int8, {nb} blocks: calls of {', '.join(f'{t * 1e3:.3f}' for t in ts)} ms", flush=True)
+    print(f"{fs / 1e6:g} Msps int{8 * ss}, {nb} blocks: calls of {', '.join(f'{t * 1e3:.3f}' for t in ts)} ms", flush=True)
 print("device evaluation statistics:", gpsiq.device_eval_stats(), flush=True)
 sys.stdout.flush()
 ctx.close()

@@ -36,18 +36,16 @@ for db in sorted(glob.glob(os.path.join(src, "kt*", "*.db"))):
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     sel = "name, start, end, grid_x, workgroup_x" + (", " + qcol if qcol else "")
     rows = q(db, f"select {sel} from kernels order by start")
-    # a call = the dispatches from one chain_prepare with no start estimate... simpler: split where the gap to the dispatch before exceeds 150 us
+    # a call ends with its apply_patches (every call of the profiled script has patches)
     calls_, cur = [], []
     for r in rows:
-        if cur and r[1] - max(x[2] for x in cur) > 150000:
-            calls_.append(cur); cur = []
         cur.append(r)
-    if cur:
-        calls_.append(cur)
+        if "apply_patches" in r[0]:
+            calls_.append(cur); cur = []
     seen = set()
     for call in reversed(calls_):
         nsynth = sum(1 for r in call if "synth_tile" in r[0])
-        grid = max((r[3] for r in call if "synth_tile" in r[0]), default=0)
+        grid = sum(r[3] for r in call if "synth_tile" in r[0])
         key = (nsynth, grid)
         if not nsynth or key in seen or not any("eval_blocks" in r[0] for r in call):
             continue

@@ -4,6 +4,7 @@
 // slots re-allocated and unused, a timeline continued from an earlier call, ranges summarised and folded as the ranks of a
 // time-sharded run do.  Every start state, end state and last_prn must be equal, bit for bit.  TEST INFRASTRUCTURE.
 //   usage: chain_parallel [seed] [cases]       prints  cases=.. blocks=.. linked=.. walked=.. bad=..
+#define GPSIQ_JOIN_CHECK 1
 #include "gpsiq_exact.cpp"          // (with its internals: the general walker Nco is what the top-tie walk is held against)
 #include "gpsiq_chain.cpp"
 #include <random>
@@ -171,6 +172,9 @@ int main(int argc, char **argv)
             if (std::memcmp(&want_end[i], &got_end[i], 8) || want_prn[i] != got_prn[i]) { if (bad < 10) std::printf("case %d (variant %d): end of slot %d: %.17g (prn %d) != %.17g (prn %d)\n", it, variant, i, got_end[i], got_prn[i], want_end[i], want_prn[i]); ++bad; }
     }
     gpsiq_chain_stats(s1);
-    std::printf("cases=%d blocks=%ld linked=%lu walked=%lu bad=%ld\n", cases, blocks, (unsigned long) (s1[0] - s0[0]), (unsigned long) (s1[1] - s0[1]), bad);
+    // the join of a block's stretches as a scan (the device's form, gpsiq_lane.h join_stretches_scan) == the loop, every map of every case
+    if (g_join_mismatch.load()) { std::printf("join as a scan differs from the loop in %ld of %ld maps\n", g_join_mismatch.load(), g_join_checked.load()); bad += g_join_mismatch.load(); }
+    if (!g_join_checked.load()) { std::printf("the join check did not run\n"); ++bad; }
+    std::printf("cases=%d blocks=%ld linked=%lu walked=%lu joins_checked=%ld bad=%ld\n", cases, blocks, (unsigned long) (s1[0] - s0[0]), (unsigned long) (s1[1] - s0[1]), g_join_checked.load(), bad);
     return bad ? 1 : 0;
 }

@@ -141,11 +141,21 @@ static long test_evaluation(int cases, long *chans, long *host, long *npatch)
         if (!(start >= 0.0 && start <= 1.0)) start = 0.25;
         std::vector<gpsiq_patch_t> want, got;
         gpsiq_qchan_t qw, qg;
-        const int rc = eval_block(c, start, delt, nsamp, 7, 3, &codes, &qw, &want);
+        // what the descriptor is seeded from: the start state itself (the host path), or an estimate of it some way off -- the
+        // device renders from chain_prepare's estimate (good to ~1e-11 cycle; here also far worse ones) and learns the truth later
+        double est = start;
+        const int em = (int) (rng() % 8);
+        if (em >= 3) est = start + (up() - 0.5) * (em == 3 ? 1e-13 : em == 4 ? 1e-11 : em == 5 ? 1e-9 : em == 6 ? 1e-6 : 0.3);
+        if (est < 0.0) est += 1.0;
+        if (est >= 1.0) est -= 1.0;
+        if (!(est >= 0.0 && est < 1.0)) est = 0.0;
+        const uint64_t seed = carr_phase_to_fixed(est);
+        const bool own = est == start;
+        const int rc = eval_block(c, start, delt, nsamp, 7, 3, &codes, &qw, &want, false, nullptr, 0, own ? nullptr : &seed);
         ev::DChan d;
         ev::pack_chan(c, &d);
         Collect col = {&got, 7, 3};
-        const int st = ev::eval_chan(d, start, delt, nsamp, chips, col, &qg);
+        const int st = ev::eval_chan(d, start, est, delt, nsamp, chips, col, &qg);
         ++*chans;
         if (st < 0) { if (rc != ev::qstatus_code(-st)) { if (bad++ < 5) std::printf("evaluation: status %d against rc %d\n", st, rc); } continue; }
         if (rc != GPSIQ_OK) { if (bad++ < 5) std::printf("evaluation: ok against rc %d (%s)\n", rc, gpsiq_last_error()); continue; }

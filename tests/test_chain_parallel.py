@@ -248,7 +248,7 @@ def test_a_batch_with_the_chain_on_the_device_and_a_descriptor_outside_the_forma
     from gpsiq.abi import NCO_REFERENCE, SC08
     from gpsiq.scenario import synth_blocks
     monkeypatch.setenv("GPSIQ_CHAIN", "device")
-    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "8")
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", "8")
     fs, ns, nb, nc = 2.6e6, 26000, 120, 6
     d = synth_blocks(nb, nc, seed=17)
     bad = d.copy()

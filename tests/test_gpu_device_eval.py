@@ -137,7 +137,7 @@ def test_seeded_render_on_the_device(ctx, monkeypatch):
 def test_a_refused_descriptor_in_a_late_piece(ctx, monkeypatch, mode):
     """The quantiser on the device refuses a descriptor: the call fails with the host quantiser's words, everything queued is
     drained, and the context goes on working."""
-    monkeypatch.setenv("GPSIQ_EVAL_HEAD", "40")
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", "40")
     fs, ns, nb, nc = 2.6e6, 26000, 200, 6
     d = synth_blocks(nb, nc, seed=91)
     bad = d.copy()

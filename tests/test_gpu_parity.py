@@ -577,7 +577,7 @@ def test_device_batch_quantised_and_rendered_in_pieces(ctx, oracle, monkeypatch,
     prefix -- slots going out of view and coming back re-seed inside and across pieces -- and the phase handed out chains
     the next call."""
     import torch
-    monkeypatch.setenv("GPSIQ_BATCH_PIECE_BLOCKS", piece)
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", piece)
     fs, ns, nb, nc = 2.6e6, 26000, 13, 9
     d = synth_blocks(nb, nc, seed=58)
     d["prn"][3:6, 2] = 0                       # out of view over a piece edge, back with its own phase
@@ -604,8 +604,8 @@ def test_an_error_in_a_late_piece_of_a_batch(ctx, oracle, monkeypatch, mode):
     piece: the call reports it (the earlier pieces are already on the device, everything queued is drained before the
     call returns), and the context goes on working."""
     import torch
-    monkeypatch.setenv("GPSIQ_BATCH_PIECE_BLOCKS", "3")
-    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "3")
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", "3")
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", "3")
     fs, ns, nb, nc = 2.6e6, 26000, 11, 6
     d = synth_blocks(nb, nc, seed=91)
     bad = d.copy()

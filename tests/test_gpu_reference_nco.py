@@ -261,7 +261,7 @@ def test_batch_walked_and_rendered_in_pieces(rctx, oracle, monkeypatch, pieces):
     piece k+1: whatever the piece length (1 block, 3 blocks, the whole batch), host or device destination, the result is
     the float loop, every element, and the phase handed out is the loop's."""
     import torch
-    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", pieces)
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", pieces)
     fs, nb, nc = 10e6, 8, 16
     ns = int(fs) // 10
     d = synth_blocks(nb, nc, seed=77)
@@ -285,7 +285,7 @@ def test_batch_walked_and_rendered_in_pieces(rctx, oracle, monkeypatch, pieces):
 def test_multi_device_reference_nco_in_pieces(oracle, monkeypatch):
     """gpsiq_generate_batch_multi in GPSIQ_NCO_REFERENCE: one thread walks, every device renders its range piece by piece
     as the walk reaches it (three contexts on the one GPU here) == the single-context batch == the float loop."""
-    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "2")
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", "2")
     fs, nb, nc = 2.6e6, 13, 12
     ns = int(fs) // 10
     d = synth_blocks(nb, nc, seed=12)
@@ -403,15 +403,13 @@ print("RESULT", hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest(), best, t
     assert out["2"][1] < 12.0 * out[None][1]
 
 
-@pytest.mark.parametrize("streams,sets", [("1", "2"), ("1", "4"), ("2", "2"), ("2", "3")])
-def test_pieces_on_one_or_two_streams_over_two_to_four_descriptor_sets(rctx, oracle, monkeypatch, streams, sets):
-    """The A/B switches of the piece scheduling (GPSIQ_PIECE_STREAMS, GPSIQ_DESC_SETS; default: two streams, four sets) change
-    nothing but the schedule: 21 blocks in pieces of 2, both NCO models, every element the oracle's / the float loop's."""
+@pytest.mark.parametrize("how", ["host", "device"])
+def test_many_small_pieces_on_two_streams_over_four_descriptor_sets(rctx, oracle, monkeypatch, how):
+    """The piece scheduling (two alternating streams, four descriptor sets taken in turn) under a piece size of 2 blocks: 21 blocks,
+    both NCO models, host and device evaluation, every element the oracle's / the float loop's."""
     import torch
-    monkeypatch.setenv("GPSIQ_PIECE_STREAMS", streams)
-    monkeypatch.setenv("GPSIQ_DESC_SETS", sets)
-    monkeypatch.setenv("GPSIQ_REF_CHUNK_BLOCKS", "2")
-    monkeypatch.setenv("GPSIQ_BATCH_PIECE_BLOCKS", "2")
+    monkeypatch.setenv("GPSIQ_EVAL", how)
+    monkeypatch.setenv("GPSIQ_PIECE_BLOCKS", "2")
     fs, nb, nc = 2.6e6, 21, 7
     ns = 26000
     d = synth_blocks(nb, nc, seed=131)
