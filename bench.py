@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--cpu-blocks", type=int, default=299, help="blocks of the CPU baseline sample (299 = 30 s, config 1)")
     ap.add_argument("--rounds", type=int, default=16, help="rounds of the streamed end-to-end leg")
     ap.add_argument("--sweep", action="store_true", help="also time every kernel variant (extra stderr lines)")
+    ap.add_argument("--exact-leg-only", action="store_true", help="only the GPSIQ_NCO_REFERENCE batch call at the headline size, one JSON line "
+                                                                   "(the default run starts this with GPSIQ_THREADS=2 for reference_nco.two_host_threads)")
     ap.add_argument("--dry-run", action="store_true",
                     help="host side only (launch logic, rendezvous, sharded refresh/quantise, seed exchange); no device, value null")
     return ap.parse_args()
@@ -287,6 +289,9 @@ class Scenario:
 
 def main():
     args = parse()
+    if args.exact_leg_only:
+        ensure_built()
+        return exact_leg_only(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -615,7 +620,11 @@ def main():
                 out["exact_mode_value"] = out["reference_nco"]["value"]
                 out["exact_mode_unit"] = "Msamples/s"
                 out["exact_mode_roofline"] = out["reference_nco"]["roofline"]
-                out["exact_mode_bound"] = out["reference_nco"]["legs"]["2M6_int8_16ch"]["bound"]
+                hl = out["reference_nco"]["legs"]["2M6_int8_16ch"]
+                out["exact_mode_bound"] = hl["bound"]
+                out["exact_mode_call_over_kernel"] = hl["call_over_kernel"]
+                out["exact_mode_value_best_call"] = round(hl["value"] * hl["call_ms_median_of_12"] / hl["call_ms_best"], 1)
+                out["exact_mode_what"] = "median of 12 gpsiq_generate_batch calls in GPSIQ_NCO_REFERENCE at the headline's blocks per launch, descriptors in pageable memory"
             out["extra"] = extra
         if ref_sharded is not None:
             out["reference_nco"] = dict(ref_sharded, nco_mode="reference (GPSIQ_NCO_REFERENCE), time-sharded: see `what`",
@@ -718,7 +727,7 @@ def reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather
     import gpsiq
     from gpsiq.abi import NCO_REFERENCE  # noqa: F401
     from gpsiq.scenario import synth_blocks
-    from gpsiq.shard import max_over_ranks, reference_own_shard, shard_range
+    from gpsiq.shard import max_over_ranks, reference_chain_by_time, reference_own_shard, shard_range
     out = {"legs": {}}
     pat = synth_blocks(64, args.nchan, seed=args.seed)
     for label, fs_r, ss_r, nb_r in (("2M6_int8_16ch", args.fs, args.sample_size, 2000), ("25M_int16_16ch", 25e6, 2, 200)):
@@ -740,36 +749,150 @@ def reference_sharded_leg(ctx, ring, stream, args, rank, world, dist, cpu_gather
                 r = cpu_gather(b)
                 _p["exchange"] = _p.get("exchange", 0.0) + time.perf_counter() - t
                 return r
-            q_r, patches, _, _ = reference_own_shard(d_own, fs_r, ns_r, rank, world, timed_gather, by_time=True, ctx=None if dry else ctx)
-            t1 = time.perf_counter()
-            if not dry:
-                ctx.set_descriptors(q_r)
-                ctx.set_patches(patches)
-                t2 = time.perf_counter()
-                ctx.launch(0, len(q_r), ns_r, ss_r, ring.data_ptr(), blk_r, stream=stream)
-                import torch
-                torch.cuda.synchronize()
+            host_stage = 0.0
+            if dry:
+                q_r, patches, _, _ = reference_own_shard(d_own, fs_r, ns_r, rank, world, timed_gather, by_time=True, ctx=None)
+                t1 = t2 = time.perf_counter()
+                npatch_ = len(patches)
             else:
+                # the chain by time (level 1 on this rank's GPU, the true states relayed rank to rank), then the rank's own blocks
+                # from their start states: quantiser, evaluation, synthesis and patches on the device (gpsiq_generate_seeded)
+                start_own, _, _ = reference_chain_by_time(gpsiq.chain_inputs(d_own), fs_r, ns_r, rank, world, timed_gather, ctx=ctx)
+                t1 = time.perf_counter()
+                ctx.generate_seeded(d_own, ns_r, fs_r, ss_r, start_own, device_ptr=ring.data_ptr())
                 t2 = time.perf_counter()
+                host_stage = ctx.device_eval_host_ms() * 1e-3
+                npatch_ = 0
             t3 = time.perf_counter()
             tot = max_over_ranks(t3 - t0, dist, device=xdev)
             if best is None or tot < best[0]:
-                best = (tot, t1 - t0, parts.get("exchange", 0.0), t2 - t1, t3 - t2, len(patches))
-        tot, host, exch, upload, kern, npatch = best
-        mine = {"rank": rank, "chain_and_evaluation_ms": round((host - exch) * 1e3, 3), "exchange_ms": round(exch * 1e3, 3),
-                "validate_upload_ms": round(upload * 1e3, 3), "kernel_and_patches_ms": None if dry else round(kern * 1e3, 3),
-                "patched_samples": npatch, "threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus()}
-        mine["bound"] = None if dry else ("host" if host > kern else "kernel")
+                best = (tot, t1 - t0, parts.get("exchange", 0.0), host_stage, t3 - t1, npatch_)
+        tot, host, exch, host_stage, render, npatch = best
+        mine = {"rank": rank, "chain_by_time_ms": round((host - exch) * 1e3, 3), "exchange_ms": round(exch * 1e3, 3),
+                "render_call_ms": None if dry else round(render * 1e3, 3), "render_host_stage_ms": round(host_stage * 1e3, 3),
+                "threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus()}
+        mine["bound"] = None if dry else ("host" if (host + host_stage) > (render - host_stage) else "kernel")
         per_rank = [json.loads(b.decode()) for b in cpu_gather(json.dumps(mine).ljust(320).encode())]
         out["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks per GPU, one serial pass "
-                                          "(chain: maps on the GPU + link on the host; evaluation on the host; upload; one launch)",
+                                          "(chain by time: summaries + maps on the GPU + link relayed; then gpsiq_generate_seeded: quantiser, evaluation, synthesis, patches on the device)",
                               "value": None if dry else round(nb_r * world * ns_r / tot / 1e6, 1), "unit": "Msamples/s",
                               "x_realtime": None if dry else round(nb_r * world * 0.1 / tot, 1), "seconds": round(tot, 5), "per_rank": per_rank,
                               "bound": None if dry else ("host" if any(r["bound"] == "host" for r in per_rank) else "kernel")}
     out["what"] = ("GPSIQ_NCO_REFERENCE time-sharded over the ranks: every rank walks the carrier chain of ITS OWN blocks (level 1, the certified "
-                   "map of every block, on its GPU; level 2 an addition per block on the host, relayed rank to rank), evaluates and renders them; "
-                   "what is left on the host per rank is the evaluation of its own blocks (~0.4 us per block and channel on each thread)")
+                   "map of every block, on its GPU; level 2 an addition per block on the host, relayed rank to rank), then renders them from their "
+                   "start states with quantiser, evaluation and patches on the device; what is left on the host per rank is the relayed link and the pack of its descriptors")
     return out
+
+
+def exact_leg_shapes(args, ring_bytes):
+    """(label, fs, sample bytes, blocks): the headline workload's size first (what `value` renders per launch), then round 5's sizes."""
+    ns = int(round(args.fs / 10))
+    nb_head = min(4130, ring_bytes // (2 * ns * args.sample_size))
+    return (("2M6_int8_16ch", args.fs, args.sample_size, nb_head), ("2M6_int8_16ch_2000_blocks", args.fs, args.sample_size, 2000),
+            ("25M_int16_16ch", 25e6, 2, 200))
+
+
+def exact_leg(ctx, ring, stream, pat, fs_r, ss_r, nb_r, nchan, calls=12, parts=True):
+    """One GPSIQ_NCO_REFERENCE workload: the whole batch call (median and best of `calls`) for descriptors in pageable, page-locked and
+    device memory, the host stages of each, kernel + patches alone, and (parts) the host-evaluation path and the chain's parts."""
+    import torch
+    import gpsiq
+    ns_r = int(round(fs_r / 10))
+    blk_r = 2 * ns_r * ss_r
+    nb_r = min(nb_r, ring.numel() // blk_r)
+    d_r = pat[np.arange(nb_r) % 64]
+    raw = torch.from_numpy(d_r.view(np.uint8).reshape(-1).copy())
+    pinned, resident = raw.pin_memory(), raw.cuda()
+    srcs = (("pageable", d_r), ("page_locked", (pinned.data_ptr(), nb_r, nchan)), ("device", (resident.data_ptr(), nb_r, nchan)))
+
+    def timed(src, n):
+        ctx.generate_batch(src, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
+        dts = []
+        for _ in range(n):
+            t1 = time.perf_counter()
+            ctx.generate_batch(src, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
+            dts.append(time.perf_counter() - t1)
+        dts.sort()
+        return dts[len(dts) // 2], dts[0]
+
+    keep = {k: os.environ.get(k) for k in ("GPSIQ_EVAL", "GPSIQ_CHAIN")}
+    os.environ.pop("GPSIQ_EVAL", None)
+    os.environ.pop("GPSIQ_CHAIN", None)
+    s0 = gpsiq.device_eval_stats()
+    by_mem = {}
+    for kind, src in srcs:
+        med, best = timed(src, calls)
+        by_mem[kind] = {"call_ms_median": round(med * 1e3, 3), "call_ms_best": round(best * 1e3, 3), "value": round(nb_r * ns_r / med / 1e6, 1),
+                        "host_stage_ms": round(ctx.device_eval_host_ms(), 3)}
+    s1 = gpsiq.device_eval_stats()
+    q_r, patches, _ = gpsiq.reference_blocks(d_r, fs_r, ns_r)
+    ctx.set_descriptors(q_r)
+    ctx.set_patches(patches)
+    ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 3, stream=stream)
+    km = min(ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 5, stream=stream) for _ in range(2))
+    for v in by_mem.values():
+        v["call_over_kernel"] = round(v["call_ms_median"] / km, 3)
+        v["gpus_the_host_can_feed"] = round(km / v["host_stage_ms"], 1) if v["host_stage_ms"] > 0 else None
+    med = by_mem["pageable"]["call_ms_median"] * 1e-3
+    calls_n = max(1, s1[0] - s0[0])
+    traffic, stale = replayed_traffic(f"exact_{int(fs_r)}_{nchan}_{ss_r}_{nb_r}")
+    leg = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {nchan} ch, {nb_r} blocks, gpsiq_generate_batch -> device memory",
+           "value": round(nb_r * ns_r / med / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / med, 1),
+           "call_ms": by_mem["pageable"]["call_ms_median"], "call_ms_median_of_12": by_mem["pageable"]["call_ms_median"], "call_ms_best": by_mem["pageable"]["call_ms_best"],
+           "call_by_descriptor_memory": by_mem,
+           "kernel_and_patches_ms": round(km, 3), "patched_samples": int(len(patches)),
+           "call_over_kernel": by_mem["pageable"]["call_over_kernel"],
+           "host_stage_ms": by_mem["pageable"]["host_stage_ms"], "gpus_the_host_can_feed": by_mem["pageable"]["gpus_the_host_can_feed"],
+           "bound": "host" if by_mem["pageable"]["host_stage_ms"] > km else "kernel",
+           "evaluated_on": "device" if s1[1] > s0[1] else "host threads",
+           "per_call": {"block_channel_pairs": (s1[1] - s0[1]) // calls_n, "pairs_to_the_host_walker": round((s1[2] - s0[2]) / calls_n, 2),
+                        "slots_repaired_by_the_host": round((s1[3] - s0[3]) / calls_n, 2), "calls_that_fell_back_to_the_host_path": s1[5] - s0[5]},
+           "roofline": roofline_obj(nb_r * blk_r, med * 1e3, traffic),
+           "roofline_kernel_only": roofline_obj(nb_r * blk_r, km)}
+    if stale:
+        leg["roofline"]["stale_profile"] = True
+    if parts:
+        os.environ["GPSIQ_EVAL"] = "host"                       # rounds 4-5's path in the same process: chain link + evaluation on host threads
+        med_h, best_h = timed(d_r, 6)
+        os.environ.pop("GPSIQ_EVAL", None)
+        cin = gpsiq.chain_inputs(d_r)
+        starts, _, _ = gpsiq.reference_chain(cin, fs_r, ns_r)
+        chain_ms = min(gpsiq.chain_maps(cin, fs_r, ns_r, ctx=ctx)[2] for _ in range(5))
+        maps = gpsiq.chain_maps(cin, fs_r, ns_r, ctx=ctx)[0]
+        c0 = gpsiq.chain_stats()
+        linked_starts = gpsiq.chain_link(cin, maps, fs_r, ns_r)[0]
+        c1 = gpsiq.chain_stats()
+        leg["call_ms_host_evaluation"] = {"median": round(med_h * 1e3, 3), "best": round(best_h * 1e3, 3)}
+        leg["chain"] = {"level1_device_kernels_ms": round(chain_ms, 3), "blocks_linked_through_their_map": int(c1[0] - c0[0]),
+                        "blocks_walked_from_their_true_start": int(c1[1] - c0[1]), "equal_to_the_serial_chain": bool(linked_starts.tobytes() == starts.tobytes())}
+    for k, v in keep.items():                                    # (a caller's own switches survive the leg)
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    del pinned, resident
+    return leg
+
+
+def exact_leg_only(args):
+    """bench.py --exact-leg-only: the GPSIQ_NCO_REFERENCE call at the headline size under the environment given (the parent runs
+    this with GPSIQ_THREADS=2), one JSON line."""
+    import torch
+    import gpsiq
+    from gpsiq.abi import NCO_REFERENCE
+    from gpsiq.scenario import synth_blocks
+    ctx = gpsiq.Context(0)
+    ring = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+    ctx.set_nco_mode(NCO_REFERENCE)
+    pat = synth_blocks(64, args.nchan, seed=args.seed)
+    label, fs_r, ss_r, nb_r = exact_leg_shapes(args, ring.numel())[0]
+    leg = exact_leg(ctx, ring, torch.cuda.current_stream().cuda_stream, pat, fs_r, ss_r, nb_r, args.nchan, calls=8, parts=True)
+    out = {"host_threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus(), "workload": leg["workload"]}
+    for k in ("value", "call_ms_median_of_12", "call_ms_best", "kernel_and_patches_ms", "call_over_kernel", "host_stage_ms", "gpus_the_host_can_feed", "bound",
+              "call_by_descriptor_memory", "call_ms_host_evaluation"):
+        out[k] = leg[k]
+    print(json.dumps(out), flush=True)
+    ctx.close()
 
 
 def extra_legs(ctx, ring, stream, args, first):
@@ -887,88 +1010,25 @@ def extra_legs(ctx, ring, stream, args, first):
     ex["block_call_async_reference_nco"] = {"what": "the same in GPSIQ_NCO_REFERENCE (the host walks block k+1's carrier while block k is rendered and copied)",
                                             "us_per_block": round(dt / 50 * 1e6, 1), "x_realtime": round(0.1 * 50 / dt, 1)}
     ctx.set_nco_mode(NCO_FIXED)
-    # GPSIQ_NCO_REFERENCE, the model whose output IS the reference's (T2 = 0): the batch call into device memory at the
-    # headline workload and at 25 Msps, each with the whole call (host carrier walk + candidates in pieces, the device
-    # rendering piece k under the walk of piece k+1), the host side alone (gpsiq_reference_batch) and the kernel alone
+    # GPSIQ_NCO_REFERENCE, the model whose output IS the reference's (T2 = 0): the whole gpsiq_generate_batch call into device
+    # memory, at the headline workload's size and two smaller ones.  Quantiser, carrier chain (level 1 lanes, level 2 as a scan)
+    # and candidate evaluation run on the device (csrc/gpsiq_evaldev.cpp); what the host still does is reported as host_stage_ms.
     ctx.set_nco_mode(NCO_REFERENCE)
     ref = {"nco_mode": "reference (GPSIQ_NCO_REFERENCE: the reference's double accumulators reproduced exactly; whole runs equal "
                        "the reference program's file, tests/test_reference_program.py, tests/test_config4.py)",
            "host_cpus": effective_cpus(), "legs": {}}
-    for label, fs_r, ss_r, nb_r in (("2M6_int8_16ch", args.fs, args.sample_size, 2000), ("25M_int16_16ch", 25e6, 2, 200)):
-        ns_r = int(round(fs_r / 10))
-        blk_r = 2 * ns_r * ss_r
-        nb_r = min(nb_r, ring_bytes // blk_r)
-        d_r = pat[np.arange(nb_r) % 64]
-        ctx.generate_batch(d_r[:64], ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
-        dts = []
-        a0 = gpsiq.chain_stats()
-        for _ in range(12):                             # a call is 2-6 ms of sixteen host threads and the first ones find the device
-            t1 = time.perf_counter()                    # cold (3.4, 2.5, 2.5, 2.45, 2.4, 2.4 ... ms): best of twelve, the median beside it
-            ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
-            dts.append(time.perf_counter() - t1)
-        dt = min(dts)
-        a1 = gpsiq.chain_stats()                        # blocks linked through device maps inside the calls: where the library put level 1
-        th = float("inf")
-        for _ in range(3):
-            t1 = time.perf_counter()
-            q_r, patches, _ = gpsiq.reference_blocks(d_r, fs_r, ns_r)
-            th = min(th, time.perf_counter() - t1)
-        # the parts on their own.  The carrier chain: level 1 (the certified map of every block) on the device, level 2 (an exact
-        # addition per block, the odd block walked) on the host; the serial walk on host threads it replaces, for comparison; the
-        # evaluation of the blocks from their start states (shards over threads, devices and ranks)
-        cin = gpsiq.chain_inputs(d_r)
-        tc = te = tl = float("inf")
-        s0 = gpsiq.reference_stats()
-        for _ in range(3):
-            t1 = time.perf_counter()
-            starts, _, _ = gpsiq.reference_chain(cin, fs_r, ns_r)
-            tc = min(tc, time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            gpsiq.reference_seeded(d_r, fs_r, ns_r, starts)
-            te = min(te, time.perf_counter() - t1)
-        s1 = gpsiq.reference_stats()
-        chain_ms = min(gpsiq.chain_maps(cin, fs_r, ns_r, ctx=ctx)[2] for _ in range(5))
-        maps = gpsiq.chain_maps(cin, fs_r, ns_r, ctx=ctx)[0]
-        c0 = gpsiq.chain_stats()
-        linked_starts = gpsiq.chain_link(cin, maps, fs_r, ns_r)[0]
-        c1 = gpsiq.chain_stats()
-        for _ in range(3):
-            t1 = time.perf_counter()
-            gpsiq.chain_link(cin, maps, fs_r, ns_r)
-            tl = min(tl, time.perf_counter() - t1)
-        ctx.set_descriptors(q_r)
-        ctx.set_patches(patches)
-        ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 3, stream=stream)
-        km = min(ctx.time_launches(0, nb_r, ns_r, ss_r, ring.data_ptr(), blk_r, 5, stream=stream) for _ in range(2))
-        os.environ["GPSIQ_CHAIN"] = "host"                     # the call with the serial chain on host threads (round 4's path), same process
-        ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
-        dt_host = float("inf")
-        for _ in range(4):
-            t1 = time.perf_counter()
-            ctx.generate_batch(d_r, ns_r, fs_r, ss_r, device_ptr=ring.data_ptr())
-            dt_host = min(dt_host, time.perf_counter() - t1)
-        del os.environ["GPSIQ_CHAIN"]
-        host_side = te + tl                                    # what is left on the host: link + evaluation (they pipeline under the kernel)
-        device_side = km + chain_ms
-        ref["legs"][label] = {"workload": f"{fs_r / 1e6:g} Msps int{8 * ss_r}, {args.nchan} ch, {nb_r} blocks, gpsiq_generate_batch -> device memory",
-                              "value": round(nb_r * ns_r / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(nb_r * 0.1 / dt, 1),
-                              "call_ms": round(dt * 1e3, 3), "call_ms_median_of_12": round(sorted(dts)[len(dts) // 2] * 1e3, 3),
-                              "chain_level1_in_the_call": "device" if a1[0] > a0[0] else "host threads (the library's choice: the serial walk hides under the kernel here)",
-                              "call_ms_chain_on_host_threads": round(dt_host * 1e3, 3),
-                              "chain": {"level1_device_kernels_ms": round(chain_ms, 3), "level2_host_link_ms": round(tl * 1e3, 3),
-                                        "blocks_linked_through_their_map": int(c1[0] - c0[0]), "blocks_walked_from_their_true_start": int(c1[1] - c0[1]),
-                                        "equal_to_the_serial_chain": bool(linked_starts.tobytes() == starts.tobytes()),
-                                        "serial_walk_on_host_threads_ms": round(tc * 1e3, 3),
-                                        "serial_walk_us_per_block_and_thread": round(tc * 1e6 * min(effective_cpus(), args.nchan) / (nb_r * args.nchan), 3)},
-                              "host_walk_and_candidates_ms": round(th * 1e3, 3),
-                              "host_evaluation_only_ms": round(te * 1e3, 3),
-                              "candidate_states_decided_without_a_walk": round((s1[1] - s0[1]) / max(1, s1[0] - s0[0]), 5),
-                              "gpus_the_chain_can_feed": round(km / (tl * 1e3), 2),
-                              "gpus_the_host_can_feed": round(km / (host_side * 1e3), 2),
-                              "kernel_and_patches_ms": round(km, 3), "patched_samples": int(len(patches)),
-                              "bound": "host" if host_side * 1e3 > device_side else "kernel",
-                              "roofline": roofline_obj(nb_r * blk_r, dt * 1e3),
-                              "roofline_kernel_only": roofline_obj(nb_r * blk_r, km)}
+    for label, fs_r, ss_r, nb_r in exact_leg_shapes(args, ring_bytes):
+        ref["legs"][label] = exact_leg(ctx, ring, stream, pat, fs_r, ss_r, nb_r, args.nchan, calls=12, parts=True)
+    # the same call on a thread-starved host (GPSIQ_THREADS=2: what a rank of an 8-rank job gets from a 16-CPU box), in a child
+    # process (the pool is sized once per process)
+    try:
+        import subprocess
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--exact-leg-only", "--nchan", str(args.nchan), "--fs", str(args.fs),
+                                "--sample-size", str(args.sample_size), "--seed", str(args.seed)],
+                               env=dict(os.environ, GPSIQ_THREADS="2", GPSIQ_BENCH_NO_RCCL_SELFTEST="1"), capture_output=True, text=True, timeout=240)
+        ref["two_host_threads"] = json.loads(child.stdout.strip().splitlines()[-1])
+    except Exception as ex_:                               # the figure is informational: the bench line does not depend on it
+        ref["two_host_threads"] = {"error": f"{type(ex_).__name__}: {ex_}"[:200]}
     # the same model from nothing: RINEX-derived ephemeris, static receiver -> per-block host refresh (gpsiq_refresh_epochs, the
     # double-precision descriptors the reference's host code would hand over) -> gpsiq_generate_batch in GPSIQ_NCO_REFERENCE,
     # in rounds of 1000 blocks chained through carr_phase as a run-ahead host does (host/gpsiq_runahead.c)
@@ -997,16 +1057,17 @@ def extra_legs(ctx, ring, stream, args, first):
                                      "descriptors) + gpsiq_generate_batch in GPSIQ_NCO_REFERENCE, chained through carr_phase (serial: refresh, then the call)",
                              "value": round(rounds_e * nb_e * ns_e / best / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(rounds_e * nb_e * 0.1 / best, 1),
                              "seconds": round(best, 5), "host_refresh_ms_per_round": round(best_host / rounds_e * 1e3, 3), "channels": len(scen.svs)}
-    ref["value"] = ref["legs"]["2M6_int8_16ch"]["value"]
+    head_leg = ref["legs"]["2M6_int8_16ch"]
+    ref["value"] = head_leg["value"]
     ref["unit"] = "Msamples/s"
-    ref["roofline"] = ref["legs"]["2M6_int8_16ch"]["roofline"]
-    ref["what"] = ("whole gpsiq_generate_batch call (carrier chain + evaluation + upload + kernel + patches) at the headline workload.  The chain is "
-                   "parallel in time: every block's certified map on the device (chain.level1_device_kernels_ms: two launches, the second under the "
-                   "first pieces' synthesis), the chain itself an exact addition per block on the host (chain.level2_host_link_ms, inside the "
-                   "walkers' tasks); the evaluation of a block needs its start state alone and nearly every candidate is decided without "
-                   "walking an accumulator.  bound: host (link + evaluation) against device (synthesis + patches + chain kernels), which pipeline; "
-                   "gpus_the_chain_can_feed = kernel time / link time, gpus_the_host_can_feed = kernel time / (link + evaluation) on this "
-                   "host's threads.  call_ms_chain_on_host_threads: the same call with round 4's serial walk (GPSIQ_CHAIN=host)")
+    ref["roofline"] = head_leg["roofline"]
+    ref["what"] = ("whole gpsiq_generate_batch call in GPSIQ_NCO_REFERENCE into device memory, MEDIAN of 12 calls (the best beside it), descriptors in "
+                   "pageable host memory as the Python binding hands them over (page-locked and device-resident descriptors: legs.*.call_by_descriptor_memory).  "
+                   "The call: descriptors packed (pool) and uploaded; per piece chain_prepare -> quantize_est -> synthesis from the ESTIMATED start states; beside "
+                   "it, on high-priority streams, chain_lanes -> chain_link_scan (the TRUE start states) -> eval_blocks (patches); apply_patches at the end.  "
+                   "host_stage_ms: what is left on host threads (pack of pageable rows, repair of slots whose maps do not apply, the host walker's share of the "
+                   "evaluation); gpus_the_host_can_feed = kernel_and_patches_ms / host_stage_ms; call_over_kernel = call_ms_median / kernel_and_patches_ms.  "
+                   "call_ms_host_evaluation: the same call on rounds 4-5's path (GPSIQ_EVAL=host: chain link + evaluation on host threads)")
     ex["reference_nco"] = ref
     ctx.set_nco_mode(NCO_FIXED)
     # the batch call with a device destination from double-precision descriptors: host quantiser + upload + kernel

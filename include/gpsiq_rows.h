@@ -12,6 +12,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- [next rows] per-block host refresh, batched ----------- */
 /* What the reference does on the host just before every pass of the sample loop
@@ -158,6 +161,9 @@ int gpsiq_rinex_read(const char *path, int version, gpsiq_rinex_eph_t *eph, gpsi
  * satellite whose toc is within one hour of (week, sec); -1 if none. */
 int gpsiq_rinex_select(const gpsiq_rinex_eph_t *eph, int nsets, int week, double sec);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1432,3 +1432,20 @@ int gpsiq_generate_reference_host(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblo
 {
     return generate_reference(c, ch, nblocks, nchan, nsamp, fs, sample_size, dst, dst_is_device, carr_phase_out, seeds);
 }
+
+// ---- the one exported entry to the plumbing (gpsiq_plumbing.h) --------------------------------------------------------------
+extern "C" void *gpsiq_plumbing(const char *name)
+{
+    static const struct { const char *name; void *fn; } table[] = {
+#define GPSIQ_P(f) {#f, reinterpret_cast<void *>(&f)}
+        GPSIQ_P(gpsiq_reference_chain), GPSIQ_P(gpsiq_reference_seeded), GPSIQ_P(gpsiq_reference_stats), GPSIQ_P(gpsiq_chain_inputs),
+        GPSIQ_P(gpsiq_chain_maps), GPSIQ_P(gpsiq_chain_link), GPSIQ_P(gpsiq_chain_summary), GPSIQ_P(gpsiq_chain_fold), GPSIQ_P(gpsiq_chain_stats),
+        GPSIQ_P(gpsiq_chain_maps_device), GPSIQ_P(gpsiq_time_launches), GPSIQ_P(gpsiq_num_variants), GPSIQ_P(gpsiq_variant_name),
+        GPSIQ_P(gpsiq_device_eval_stats), GPSIQ_P(gpsiq_device_eval_host_ms),
+#undef GPSIQ_P
+    };
+    if (!name) return nullptr;
+    for (const auto &e : table)
+        if (!std::strcmp(e.name, name)) return e.fn;
+    return nullptr;
+}

@@ -376,8 +376,9 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
             he = launch_variant(v, nb_.d, nchan, nsamp, sample_size, dev, stride, b0, nb, c->d_tab, s, max_active > 0 ? max_active : 1, max_amp, nullptr);
             if (k == npieces - 1) { (void) hipEventRecord(e.t_synth1, s); timed_blocks = nb; }
             if (trace && k == 0) t_first_launch = gpsiq_wall_ms() - t0;
-            if (he == hipSuccess && !direct && !reference) {
-                // (reference mode copies out after the patches; the fixed model's pieces are final as rendered)
+            if (he == hipSuccess && !direct) {
+                // a piece crosses to the destination as soon as it is rendered (the next piece's kernel covers the copy); in
+                // GPSIQ_NCO_REFERENCE the few blocks that hold a patched sample are copied once more behind apply_patches
                 hipStream_t cs = c->copy_stream[copies & 1];
                 he = hipEventRecord(c->chunk_done[copies & 1], s);
                 if (he == hipSuccess) he = hipStreamWaitEvent(cs, c->chunk_done[copies & 1], 0);
@@ -467,57 +468,15 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
         if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d evaluation: %s", k, hipGetErrorString(he)); }
     }
 
-    // ---- GPSIQ_CHAIN_VERIFY=N: every N-th block that went through its certified map is also walked serially ---------------------
-    // (on host threads, from the start state the scan gave it, while the device renders: gps.c:2821-2826 is the judge)
-    const int verify_n = reference && !seeds ? chain_verify_every() : 0;
-    unsigned verified = 0;
-    if (rc == GPSIQ_OK && verify_n > 0) {
-        const double tv = gpsiq_wall_ms();
-        he = hipMemcpyAsync(h_chan, d_chan, n * sizeof(ev::DChan), hipMemcpyDeviceToHost, E);
-        if (he == hipSuccess) he = hipMemcpyAsync(e.h_link, e.d_link, (size_t) nchan * sizeof(LinkCarry), hipMemcpyDeviceToHost, E);
-        if (he == hipSuccess) he = hipStreamSynchronize(E);
-        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, verify: %s", hipGetErrorString(he)); }
-        else {
-            struct VJob { const ev::DChan *ch; const LinkCarry *end; const bool *skip; int nblocks, nchan, nsamp, every; double delt; long bad; unsigned count; };
-            VJob vj = {h_chan, e.h_link, host_owned, nblocks, nchan, nsamp, verify_n, delt, -1, 0};
-            parallel_for(nblocks, 0, 64, [](void *p, int b0, int b1) {
-                VJob &j = *static_cast<VJob *>(p);
-                unsigned count = 0;
-                for (int b = b0; b < b1; ++b)
-                    for (int i = 0; i < j.nchan; ++i) {
-                        if ((b + i) % j.every || j.skip[i]) continue;
-                        const ev::DChan &d = j.ch[(size_t) b * j.nchan + i];
-                        if (d.prn <= 0 || !(d.start >= 0.0 && d.start <= 1.0) || !(std::fabs(d.f_carr * j.delt) < 0.5)) continue;
-                        double want;
-                        if (b + 1 < j.nblocks) {
-                            const ev::DChan &nx = j.ch[(size_t) (b + 1) * j.nchan + i];
-                            if (nx.prn != d.prn) continue;                       // the slot ends or is re-seeded: nobody reads this block's end
-                            want = nx.start;
-                        } else if (j.end[i].known) want = j.end[i].y;
-                        else continue;
-                        const double got = chain_block_true(d.f_carr, j.delt, j.nsamp, d.start);
-                        ++count;
-                        if (bits_of(got) != bits_of(want)) __sync_val_compare_and_swap(&j.bad, -1L, (long) b * j.nchan + i);
-                    }
-                __sync_fetch_and_add(&j.count, count);
-            }, &vj);
-            verified = vj.count;
-            if (vj.bad >= 0) {
-                rc = GPSIQ_E_VERIFY;
-                std::snprintf(err, sizeof err, "block %ld slot %ld: the state after the block through its certified map is not the serial walk's (GPSIQ_CHAIN_VERIFY=%d)",
-                              vj.bad / nchan, vj.bad % nchan, verify_n);
-            }
-        }
-        e.host_ms += gpsiq_wall_ms() - tv;
-    }
-
     // ---- the end of the evaluation: errors, the host walker's share, the patches -----------------------------------------------
     EvalCtrl &fin = e.h_ctrl[kEvalMaxPieces];
     fin = zero;
     size_t npatch_total = 0;
     bool fall_back = false;
     if (rc == GPSIQ_OK) {
-        he = hipMemcpyAsync(&fin, e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, E);
+        // (the fixed model's kernels ran on the staging stream: the results' way back waits for the last piece's)
+        he = hipStreamWaitEvent(E, staged[npieces - 1], 0);
+        if (he == hipSuccess) he = hipMemcpyAsync(&fin, e.d_ctrl, sizeof(EvalCtrl), hipMemcpyDeviceToHost, E);
         if (he == hipSuccess && reference) {
             // the first entries of both lists ride along (nearly always all there are)
             he = hipMemcpyAsync(e.h_patches, e.d_patches, 1024 * sizeof(gpsiq_patch_t), hipMemcpyDeviceToHost, E);
@@ -601,12 +560,71 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
             uint8_t *dev = direct ? static_cast<uint8_t *>(dst) : static_cast<uint8_t *>(c->d_out);
             if (he == hipSuccess) he = launch_patches(nb_.d, nchan, nsamp, sample_size, dev, stride, 0, nblocks, c->d_tab, nb_.d_patch, (int) npatch_total, c->stream);
         }
-        if (he == hipSuccess && !direct) {
+        if (he == hipSuccess && !direct && npatch_total) {
+            // the blocks apply_patches touched go to the destination again -- behind the pieces' own copies, which may still be
+            // on their way (join the copy streams) -- or the whole timeline when that is most of it
             const hipMemcpyKind kd = dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-            if (stride == blk_bytes) he = hipMemcpyAsync(dst, c->d_out, blk_bytes * (size_t) nblocks, kd, c->stream);
-            else he = hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks, kd, c->stream);
+            for (int k = 0; k < 2 && he == hipSuccess; ++k) {
+                he = hipEventRecord(c->chunk_done[k], c->copy_stream[k]);
+                if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, c->chunk_done[k], 0);
+            }
+            size_t touched = 0;
+            for (size_t k = 0; k < patches.size(); ++k) touched += k == 0 || patches[k].block != patches[k - 1].block;
+            if (he == hipSuccess && touched * 4 > (size_t) nblocks) {
+                if (stride == blk_bytes) he = hipMemcpyAsync(dst, c->d_out, blk_bytes * (size_t) nblocks, kd, c->stream);
+                else he = hipMemcpy2DAsync(dst, blk_bytes, c->d_out, stride, blk_bytes, (size_t) nblocks, kd, c->stream);
+            } else
+                for (size_t k = 0; k < patches.size() && he == hipSuccess; ++k)
+                    if (k == 0 || patches[k].block != patches[k - 1].block)
+                        he = hipMemcpyAsync(static_cast<uint8_t *>(dst) + (size_t) patches[k].block * blk_bytes,
+                                            static_cast<uint8_t *>(c->d_out) + (size_t) patches[k].block * stride, blk_bytes, kd, c->stream);
         }
         if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, patches: %s", hipGetErrorString(he)); }
+    }
+
+    // ---- GPSIQ_CHAIN_VERIFY=N: every N-th block that went through its certified map is also walked serially ---------------------
+    // (on a few host threads, from the start state the scan gave it, when everything of the call has been queued and only the
+    // synthesis is still running: gps.c:2821-2826 is the judge)
+    const int verify_n = reference && !seeds ? chain_verify_every() : 0;
+    unsigned verified = 0;
+    if (rc == GPSIQ_OK && verify_n > 0) {
+        const double tv = gpsiq_wall_ms();
+        he = hipMemcpyAsync(h_chan, d_chan, n * sizeof(ev::DChan), hipMemcpyDeviceToHost, E);
+        if (he == hipSuccess) he = hipMemcpyAsync(e.h_link, e.d_link, (size_t) nchan * sizeof(LinkCarry), hipMemcpyDeviceToHost, E);
+        if (he == hipSuccess) he = hipStreamSynchronize(E);
+        if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, verify: %s", hipGetErrorString(he)); }
+        else {
+            struct VJob { const ev::DChan *ch; const LinkCarry *end; const bool *skip; int nblocks, nchan, nsamp, every; double delt; long bad; unsigned count; };
+            VJob vj = {h_chan, e.h_link, host_owned, nblocks, nchan, nsamp, verify_n, delt, -1, 0};
+            parallel_for(nblocks, 4, 64, [](void *p, int b0, int b1) {
+                VJob &j = *static_cast<VJob *>(p);
+                unsigned count = 0;
+                for (int b = b0; b < b1; ++b)
+                    for (int i = 0; i < j.nchan; ++i) {
+                        if ((b + i) % j.every || j.skip[i]) continue;
+                        const ev::DChan &d = j.ch[(size_t) b * j.nchan + i];
+                        if (d.prn <= 0 || !(d.start >= 0.0 && d.start <= 1.0) || !(std::fabs(d.f_carr * j.delt) < 0.5)) continue;
+                        double want;
+                        if (b + 1 < j.nblocks) {
+                            const ev::DChan &nx = j.ch[(size_t) (b + 1) * j.nchan + i];
+                            if (nx.prn != d.prn) continue;                       // the slot ends or is re-seeded: nobody reads this block's end
+                            want = nx.start;
+                        } else if (j.end[i].known) want = j.end[i].y;
+                        else continue;
+                        const double got = chain_block_true(d.f_carr, j.delt, j.nsamp, d.start);
+                        ++count;
+                        if (bits_of(got) != bits_of(want)) __sync_val_compare_and_swap(&j.bad, -1L, (long) b * j.nchan + i);
+                    }
+                __sync_fetch_and_add(&j.count, count);
+            }, &vj);
+            verified = vj.count;
+            if (vj.bad >= 0) {
+                rc = GPSIQ_E_VERIFY;
+                std::snprintf(err, sizeof err, "block %ld slot %ld: the state after the block through its certified map is not the serial walk's (GPSIQ_CHAIN_VERIFY=%d)",
+                              vj.bad / nchan, vj.bad % nchan, verify_n);
+            }
+        }
+        e.host_ms += gpsiq_wall_ms() - tv;
     }
 
     // ---- drain: on every path nothing may still be writing the caller's buffer or reading our staging -------------------------

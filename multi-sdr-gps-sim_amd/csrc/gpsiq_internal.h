@@ -2,7 +2,9 @@
 #ifndef GPSIQ_INTERNAL_H
 #define GPSIQ_INTERNAL_H
 
+#define GPSIQ_BUILDING_LIBRARY 1
 #include "../../include/gpsiq_extras.h"      // gpsiq.h (the boundary) + gpsiq_rows.h (section 8f rows) + the frozen convenience set
+#include "gpsiq_plumbing.h"                  // the library's own plumbing (hidden symbols, reached through gpsiq_plumbing())
 #include "gpsiq_tables.h"
 
 #include <pthread.h>

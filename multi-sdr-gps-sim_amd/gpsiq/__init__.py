@@ -56,7 +56,17 @@ class GpsiqError(RuntimeError):
 
 
 def _sig(name, restype, *argtypes):
-    f = getattr(_lib, name)
+    """A function of the C-ABI (include/*.h: an exported symbol), or of the library's plumbing (csrc/gpsiq_plumbing.h: hidden
+    symbols, resolved through the one exported entry gpsiq_plumbing(name))."""
+    try:
+        f = getattr(_lib, name)
+    except AttributeError:
+        _lib.gpsiq_plumbing.restype = C.c_void_p
+        _lib.gpsiq_plumbing.argtypes = [C.c_char_p]
+        addr = _lib.gpsiq_plumbing(name.encode())
+        if not addr:
+            raise
+        return C.CFUNCTYPE(restype, *argtypes)(addr)
     f.restype = restype
     f.argtypes = list(argtypes)
     return f

@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include "gpsiq.h"
+#include "gpsiq_plumbing.h"      /* the chain on its own: not part of the boundary, reached through gpsiq_plumbing() */
 
 struct play_header {
     char     magic[8];         /* "GPSIQD1" */
@@ -63,8 +64,8 @@ int main(int argc, char **argv)
         gpsiq_chain_in_t *cin = malloc(sizeof *cin * (n ? n : 1));
         start = malloc(sizeof *start * (n ? n : 1));
         if (!cin || !start) { fprintf(stderr, "out of memory\n"); return 1; }
-        gpsiq_chain_inputs(desc, (int) n, cin);
-        if (gpsiq_reference_chain(cin, (int) h.nblocks, (int) h.nchan, h.fs, (int) h.nsamp, NULL, NULL, start, NULL, NULL) != GPSIQ_OK)
+        gpsiq_p_chain_inputs(desc, (int) n, cin);
+        if (gpsiq_p_reference_chain(cin, (int) h.nblocks, (int) h.nchan, h.fs, (int) h.nsamp, NULL, NULL, start, NULL, NULL) != GPSIQ_OK)
             return die("chain");
         free(cin);
     } else if (gpsiq_quantize_batch(desc, (int) h.nblocks, (int) h.nchan, h.fs, (int) h.nsamp, q, NULL, NULL) != GPSIQ_OK) {

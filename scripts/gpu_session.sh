@@ -5,10 +5,11 @@
 #   chainpmc rocprofv3 counters of the chain kernels (scripts/chain_pmc.py)      soak     tests/soak_chain_device.py, 3 seeds
 #   cpu      pytest -m "not gpu" on the box's host               smoke    __graft_entry__.smoke()
 #   bench    the default bench line                              sweep    bench.py --sweep (all kernel variants, refresh sweep)
-#   2rank    bench.py --gpus 2 over gloo on the box's one GPU (the N > 1 code path; GPSIQ_BENCH_SHARE_GPU=1)
+#   2rank    bench.py --gpus 2 over gloo on the box's one GPU (the N > 1 code path; GPSIQ_BENCH_SHARE_GPU=1)      8rank   the same with eight ranks
 #   prof     rocprofv3 passes of the default bench (scripts/gpu_prof.sh)        profcfg  the same for configs 3 and 5
 #   rates    throughput over the BASELINE / front-end sample rates
 #   exactprof rocprofv3 kernel trace + HBM traffic of the GPSIQ_NCO_REFERENCE batch call (scripts/exact_call_prof.py)
+#   soakeval tests/soak_device_eval.py, 3 seeds: device evaluation == host evaluation (== the reference's own loop) on random runs
 #   eval     the device evaluation: tests/test_gpu_device_eval.py, scripts/eval_timing.py (all threads, then GPSIQ_THREADS=2)
 TAG=${TAG:-r06}
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -41,6 +42,8 @@ for step in "$@"; do
       ( timeout 1500 python -m pytest tests/test_gpu_reference_nco.py tests/test_config5_shares.py -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${TAG}_refnco_tests.log 2>&1; tail -4 gpurun_out/${TAG}_refnco_tests.log ;;
     soak)
       for s in 1 2 3; do ( timeout 200 python tests/soak_chain_device.py ${SOAK_SECONDS:-50} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_chain_device.txt ;;
+    soakeval)
+      for s in 1 2 3; do ( timeout 400 python tests/soak_device_eval.py ${SOAK_SECONDS:-90} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_device_eval.txt ;;
     tests)
       ( timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${TAG}_pytest_gpu.log ;;
     cpu)
@@ -54,6 +57,12 @@ for step in "$@"; do
     2rank)
       ( GPSIQ_BENCH_SHARE_GPU=1 GPSIQ_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 5 --warmup 1 --blocks 1000 --launches 4 ) > gpurun_out/${TAG}_bench_2rank_gloo.log 2>&1
       tail -1 gpurun_out/${TAG}_bench_2rank_gloo.log | cut -c1-400 ;;
+    8rank)
+      # eight ranks SHARING the box's one GPU over gloo: the N > 1 code path at current code with the host side as it is on such a box
+      # (8 processes x 2 threads on the 16-CPU quota); the kernels take turns on the one device: readiness evidence, not a scaling curve
+      ( GPSIQ_BENCH_SHARE_GPU=1 GPSIQ_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --blocks 1000 --launches 4 --rounds 4 ) > gpurun_out/${TAG}_bench_8rank_gloo.log 2> gpurun_out/${TAG}_bench_8rank_gloo.err
+      tail -1 gpurun_out/${TAG}_bench_8rank_gloo.log | cut -c1-300
+      python scripts/eight_rank_summary.py gpurun_out/${TAG}_bench_8rank_gloo.log > gpurun_out/${TAG}_8rank_shared_gpu_gloo.txt 2>&1; cat gpurun_out/${TAG}_8rank_shared_gpu_gloo.txt ;;
     prof)
       PROF_TAG=$TAG bash scripts/gpu_prof.sh ;;
     profcfg)

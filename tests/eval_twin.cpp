@@ -7,7 +7,8 @@
 //                                               (an undecided candidate) is counted and must stay rare
 //   D  the chain as a scan (Link)            == gpsiq_chain_link: every start state the scan calls known is the serial chain's,
 //                                               whatever the association of the scan and wherever the timeline is cut in pieces
-//   usage: eval_twin [seed] [cases]       prints  cases=.. chans=.. host=.. patches=.. known=.. unknown=.. bad=..
+//   usage: eval_twin [seed] [cases]       prints  cases=.. chans=.. evals=.. host=.. evals_near=.. host_near=.. patches=.. known=.. unknown=.. bad=..
+//   (host: evaluations handed to the host walker; _near: those whose descriptor was seeded within 1e-9 cycle of the start state)
 #include "gpsiq_exact.cpp"
 #include "gpsiq_chain.cpp"
 #include "gpsiq_eval.h"
@@ -125,7 +126,7 @@ static long test_candidates(int cases)
 
 static bool patch_less(const gpsiq_patch_t &a, const gpsiq_patch_t &b) { return a.sample < b.sample; }
 
-static long test_evaluation(int cases, long *chans, long *host, long *npatch)
+static long test_evaluation(int cases, long *chans, long *host, long *npatch, long *near, long *host_near)
 {
     long bad = 0;
     HostChips chips;
@@ -133,7 +134,12 @@ static long test_evaluation(int cases, long *chans, long *host, long *npatch)
     for (int it = 0; it < cases * 400; ++it) {
         static const double rates[] = {2.6e6, 3.0e6, 10.0e6, 25.0e6, 2.6e6, 25.0e6};
         const double fs = rates[it % 6], delt = 1.0 / fs;
-        const int nsamp = it % 9 == 0 ? 1000 + (int) (rng() % 400000) : (int) (fs / 10.0);
+        int nsamp = it % 9 == 0 ? 1000 + (int) (rng() % 400000) : (int) (fs / 10.0);
+        // what the descriptor is seeded from: the start state itself (the host path), or an estimate of it some way off -- the
+        // device renders from chain_prepare's estimate (good to ~1e-11 cycle; here also far worse ones) and learns the truth later.
+        // Estimates 1e-6 .. 0.3 cycle off make every sample a candidate (the host walks them all): few, and on short blocks
+        int em = (int) (rng() % 6);
+        if (it % 16 == 5) { em = 6 + (int) (rng() % 2); nsamp = 2000 + (int) (rng() % 30000); }
         gpsiq_chan_t c = random_chan(fs, it % 6);
         double start = up();
         if (it % 6 == 4) start = std::ldexp((double) (rng() % 512), -9) + (rng() % 3 == 0 ? 0.0 : (up() - 0.3) * 2e-11);      // a start next to a LUT step
@@ -141,10 +147,7 @@ static long test_evaluation(int cases, long *chans, long *host, long *npatch)
         if (!(start >= 0.0 && start <= 1.0)) start = 0.25;
         std::vector<gpsiq_patch_t> want, got;
         gpsiq_qchan_t qw, qg;
-        // what the descriptor is seeded from: the start state itself (the host path), or an estimate of it some way off -- the
-        // device renders from chain_prepare's estimate (good to ~1e-11 cycle; here also far worse ones) and learns the truth later
         double est = start;
-        const int em = (int) (rng() % 8);
         if (em >= 3) est = start + (up() - 0.5) * (em == 3 ? 1e-13 : em == 4 ? 1e-11 : em == 5 ? 1e-9 : em == 6 ? 1e-6 : 0.3);
         if (est < 0.0) est += 1.0;
         if (est >= 1.0) est -= 1.0;
@@ -157,6 +160,8 @@ static long test_evaluation(int cases, long *chans, long *host, long *npatch)
         Collect col = {&got, 7, 3};
         const int st = ev::eval_chan(d, start, est, delt, nsamp, chips, col, &qg);
         ++*chans;
+        if (em < 6) ++*near;                           // an estimate as chain_prepare gives them, or somewhat worse
+        if (em < 6 && st == ev::kEvalHost) ++*host_near;
         if (st < 0) { if (rc != ev::qstatus_code(-st)) { if (bad++ < 5) std::printf("evaluation: status %d against rc %d\n", st, rc); } continue; }
         if (rc != GPSIQ_OK) { if (bad++ < 5) std::printf("evaluation: ok against rc %d (%s)\n", rc, gpsiq_last_error()); continue; }
         if (std::memcmp(&qw, &qg, sizeof qw)) { if (bad++ < 5) std::printf("evaluation: descriptors differ\n"); continue; }
@@ -292,8 +297,10 @@ int main(int argc, char **argv)
     long bad = test_quantiser(cases, &chans);
     bad += test_candidates(cases);
     long evals = 0;
-    bad += test_evaluation(cases, &evals, &host, &npatch);
+    long near = 0, host_near = 0;
+    bad += test_evaluation(cases, &evals, &host, &npatch, &near, &host_near);
     bad += test_link(cases * 2, &nknown, &nunknown);
-    std::printf("cases=%d chans=%ld evals=%ld host=%ld patches=%ld known=%ld unknown=%ld bad=%ld\n", cases, chans, evals, host, npatch, nknown, nunknown, bad);
+    std::printf("cases=%d chans=%ld evals=%ld host=%ld evals_near=%ld host_near=%ld patches=%ld known=%ld unknown=%ld bad=%ld\n", cases, chans, evals, host, near, host_near,
+                npatch, nknown, nunknown, bad);
     return bad ? 1 : 0;
 }

@@ -72,8 +72,7 @@ def test_gpus_8_dry_run_is_one_line_from_eight_ranks():
     for leg in ("2M6_int8_16ch", "25M_int16_16ch"):
         pr = ref["legs"][leg]["per_rank"]
         assert [p["rank"] for p in pr] == list(range(8)) and ref["legs"][leg]["value"] is None
-        assert all(p["chain_and_evaluation_ms"] > 0.0 and p["exchange_ms"] > 0.0 and p["kernel_and_patches_ms"] is None for p in pr)
-        assert len({p["patched_samples"] for p in pr}) >= 1 and sum(p["patched_samples"] for p in pr) > 0
+        assert all(p["chain_by_time_ms"] > 0.0 and p["exchange_ms"] > 0.0 and p["render_call_ms"] is None for p in pr)
 
 
 def test_collective_selftest_statements_run_over_gloo():

@@ -26,9 +26,10 @@ def test_lane_code_equals_the_host_evaluation(tmp_path):
         assert r.returncode == 0 and " bad=0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         f = dict(kv.split("=") for kv in r.stdout.strip().splitlines()[-1].split())
         assert int(f["patches"]) > 50 and int(f["known"]) > 10000        # the comparison had something to compare
-        # what the lanes hand to the host walker: the adversarial sixth of the cases (a start state or a code phase ON a boundary)
-        # and a start of exactly 1.0 -- not the rule
-        assert int(f["host"]) < 0.15 * int(f["evals"])
+        # what the lanes hand to the host walker when the descriptor is seeded from the start state or a usable estimate of it: the
+        # adversarial sixth of the cases (a start state or a code phase ON a boundary) and a start of exactly 1.0 -- not the rule
+        # (estimates 1e-6 .. 0.3 cycle off, a quarter of the cases, go there by design: every sample is a candidate)
+        assert int(f["host_near"]) < 0.15 * int(f["evals_near"])
 
 
 def test_lane_code_under_asan_and_ubsan(tmp_path):

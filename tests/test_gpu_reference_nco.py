@@ -362,10 +362,11 @@ def test_two_contexts_walk_at_the_same_time_on_two_host_threads():
 
 
 def test_fewer_host_threads_than_channels_is_piece_major_and_exact(tmp_path):
-    """GPSIQ_THREADS=2 with 16 channels (the share a rank gets when eight of them divide a 16-CPU host): the library never starts
-    more than its share, works the timeline piece-major (all channels through piece k before piece k+1, so rendering still
-    overlaps the host side) and says so under GPSIQ_TRACE; the result is bit-identical to the uncapped run and the call costs
-    no more than the thread ratio allows (16 / 2 = 8 x the host-bound time, with slack)."""
+    """GPSIQ_THREADS=2 with 16 channels (the share a rank gets when eight of them divide a 16-CPU host).  Host evaluation
+    (GPSIQ_EVAL=host, rounds 4-5's path): the library never starts more than its share, works the timeline piece-major (all
+    channels through piece k before piece k+1, so rendering still overlaps the host side) and says so under GPSIQ_TRACE; the
+    result is bit-identical to the uncapped run and the call costs no more than the thread ratio allows (16 / 2 = 8 x the
+    host-bound time, with slack).  Device evaluation (the default): the same bytes, and two threads cost next to nothing."""
     import os
     import subprocess
     import sys
@@ -388,19 +389,23 @@ import threading
 print("RESULT", hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest(), best, threading.active_count(), len(os.listdir("/proc/self/task")))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for threads in ("2", None):
-        env = dict(os.environ, GPSIQ_TRACE="1")
-        env.pop("GPSIQ_THREADS", None)
-        if threads:
-            env["GPSIQ_THREADS"] = threads
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()
-        out[threads] = (line[1], float(line[2]), r.stderr)
-    assert out["2"][0] == out[None][0]
-    assert "piece-major" in out["2"][2] and "piece-major" not in out[None][2]
-    print("reference-NCO batch, 600 blocks: %.2f ms with all host threads, %.2f ms with GPSIQ_THREADS=2" % (out[None][1] * 1e3, out["2"][1] * 1e3))
-    assert out["2"][1] < 12.0 * out[None][1]
+    for how in ("host", "device"):
+        for threads in ("2", None):
+            env = dict(os.environ, GPSIQ_TRACE="1", GPSIQ_EVAL=how)
+            env.pop("GPSIQ_THREADS", None)
+            if threads:
+                env["GPSIQ_THREADS"] = threads
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()
+            out[how, threads] = (line[1], float(line[2]), r.stderr)
+    assert len({v[0] for v in out.values()}) == 1                        # the same bytes, whoever evaluates and with however many threads
+    assert "piece-major" in out["host", "2"][2] and "piece-major" not in out["host", None][2]
+    assert "device evaluation" in out["device", "2"][2]
+    print("reference-NCO batch, 600 blocks: host evaluation %.2f ms with all host threads, %.2f ms with GPSIQ_THREADS=2; device evaluation %.2f / %.2f ms"
+          % (out["host", None][1] * 1e3, out["host", "2"][1] * 1e3, out["device", None][1] * 1e3, out["device", "2"][1] * 1e3))
+    assert out["host", "2"][1] < 12.0 * out["host", None][1]
+    assert out["device", "2"][1] < 1.5 * out["device", None][1] + 0.2e-3
 
 
 @pytest.mark.parametrize("how", ["host", "device"])

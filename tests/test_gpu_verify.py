@@ -98,7 +98,7 @@ def test_the_verify_mode_costs_little(tmp_path):
                 ts.append(time.perf_counter() - t0)
             t[every] = min(t.get(every, 1e9), sorted(ts)[len(ts) // 2])
         print(f"median call {t['0'] * 1e3:.3f} ms, with GPSIQ_CHAIN_VERIFY=64 {t['64'] * 1e3:.3f} ms")
-        assert t["64"] < 1.05 * t["0"] + 20e-6, t
+        assert t["64"] < 1.05 * t["0"] + 40e-6, t
     finally:
         os.environ.pop("GPSIQ_CHAIN_VERIFY", None)
         os.environ.pop("GPSIQ_EVAL", None)

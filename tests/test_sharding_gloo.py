@@ -118,8 +118,7 @@ def _ref_worker(rank, world, port, out, by_time):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("by_time", [True, False])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,by_time", [(2, True), (2, False), (3, True), (3, False), (8, True)])
 def test_reference_nco_shards_equal_the_whole_timeline(world, by_time):
     """Two (three) gloo ranks, each holding only its own blocks' descriptors.  by_time: the carrier chain sharded by TIME
     (gpsiq/shard.py::reference_chain_by_time: every rank walks the certified maps of its own blocks, the true states are
@@ -173,7 +172,8 @@ def _chain_worker(rank, world, port, out):
     import gpsiq
     from gpsiq.shard import reference_chain_by_time, torch_all_gather_bytes
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    cuts = [0, 31, 31, CNB] if world == 3 else [0, 37, CNB]         # uneven ranges, one rank without blocks
+    # uneven ranges, one rank without blocks (world 3 and 8), a one-block range (world 8)
+    cuts = {2: [0, 37, CNB], 3: [0, 31, 31, CNB], 8: [0, 5, 19, 19, 20, 44, 61, 78, CNB]}[world]
     before = gpsiq.chain_stats()
     start, end, prn = reference_chain_by_time(_chain_timeline()[cuts[rank]:cuts[rank + 1]], CFS, CNS, rank, world, torch_all_gather_bytes(dist))
     linked, walked = (a - b for a, b in zip(gpsiq.chain_stats(), before))
@@ -185,10 +185,11 @@ def _chain_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_time_sharded_chain_equals_the_serial_chain_over_the_whole_timeline(world):
     """gpsiq_reference_chain over 90 blocks x 9 slots in one process == the ranks' own rows of the chain sharded by time,
-    bit for bit, and every rank ends up with the state after the whole timeline; most blocks go through their maps."""
+    bit for bit, and every rank ends up with the state after the whole timeline; most blocks go through their maps.
+    World 8 (one node's worth of ranks): uneven ranges, a rank without blocks, a rank with one block."""
     import gpsiq
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -204,9 +205,9 @@ def test_time_sharded_chain_equals_the_serial_chain_over_the_whole_timeline(worl
         p.join(timeout=60)
         assert p.exitcode == 0
     want_start, want_end, want_prn = gpsiq.reference_chain(_chain_timeline(), CFS, CNS)
-    rows = b"".join(g[1] for g in sorted(gathered, key=lambda g: g[0]))
+    rows = b"".join(g[1] for g in sorted(gathered, key=lambda g: g[0]))           # (a rank without blocks contributes b"")
     assert rows == want_start.tobytes()
     for g in gathered:
         assert g[2] == want_end.tobytes() and g[3] == want_prn.tobytes()
     linked, walked = sum(g[4] for g in gathered), sum(g[5] for g in gathered)
-    assert linked > 4 * walked, (linked, walked)
+    assert linked > (4 if world < 8 else 2) * walked, (linked, walked)       # (short ranges: more blocks at a range's start, fewer tails to walk from)
