@@ -885,12 +885,17 @@ def exact_leg_only(args):
     ring = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
     ctx.set_nco_mode(NCO_REFERENCE)
     pat = synth_blocks(64, args.nchan, seed=args.seed)
-    label, fs_r, ss_r, nb_r = exact_leg_shapes(args, ring.numel())[0]
+    shapes = exact_leg_shapes(args, ring.numel())
+    label, fs_r, ss_r, nb_r = shapes[0]
     leg = exact_leg(ctx, ring, torch.cuda.current_stream().cuda_stream, pat, fs_r, ss_r, nb_r, args.nchan, calls=8, parts=True)
     out = {"host_threads": int(os.environ.get("GPSIQ_THREADS", "0")) or effective_cpus(), "workload": leg["workload"]}
     for k in ("value", "call_ms_median_of_12", "call_ms_best", "kernel_and_patches_ms", "call_over_kernel", "host_stage_ms", "gpus_the_host_can_feed", "bound",
               "call_by_descriptor_memory", "call_ms_host_evaluation"):
         out[k] = leg[k]
+    if os.environ.get("GPSIQ_BENCH_ALL_EXACT_LEGS"):            # (development: every shape of the default run's reference_nco leg, on its own)
+        for label, fs_r, ss_r, nb_r in shapes[1:]:
+            l2 = exact_leg(ctx, ring, torch.cuda.current_stream().cuda_stream, pat, fs_r, ss_r, nb_r, args.nchan, calls=8, parts=False)
+            out[label] = {k: l2[k] for k in ("call_by_descriptor_memory", "kernel_and_patches_ms")}
     print(json.dumps(out), flush=True)
     ctx.close()
 

@@ -103,22 +103,27 @@ int evd_reserve(gpsiq_ctx *c, size_t n, SrcKind kind, bool seeds)
     return GPSIQ_OK;
 }
 
-// Piece boundaries.  Nothing renders before the first piece is through pack, chain and evaluation (~0.15 ms of launches and
-// latencies however small it is), and its synthesis has to cover the chain kernels of what is left: a head worth ~0.35 ms of
-// synthesis, then pieces three times the one before.  GPSIQ_PIECE_BLOCKS (blocks of the first piece; <= 0: one piece) for A/B, read per call.
-void device_piece_ends(int nblocks, int nsamp, int nchan, std::vector<int> *ends)
+// Piece boundaries.  A piece's synthesis waits for its own descriptors only (pack, estimate, quantise), so pieces exist to start
+// the first synthesis early and to stage piece k+1 under the synthesis of piece k; every further piece costs a launch ramp
+// (~0.05 ms).  Descriptors the device reads where they lie stage in microseconds: one piece in the fixed-point model, a short
+// head in GPSIQ_NCO_REFERENCE (chain_prepare is 16 workgroups walking the timeline: 25 us per 1 000 blocks).  Pageable
+// descriptors are packed by the pool at ~14 x the synthesis rate (16 threads): a short head, then pieces eight times the one
+// before.  GPSIQ_PIECE_BLOCKS (blocks of the first piece; <= 0: one piece) for A/B, read per call.
+void device_piece_ends(int nblocks, int nsamp, int nchan, bool pageable, bool reference, std::vector<int> *ends)
 {
     const double t_block = (double) nsamp * (double) nchan / gpsiq_rate_kernel();
-    long head = (long) (0.35e-3 / (t_block > 0.0 ? t_block : 1e-6)) + 1;
-    if (head < 32) head = 32;
+    long head = (long) ((reference ? 0.15e-3 : 0.10e-3) / (t_block > 0.0 ? t_block : 1e-6)) + 1;
+    if (head < 16) head = 16;
+    if (!pageable && !reference) head = 0;
     if (const char *e = std::getenv("GPSIQ_PIECE_BLOCKS")) head = std::atol(e);
+    const long growth = 8;
     if (head <= 0 || 2 * head > nblocks) { ends->push_back(nblocks); return; }
-    long b = head, size = 3 * head;
+    long b = head, size = growth * head;
     ends->push_back((int) b);
     while (nblocks - b > size + size / 2 && (int) ends->size() < kEvalMaxPieces - 1) {
         b += size;
         ends->push_back((int) b);
-        size *= 3;
+        size *= growth;
     }
     ends->push_back(nblocks);
 }
@@ -294,7 +299,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
     }
 
     std::vector<int> ends;
-    device_piece_ends(nblocks, nsamp, nchan, &ends);
+    device_piece_ends(nblocks, nsamp, nchan, kind == kSrcPageable, reference, &ends);
     const int npieces = (int) ends.size();
     hipStream_t S = e.chain_stream, E = e.eval_stream;
     ev::DChan *d_chan = static_cast<ev::DChan *>(e.d_chan), *h_chan = static_cast<ev::DChan *>(e.h_chan);
@@ -394,15 +399,20 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
     }
     const double t_queued = gpsiq_wall_ms();
 
-    // ---- phase B (GPSIQ_NCO_REFERENCE): the chain, piece by piece behind the descriptors; repair; the evaluation --------------------
+    // ---- phase B (GPSIQ_NCO_REFERENCE): the chain behind the descriptors, repair, the evaluation ---------------------------------
+    // One launch each over the WHOLE timeline, whatever the synthesis pieces were: every launch of the chain has a latency floor
+    // (a wave's walk, ~0.1 ms), and this path has to be through before the synthesis is (three pieces of 2 000 blocks: 2.03 ms per
+    // call against 1.84 with one).
     bool host_owned[GPSIQ_MAX_CHAN] = {};
     double host_end[GPSIQ_MAX_CHAN] = {};
     int host_last_prn[GPSIQ_MAX_CHAN] = {};
+    const std::vector<int> chain_ends(1, nblocks);
+    const int nchain = 1;
     if (rc == GPSIQ_OK && chained) {
         int max_seg = 32;
         if (const char *sv = std::getenv("GPSIQ_CHAIN_STRETCHES")) { const int v = std::atoi(sv); if (v >= 1 && v <= 32) max_seg = v; }
-        for (int k = 0; k < npieces && he == hipSuccess; ++k) {
-            const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+        for (int k = 0; k < nchain && he == hipSuccess; ++k) {
+            const int b0 = k ? chain_ends[k - 1] : 0, nb = chain_ends[k] - b0;
             const size_t off = (size_t) b0 * nchan;
             he = launch_chain(d_chan + off, (int) sizeof(ev::DChan), nb, nchan, delt, nsamp, nullptr, max_seg, static_cast<char *>(c->chain.d_prep) + off * 32,
                               c->chain.d_c_before + (size_t) k * GPSIQ_MAX_CHAN, nullptr, c->chain.d_maps + off, S, 2);
@@ -415,8 +425,8 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
         }
         if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, chain: %s", hipGetErrorString(he)); }
     }
-    for (int k = 0; k < npieces && rc == GPSIQ_OK && reference; ++k) {
-        const int b0 = k ? ends[k - 1] : 0, nb = ends[k] - b0;
+    for (int k = 0; k < nchain && rc == GPSIQ_OK && reference; ++k) {
+        const int b0 = k ? chain_ends[k - 1] : 0, nb = chain_ends[k] - b0;
         if (chained) {
             he = hipEventSynchronize(e.linked[k]);
             if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d: %s", k, hipGetErrorString(he)); break; }
@@ -461,7 +471,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
                 if (rc != GPSIQ_OK) break;
             }
         }
-        he = hipStreamWaitEvent(E, chained ? e.linked[k] : staged[k], 0);
+        he = hipStreamWaitEvent(E, chained ? e.linked[k] : staged[npieces - 1], 0);
         if (he == hipSuccess)
             he = launch_eval(d_chan, b0, nb, nchan, delt, nsamp, c->d_tab, est_rows, est_stride, e.d_patches, e.patch_cap, e.d_host, e.host_cap, e.d_ctrl,
                              seeds ? e.d_seeds : nullptr, E);
