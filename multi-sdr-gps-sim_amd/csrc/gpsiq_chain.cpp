@@ -7,6 +7,7 @@
 // The results are gpsiq_reference_chain's, bit for bit (tests/test_chain_parallel.py, tests/soak_chain_parallel.py).
 #include "gpsiq_internal.h"
 #include "gpsiq_lane.h"
+#include "gpsiq_eval.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -322,6 +323,133 @@ extern "C" int gpsiq_chain_link(const gpsiq_chain_in_t *in, const gpsiq_chain_ma
     if ((!maps || !carr_start) && nblocks) return fail(GPSIQ_E_ARG, "null pointer");
     if (!carr_in != !prn_in) return fail(GPSIQ_E_ARG, "continuation state: both or neither");
     return chain_link(in, maps, nblocks, nchan, 1.0 / fs, nsamp, carr_in, prn_in, carr_start, carr_end, last_prn);
+}
+
+// ---- a range's maps composed: the relay of a time-sharded chain in one exchange (gpsiq_plumbing.h) ------------------------------
+extern "C" int gpsiq_chain_range(const gpsiq_chain_in_t *in, const gpsiq_chain_map_t *maps, int nblocks, int nchan, double fs, int nsamp,
+                                 gpsiq_chain_range_t *out)
+{
+    int rc = check_chain_args(in, nblocks, nchan, fs, nsamp);
+    if (rc) return rc;
+    if ((!maps && nblocks) || !out) return fail(GPSIQ_E_ARG, "null pointer");
+    const Rec *rec = reinterpret_cast<const Rec *>(maps);
+    // the state after the range when its first block seeds itself: the ordinary link (also what a restart inside leaves behind)
+    std::vector<double> start((size_t) nblocks * nchan + 1), end_abs((size_t) nchan);
+    std::vector<int32_t> last_prn((size_t) nchan);
+    if (nblocks) {
+        rc = chain_link(in, maps, nblocks, nchan, 1.0 / fs, nsamp, nullptr, nullptr, start.data(), end_abs.data(), last_prn.data());
+        if (rc) return rc;
+    }
+    for (int i = 0; i < nchan; ++i) {
+        gpsiq_chain_range_t r;
+        std::memset(&r, 0, sizeof r);
+        r.nblocks = nblocks;
+        if (nblocks == 0) { out[i] = r; continue; }
+        r.abs_end = end_abs[i]; r.last_prn = last_prn[i];
+        const gpsiq_chain_in_t &d0 = in[i];
+        r.first_prn = d0.prn > 0 ? d0.prn : 0;
+        // the blocks that continue the state the range is entered with: all of them, unless the slot restarts inside
+        int n = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            const int prn = in[(size_t) b * nchan + i].prn;
+            if (prn <= 0 || (b > 0 && prn != in[(size_t) (b - 1) * nchan + i].prn)) break;
+            ++n;
+        }
+        r.restart = n < nblocks;
+        if (r.first_prn == 0 || r.restart) { out[i] = r; continue; }          // (nothing of the end depends on the entry state)
+        // compose the maps of blocks 0 .. n-1; per residue of the entry offset, the offsets at every block and what they must satisfy
+        r.xs = rec[i].xs;
+        r.e = rec[(size_t) (n - 1) * nchan + i].e;
+        int64_t pre[4] = {0, 0, 0, 0};                   // offset at block b, less the entry offset, per residue r
+        int ok = 15;
+        for (int q = 0; q < 4; ++q) { r.lo[q] = INT64_MIN / 4; r.hi[q] = INT64_MAX / 4; }
+        for (int b = 0; b < n && ok; ++b) {
+            const Rec &m = rec[(size_t) b * nchan + i];
+            const int64_t grid = m.info & 0xff;
+            if (!m.ok || grid < 1 || grid > 2 || !(std::fabs(in[(size_t) b * nchan + i].f_carr / fs) < 0.5)) { ok = 0; break; }
+            int64_t J = 0;
+            if (b > 0 && !lane::exact_units(rec[(size_t) (b - 1) * nchan + i].e, m.xs, &J)) { ok = 0; break; }
+            for (int q = 0; q < 4; ++q) {
+                if (!(ok & (1 << q))) continue;
+                if (b > 0) {
+                    const Rec &pm = rec[(size_t) (b - 1) * nchan + i];
+                    const int64_t pg = pm.info & 0xff;
+                    const int64_t dprev = (int64_t) q + pre[q];                              // mod 4 is all that matters for the parity
+                    pre[q] += pm.cum[(dprev >> (pg - 1)) & 1] + J;
+                }
+                const int64_t dres = (int64_t) q + pre[q];
+                if ((dres & (grid - 1)) || !(m.ok & (1 << ((dres >> (grid - 1)) & 1)))) { ok &= ~(1 << q); continue; }
+                int64_t l = m.lo - pre[q], h = m.hi - pre[q];
+                // ... and the state after the block, e + (d + cum)*U, has to be a double in [0, 1) (link_block's exact_shift): below
+                // 1.0, and below the first binade whose ulp would drop e's lowest bit
+                const int64_t cum = m.cum[(dres >> (grid - 1)) & 1];
+                const uint64_t be = bits_of(m.e);
+                double ymax = 1.0;
+                if (m.e > 0.0) {
+                    const int tz = __builtin_ctzll((be & kMant) | (kMant + 1));               // trailing zeros of the 53-bit mantissa
+                    const double lowbit = from_bits((uint64_t) ((int64_t) (be >> 52) - 52 + tz) << 52);
+                    if (lowbit * 0x1p53 < ymax) ymax = lowbit * 0x1p53;
+                } else if (m.e < 0.0) { ok &= ~(1 << q); continue; }
+                const double E = m.e * 0x1p53, Y = ymax * 0x1p53;
+                const int64_t kmin = (int64_t) std::ceil(-E), kmax = (int64_t) std::ceil(Y - E) - 1;      // kmin <= d + cum <= kmax
+                if (kmin - cum - pre[q] > l) l = kmin - cum - pre[q];
+                if (kmax - cum - pre[q] < h) h = kmax - cum - pre[q];
+                if (l > r.lo[q]) r.lo[q] = l;
+                if (h < r.hi[q]) r.hi[q] = h;
+            }
+        }
+        for (int q = 0; q < 4; ++q) { r.t[q] = pre[q]; if (r.lo[q] > r.hi[q]) ok &= ~(1 << q); }
+        const Rec &ml = rec[(size_t) (n - 1) * nchan + i];
+        r.cum_last[0] = ml.cum[0]; r.cum_last[1] = ml.cum[1]; r.grid_last = (int32_t) (ml.info & 0xff);
+        r.ok = ok;
+        out[i] = r;
+    }
+    return GPSIQ_OK;
+}
+
+extern "C" int gpsiq_chain_range_fold(const gpsiq_chain_range_t *ranges, int nranges, int nchan, const double *true_end, const int32_t *true_prn,
+                                      const uint8_t *true_known, double *carr, int32_t *prn, uint8_t *known)
+{
+    if ((!ranges && nranges) || !carr || !prn || !known || nranges < 0 || nchan < 1 || nchan > GPSIQ_MAX_CHAN) return fail(GPSIQ_E_ARG, "bad argument");
+    int all = 1;
+    for (int i = 0; i < nchan; ++i) {
+        double x = 0.0;
+        int pv = 0;
+        bool kn = true;
+        carr[i] = 0.0; prn[i] = 0; known[i] = 1;
+        for (int r = 0; r < nranges; ++r) {
+            const gpsiq_chain_range_t &g = ranges[(size_t) r * nchan + i];
+            const size_t at = (size_t) r * nchan + i;
+            if (g.nblocks > 0) {
+                if (true_known && true_known[r]) { x = true_end[at]; pv = true_prn[at]; kn = true; }        // the rank has linked its range: the state itself
+                else {
+                    // (which satellite the slot holds never depends on the accumulator: pv is always known)
+                    const bool continues = g.first_prn > 0 && pv == g.first_prn;
+                    if (!continues || g.restart) { x = g.abs_end; kn = true; }      // its first block seeds the slot, or the slot restarts inside: whatever came before
+                    else if (kn) {
+                        // the range continues the state it is entered with, all the way: through its composed maps
+                        int64_t d = 0;
+                        bool ok = lane::exact_units(x, g.xs, &d);
+                        const int q = (int) (d & 3);
+                        ok = ok && (g.ok & (1 << q)) && d >= g.lo[q] && d <= g.hi[q] && g.grid_last >= 1 && g.grid_last <= 2;
+                        double y = 0.0;
+                        if (ok) {
+                            const int64_t dl = d + g.t[q];
+                            ok = lane::exact_shift(g.e, dl + g.cum_last[(dl >> (g.grid_last - 1)) & 1], &y) && y >= 0.0 && y < 1.0;
+                        }
+                        kn = ok;
+                        x = y;
+                    }                                                                // (else: unknown in, unknown out)
+                    pv = g.last_prn;
+                }
+                if (pv <= 0) { pv = 0; x = 0.0; }
+            }
+            carr[(size_t) (r + 1) * nchan + i] = kn ? x : 0.0; prn[(size_t) (r + 1) * nchan + i] = kn ? pv : 0;
+            known[(size_t) (r + 1) * nchan + i] = kn ? 1 : 0;
+            if (!kn) all = 0;
+        }
+    }
+    return all;
 }
 
 extern "C" void gpsiq_chain_stats(uint64_t out[2])

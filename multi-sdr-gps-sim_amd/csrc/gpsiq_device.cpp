@@ -1440,7 +1440,7 @@ extern "C" void *gpsiq_plumbing(const char *name)
 #define GPSIQ_P(f) {#f, reinterpret_cast<void *>(&f)}
         GPSIQ_P(gpsiq_reference_chain), GPSIQ_P(gpsiq_reference_seeded), GPSIQ_P(gpsiq_reference_stats), GPSIQ_P(gpsiq_chain_inputs),
         GPSIQ_P(gpsiq_chain_maps), GPSIQ_P(gpsiq_chain_link), GPSIQ_P(gpsiq_chain_summary), GPSIQ_P(gpsiq_chain_fold), GPSIQ_P(gpsiq_chain_stats),
-        GPSIQ_P(gpsiq_chain_maps_device), GPSIQ_P(gpsiq_time_launches), GPSIQ_P(gpsiq_num_variants), GPSIQ_P(gpsiq_variant_name),
+        GPSIQ_P(gpsiq_chain_maps_device), GPSIQ_P(gpsiq_chain_range), GPSIQ_P(gpsiq_chain_range_fold), GPSIQ_P(gpsiq_time_launches), GPSIQ_P(gpsiq_num_variants), GPSIQ_P(gpsiq_variant_name),
         GPSIQ_P(gpsiq_device_eval_stats), GPSIQ_P(gpsiq_device_eval_host_ms),
 #undef GPSIQ_P
     };

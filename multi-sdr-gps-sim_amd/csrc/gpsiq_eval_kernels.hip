@@ -191,6 +191,27 @@ __global__ __launch_bounds__(kLinkThreads) void chain_link_scan(DChan *__restric
     }
 }
 
+// ---- repair: one slot's column out of the row-major arrays, and its start states back in ---------------------------------------
+// (a slot with a block whose map does not apply is relinked by the host walker: it needs that slot's maps and chain inputs only)
+__global__ __launch_bounds__(256) void gather_slot(const DChan *__restrict__ chan, const Rec *__restrict__ rec, int b0, int nb, int nchan, int slot,
+                                                   EvalSlotRow *__restrict__ out)
+{
+    const int k = (int) (blockIdx.x * 256u + threadIdx.x);
+    if (k >= nb) return;
+    const size_t at = (size_t) (b0 + k) * nchan + slot;
+    const DChan d = chan[at];
+    EvalSlotRow r;
+    r.f_carr = d.f_carr; r.carr_phase = d.carr_phase; r.start = d.start; r.prn = d.prn; r.pad = 0;
+    const Rec m = rec[at];
+    r.map.xs = m.xs; r.map.e = m.e; r.map.cum[0] = m.cum[0]; r.map.cum[1] = m.cum[1]; r.map.lo = m.lo; r.map.hi = m.hi; r.map.ok = m.ok; r.map.info = m.info;
+    out[k] = r;
+}
+__global__ __launch_bounds__(256) void scatter_starts(DChan *__restrict__ chan, int b0, int nb, int nchan, int slot, const double *__restrict__ starts)
+{
+    const int k = (int) (blockIdx.x * 256u + threadIdx.x);
+    if (k < nb) chan[(size_t) (b0 + k) * nchan + slot].start = starts[k];
+}
+
 // ---- the evaluation -----------------------------------------------------------------------------------------------------
 struct DevChips {
     const DeviceTables *tab;
@@ -398,6 +419,19 @@ hipError_t launch_link_scan(void *d_chan, const void *d_maps, int b0, int nb, in
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(chain_link_scan, dim3((unsigned) nchan), dim3(kLinkThreads), 0, s, static_cast<DChan *>(d_chan), static_cast<const Rec *>(d_maps),
                        b0, nb, nchan, delt, d_carry, d_ctrl, piece);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_slot(const void *d_chan, const void *d_maps, int b0, int nb, int nchan, int slot, EvalSlotRow *d_out, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_slot, dim3((unsigned) ((nb + 255) / 256)), dim3(256), 0, s, static_cast<const DChan *>(d_chan), static_cast<const Rec *>(d_maps), b0, nb, nchan, slot, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_starts(void *d_chan, int b0, int nb, int nchan, int slot, const double *d_starts, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_starts, dim3((unsigned) ((nb + 255) / 256)), dim3(256), 0, s, static_cast<DChan *>(d_chan), b0, nb, nchan, slot, d_starts);
     return hipGetLastError();
 }
 

@@ -29,6 +29,10 @@ struct LinkCarry { int64_t d; double y; int32_t prn; int32_t known; };     // GP
 struct FixedCarry { uint64_t phase; int32_t prn; int32_t cont; };          // GPSIQ_NCO_FIXED: exact carrier phase after the last block
 struct EvalHostItem { uint32_t block; uint16_t chan, slot; double start; uint64_t seed; };   // slot: the channel's place among the block's active ones; start: its accumulator; seed: the carrier phase its descriptor was seeded with
 
+// one block of one slot as the repair fetches it: the block's certified map and what the chain reads of its descriptor (88 bytes)
+struct EvalSlotRow { gpsiq_chain_map_t map; double f_carr, carr_phase, start; int32_t prn, pad; };
+hipError_t launch_gather_slot(const void *d_chan, const void *d_maps, int b0, int nb, int nchan, int slot, EvalSlotRow *d_out, hipStream_t s);
+hipError_t launch_scatter_starts(void *d_chan, int b0, int nb, int nchan, int slot, const double *d_starts, hipStream_t s);
 hipError_t launch_pack_raw(const gpsiq_chan_t *d_ch, int nblocks, int nchan, double delt, void *d_chan, EvalCtrl *d_ctrl, hipStream_t s);
 hipError_t launch_link_scan(void *d_chan, const void *d_maps, int b0, int nb, int nchan, double delt, LinkCarry *d_carry, EvalCtrl *d_ctrl, int piece,
                             hipStream_t s);

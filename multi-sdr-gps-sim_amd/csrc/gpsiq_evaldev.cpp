@@ -107,12 +107,14 @@ int evd_reserve(gpsiq_ctx *c, size_t n, SrcKind kind, bool seeds)
 // the first synthesis early and to stage piece k+1 under the synthesis of piece k; every further piece costs a launch ramp
 // (~0.05 ms).  Descriptors the device reads where they lie stage in microseconds: one piece in the fixed-point model, a short
 // head in GPSIQ_NCO_REFERENCE (chain_prepare is 16 workgroups walking the timeline: 25 us per 1 000 blocks).  Pageable
-// descriptors are packed by the pool at ~14 x the synthesis rate (16 threads): a short head, then pieces eight times the one
-// before.  GPSIQ_PIECE_BLOCKS (blocks of the first piece; <= 0: one piece) for A/B, read per call.
-void device_piece_ends(int nblocks, int nsamp, int nchan, bool pageable, bool reference, std::vector<int> *ends)
+// descriptors are packed by the pool at ~14 x the synthesis rate (16 threads; 2 x with two): a head worth 0.35 ms of synthesis, so
+// that the pack of what follows hides under it, then pieces eight times the one before (measured, 2.6 Msps: 2 000 blocks fixed
+// model 1.56 ms per call against 1.74 with a 0.1 ms head, reference model 1.85 against 2.06).
+// GPSIQ_PIECE_BLOCKS (blocks of the first piece; <= 0: one piece) for A/B, read per call.
+void device_piece_ends(int nblocks, int nsamp, int nchan, bool pageable /* or page-locked: host memory */, bool reference, std::vector<int> *ends)
 {
     const double t_block = (double) nsamp * (double) nchan / gpsiq_rate_kernel();
-    long head = (long) ((reference ? 0.15e-3 : 0.10e-3) / (t_block > 0.0 ? t_block : 1e-6)) + 1;
+    long head = (long) ((pageable ? 0.35e-3 : 0.15e-3) / (t_block > 0.0 ? t_block : 1e-6)) + 1;
     if (head < 16) head = 16;
     if (!pageable && !reference) head = 0;
     if (const char *e = std::getenv("GPSIQ_PIECE_BLOCKS")) head = std::atol(e);
@@ -164,17 +166,17 @@ void pack_host(PackJob *pj, int nblocks)
     }, pj);
 }
 
-// one slot's chain on the host through the device's maps (link_slot of gpsiq_chain.cpp on the packed rows), blocks [b0, b1): every
-// start state -> start_col[b - b0]; *x / *pv: the accumulator and satellite before block b0 (b0 > 0), and after block b1 - 1 on
-// return.  in / rec: rows of these blocks (row 0 = block b0).  false: a state or Doppler outside the NCO format (*bad_block)
-bool link_slot_host(const ev::DChan *in, const lane::Rec *rec, int b0, int b1, int nchan, int i, double delt, int nsamp,
-                    double *x_io, int *pv_io, double *start_col, long *linked, long *walked, int *bad_block)
+// one slot's chain on the host through the device's maps (link_slot of gpsiq_chain.cpp on the slot's gathered column), blocks
+// [b0, b1): rows[b - b0]; every start state -> start_col[b - b0]; *x / *pv: the accumulator and satellite before block b0
+// (b0 > 0), and after block b1 - 1 on return.  false: a state or Doppler outside the NCO format (*bad_block)
+bool link_slot_host(const EvalSlotRow *rows, int b0, int b1, double delt, int nsamp, double *x_io, int *pv_io, double *start_col,
+                    long *linked, long *walked, int *bad_block)
 {
+    static_assert(sizeof(gpsiq_chain_map_t) == sizeof(lane::Rec), "the map as the lanes write it");
     double x = *x_io;
     int pv = *pv_io;
     for (int b = b0; b < b1; ++b) {
-        const size_t at = (size_t) (b - b0) * nchan + i;
-        const ev::DChan &d = in[at];
+        const EvalSlotRow &d = rows[b - b0];
         if (d.prn <= 0) { pv = 0; x = 0.0; start_col[b - b0] = 0.0; continue; }
         if (b == 0 || pv != d.prn) x = d.carr_phase;
         pv = d.prn;
@@ -182,7 +184,7 @@ bool link_slot_host(const ev::DChan *in, const lane::Rec *rec, int b0, int b1, i
         const double inc = d.f_carr * delt;
         if (!(x >= 0.0 && x <= 1.0) || !(std::fabs(inc) < 0.5)) { *bad_block = b; return false; }
         double y;
-        if (lane::link_block(rec[at], x, &y)) { x = y; ++*linked; }
+        if (lane::link_block(*reinterpret_cast<const lane::Rec *>(&d.map), x, &y)) { x = y; ++*linked; }
         else { x = chain_block_true(d.f_carr, delt, nsamp, x); ++*walked; }
     }
     *x_io = x; *pv_io = pv;
@@ -225,6 +227,10 @@ void gpsiq_evaldev_destroy(gpsiq_ctx *c)
     if (e.h_fix) (void) hipHostFree(e.h_fix);
     if (e.d_patches) (void) hipFree(e.d_patches);
     if (e.h_patches) (void) hipHostFree(e.h_patches);
+    if (e.d_slot) (void) hipFree(e.d_slot);
+    if (e.h_slot) (void) hipHostFree(e.h_slot);
+    if (e.d_col) (void) hipFree(e.d_col);
+    if (e.h_col) (void) hipHostFree(e.h_col);
     if (e.d_host) (void) hipFree(e.d_host);
     if (e.h_host) (void) hipHostFree(e.h_host);
     for (auto &ev_ : e.linked) if (ev_) (void) hipEventDestroy(ev_);
@@ -299,7 +305,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
     }
 
     std::vector<int> ends;
-    device_piece_ends(nblocks, nsamp, nchan, kind == kSrcPageable, reference, &ends);
+    device_piece_ends(nblocks, nsamp, nchan, kind != kSrcDevice, reference, &ends);          // (page-locked rows cross PCIe too: staged like pageable ones)
     const int npieces = (int) ends.size();
     hipStream_t S = e.chain_stream, E = e.eval_stream;
     ev::DChan *d_chan = static_cast<ev::DChan *>(e.d_chan), *h_chan = static_cast<ev::DChan *>(e.h_chan);
@@ -435,35 +441,48 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
             for (int i = 0; i < nchan; ++i) need = need || ck.unknown[k][i] > 0 || host_owned[i];
             if (need) {
                 // A block whose certified map does not apply (a slow block, a sign change, a range the estimate missed): the host
-                // walker takes that slot from this piece on -- the piece's maps and rows come back, the slot is linked / walked from
+                // walker takes that slot from this piece on -- the slot's column of maps and rows comes back, it is linked / walked from
                 // the state it enters the piece with (lane::link_block + the true walk, as rounds 4-5 did for every slot), and its
                 // start states go back up before the piece is evaluated.  The device's own scan goes on for the other slots, and
                 // the synthesis is not held up: it runs from the estimates.
                 const double tr = gpsiq_wall_ms();
-                const size_t off = (size_t) b0 * nchan, cnt = (size_t) nb * nchan;
-                const size_t lead = b0 > 0 ? (size_t) nchan : 0;                   // the row before the piece too: which satellite each slot had
-                he = hipMemcpyAsync(c->chain.h_maps + off, c->chain.d_maps + off, cnt * sizeof(gpsiq_chain_map_t), hipMemcpyDeviceToHost, E);
-                if (he == hipSuccess) he = hipMemcpyAsync(h_chan + off - lead, d_chan + off - lead, (cnt + lead) * sizeof(ev::DChan), hipMemcpyDeviceToHost, E);   // (with the starts the scan wrote)
-                if (he == hipSuccess) he = hipStreamSynchronize(E);
-                if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, repair: %s", hipGetErrorString(he)); break; }
-                std::vector<double> col((size_t) nb);
+                const int lead = b0 > 0 ? 1 : 0;                                   // the row before the piece too: which satellite the slot had
+                if ((size_t) nb + 1 > e.slot_cap) {
+                    if (e.d_slot) (void) hipFree(e.d_slot);
+                    if (e.h_slot) (void) hipHostFree(e.h_slot);
+                    if (e.d_col) (void) hipFree(e.d_col);
+                    if (e.h_col) (void) hipHostFree(e.h_col);
+                    e.d_slot = nullptr; e.h_slot = nullptr; e.d_col = nullptr; e.h_col = nullptr; e.slot_cap = 0;
+                    const size_t cap = (size_t) nb + 1 + 256;
+                    he = hipMalloc((void **) &e.d_slot, cap * sizeof(EvalSlotRow));
+                    if (he == hipSuccess) he = hipHostMalloc((void **) &e.h_slot, cap * sizeof(EvalSlotRow), hipHostMallocDefault);
+                    if (he == hipSuccess) he = hipMalloc((void **) &e.d_col, cap * sizeof(double));
+                    if (he == hipSuccess) he = hipHostMalloc((void **) &e.h_col, cap * sizeof(double), hipHostMallocDefault);
+                    if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, repair buffers: %s", hipGetErrorString(he)); break; }
+                    e.slot_cap = cap;
+                }
                 for (int i = 0; i < nchan && rc == GPSIQ_OK; ++i) {
                     if (!(ck.unknown[k][i] > 0 || host_owned[i])) continue;
+                    // the slot's column (map + chain inputs + the starts the scan wrote), one small copy instead of every slot's rows
+                    he = launch_gather_slot(d_chan, c->chain.d_maps, b0 - lead, nb + lead, nchan, i, e.d_slot, E);
+                    if (he == hipSuccess) he = hipMemcpyAsync(e.h_slot, e.d_slot, (size_t) (nb + lead) * sizeof(EvalSlotRow), hipMemcpyDeviceToHost, E);
+                    if (he == hipSuccess) he = hipStreamSynchronize(E);
+                    if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, repair: %s", hipGetErrorString(he)); break; }
                     if (!host_owned[i]) {
                         // the state the slot enters the piece with: the scan knew every start up to its first block that does not link
-                        host_last_prn[i] = b0 > 0 && h_chan[off - nchan + i].prn > 0 ? h_chan[off - nchan + i].prn : 0;
-                        host_end[i] = h_chan[off + i].start;
+                        host_last_prn[i] = lead && e.h_slot[0].prn > 0 ? e.h_slot[0].prn : 0;
+                        host_end[i] = e.h_slot[lead].start;
                     }
                     long linked = 0, walked = 0;
                     int bad = -1;
-                    if (!link_slot_host(h_chan + off, reinterpret_cast<const lane::Rec *>(c->chain.h_maps) + off, b0, b0 + nb, nchan, i, delt, nsamp,
-                                        &host_end[i], &host_last_prn[i], col.data(), &linked, &walked, &bad)) {
+                    if (!link_slot_host(e.h_slot + lead, b0, b0 + nb, delt, nsamp, &host_end[i], &host_last_prn[i], e.h_col, &linked, &walked, &bad)) {
                         rc = GPSIQ_E_RANGE; std::snprintf(err, sizeof err, "block %d: carrier phase or Doppler outside the NCO format", bad);
                         break;
                     }
                     chain_count(linked, walked);
-                    he = hipMemcpy2DAsync(&d_chan[off + i].start, sizeof(ev::DChan) * (size_t) nchan, col.data(), sizeof(double), sizeof(double), (size_t) nb, hipMemcpyHostToDevice, E);
-                    if (he == hipSuccess) he = hipStreamSynchronize(E);                   // (col is reused for the next slot)
+                    he = hipMemcpyAsync(e.d_col, e.h_col, (size_t) nb * sizeof(double), hipMemcpyHostToDevice, E);
+                    if (he == hipSuccess) he = launch_scatter_starts(d_chan, b0, nb, nchan, i, e.d_col, E);
+                    if (he == hipSuccess) he = hipStreamSynchronize(E);                   // (the staging is reused for the next slot)
                     if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, repair upload: %s", hipGetErrorString(he)); break; }
                     if (!host_owned[i]) { host_owned[i] = true; ++e.last_repaired; }
                 }

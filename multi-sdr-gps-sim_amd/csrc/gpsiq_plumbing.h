@@ -98,10 +98,43 @@ int gpsiq_chain_link(const gpsiq_chain_in_t *in, const gpsiq_chain_map_t *maps, 
 int gpsiq_chain_summary(const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
                         const gpsiq_chain_est_t *start, gpsiq_chain_est_t *sum);
 int gpsiq_chain_fold(const gpsiq_chain_est_t *sums /* [nranges][nchan] */, int nranges, int nchan, gpsiq_chain_est_t *out);
+/* The relay of a time-sharded chain in ONE exchange instead of one per rank.  What a RANGE of blocks does to a slot's accumulator,
+ * as a function of the state it enters with: the range's maps composed (csrc/gpsiq_eval.h, Link: integer translations that depend
+ * on the entry offset mod 4), with the ranges of entry offsets for which every block of it links.
+ *   gpsiq_chain_range       rank r, after level 1 of its own blocks: one record per slot (all-gather them, 160 bytes each);
+ *   gpsiq_chain_range_fold  every rank, the same arithmetic on the same records: the (accumulator, satellite) every range is entered
+ *                           with -- carr / prn / known [nranges + 1][nchan], row r: before range r, the last row: after the whole
+ *                           timeline.  A range that has a block whose map does not apply for the state it is entered with cannot
+ *                           be composed: what follows it in that slot is unknown (known 0) until the slot is re-seeded -- or until
+ *                           the rank that owns the range has linked it and published the state it ended on: true_end / true_prn
+ *                           [nranges][nchan] with true_known[nranges] (1: that rank's rows are final; may all be NULL).  Returns 1
+ *                           when every state is known.  A rank links its own blocks (gpsiq_chain_link) once its row is known in all
+ *                           slots; gpsiq/shard.py::reference_chain_by_time iterates fold and exchange until every rank has.
+ * `abs_end` / `last_prn`: the state after the range when its first block seeds the slot itself (gpsiq_chain_link with no state
+ * handed in) -- also the state after it whatever came before when the slot is re-seeded or unused somewhere inside (restart). */
+typedef struct gpsiq_chain_range {
+    double  xs, e;                 /* representative start of the range's first block; end of its last block for entry offset 0 */
+    int64_t t[4], lo[4], hi[4];    /* entry offset d = (x - xs) / 2^-53, r = d mod 4: the offset at the last block is d + t[r], if lo[r] <= d <= hi[r] */
+    int64_t cum_last[2];           /* the last block's own map: the end is e + (d_last + cum_last[parity]) * 2^-53 */
+    double  abs_end;
+    int32_t first_prn, last_prn;   /* satellite of the range's first / last block (0: unused) */
+    int32_t ok;                    /* bit r: residue r usable */
+    int32_t restart;               /* the slot is re-seeded or unused inside the range: the end does not depend on the entry state */
+    int32_t nblocks, grid_last;    /* 0 blocks: transparent */
+} gpsiq_chain_range_t;
+int gpsiq_chain_range(const gpsiq_chain_in_t *in, const gpsiq_chain_map_t *maps, int nblocks, int nchan, double fs, int nsamp,
+                      gpsiq_chain_range_t *out /* [nchan] */);
+int gpsiq_chain_range_fold(const gpsiq_chain_range_t *ranges /* [nranges][nchan] */, int nranges, int nchan,
+                           const double *true_end, const int32_t *true_prn, const uint8_t *true_known,
+                           double *carr, int32_t *prn, uint8_t *known /* [nranges + 1][nchan] each */);
+
 /* out[0] blocks linked through their map, out[1] blocks walked from their true start, since the process started */
 void gpsiq_chain_stats(uint64_t out[2]);
 /* gpsiq_chain_maps on the context's device: one lane per stretch of a block (max_stretches <= 0: 32, or GPSIQ_CHAIN_STRETCHES), `in` and `maps` host
- * memory; kernel_ms (may be NULL): device time of the two kernels.  Synchronous.  In GPSIQ_NCO_REFERENCE gpsiq_generate_batch
+ * memory; kernel_ms (may be NULL): device time of the two kernels.  Synchronous.  `end` is the ESTIMATOR's state after the last
+ * block (phase, drift, satellite, f_carr) as gpsiq_chain_maps gives it, with two differences: `carr` is 0 and GPSIQ_CHAIN_EXACT is
+ * never set (level 1 has an estimate, not the accumulator: only gpsiq_chain_link knows that), and GPSIQ_CHAIN_RESEEDED is also set
+ * when block 0 continued an exact state handed in through `start`.  In GPSIQ_NCO_REFERENCE gpsiq_generate_batch
  * walks the chain of a batch this way itself (48 blocks or more; GPSIQ_CHAIN=host keeps the serial walk on host threads). */
 int gpsiq_chain_maps_device(gpsiq_ctx_t *ctx, const gpsiq_chain_in_t *in, int nblocks, int nchan, double fs, int nsamp,
                             const gpsiq_chain_est_t *start, int max_stretches, gpsiq_chain_map_t *maps, gpsiq_chain_est_t *end,

@@ -98,6 +98,8 @@ _chain_maps_device = _sig("gpsiq_chain_maps_device", _i, _vp, _vp, _i, _i, _d, _
 _chain_link = _sig("gpsiq_chain_link", _i, _vp, _vp, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp)
 _chain_summary = _sig("gpsiq_chain_summary", _i, _vp, _i, _i, _d, _i, _vp, _vp)
 _chain_fold = _sig("gpsiq_chain_fold", _i, _vp, _i, _i, _vp)
+_chain_range = _sig("gpsiq_chain_range", _i, _vp, _vp, _i, _i, _d, _i, _vp)
+_chain_range_fold = _sig("gpsiq_chain_range_fold", _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp)
 _chain_stats = _sig("gpsiq_chain_stats", None, _vp)
 _set_patches = _sig("gpsiq_set_patches", _i, _vp, _vp, _i)
 _set_nco_mode = _sig("gpsiq_set_nco_mode", _i, _vp, _i)
@@ -294,6 +296,39 @@ def chain_fold(sums):
     out = np.zeros(nc, dtype=CHAIN_EST_DTYPE)
     _check(_chain_fold(_p(sums) if n else None, n, nc, _p(out)))
     return out
+
+
+def chain_range(cin, maps, fs, nsamp):
+    """gpsiq_chain_range: what this range of blocks does to every slot's accumulator as a function of the state it is entered
+    with (its maps composed) -> CHAIN_RANGE_DTYPE[nchan]."""
+    from .abi import CHAIN_IN_DTYPE, CHAIN_MAP_DTYPE, CHAIN_RANGE_DTYPE
+    cin = np.ascontiguousarray(cin, dtype=CHAIN_IN_DTYPE)
+    maps = np.ascontiguousarray(maps, dtype=CHAIN_MAP_DTYPE)
+    nb, nc = cin.shape
+    out = np.zeros(nc, dtype=CHAIN_RANGE_DTYPE)
+    _check(_chain_range(_p(cin) if nb else None, _p(maps) if nb else None, nb, nc, float(fs), int(nsamp), _p(out)))
+    return out
+
+
+def chain_range_fold(ranges, true_end=None, true_prn=None, true_known=None):
+    """gpsiq_chain_range_fold over ranges[nranges][nchan]: (every state known, carr, prn, known -- each [nranges + 1][nchan]) --
+    the accumulator and satellite every range is entered with, the last row: after the whole timeline.  true_end / true_prn
+    [nranges][nchan] with true_known[nranges]: the states ranks that have linked their range ended on."""
+    from .abi import CHAIN_RANGE_DTYPE
+    ranges = np.ascontiguousarray(ranges, dtype=CHAIN_RANGE_DTYPE)
+    n, nc = ranges.shape
+    carr = np.zeros((n + 1, nc), dtype=np.float64)
+    prn = np.zeros((n + 1, nc), dtype=np.int32)
+    known = np.zeros((n + 1, nc), dtype=np.uint8)
+    te = tp = tk = None
+    if true_known is not None:
+        te = np.ascontiguousarray(true_end, dtype=np.float64)
+        tp = np.ascontiguousarray(true_prn, dtype=np.int32)
+        tk = np.ascontiguousarray(true_known, dtype=np.uint8)
+        assert te.shape == (n, nc) and tp.shape == (n, nc) and tk.shape == (n,)
+    every = _check(_chain_range_fold(_p(ranges) if n else None, n, nc, None if tk is None else _p(te), None if tk is None else _p(tp),
+                                     None if tk is None else _p(tk), _p(carr), _p(prn), _p(known)))
+    return bool(every), carr, prn, known.astype(bool)
 
 
 def chain_stats():

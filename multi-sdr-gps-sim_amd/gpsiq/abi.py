@@ -38,6 +38,11 @@ CHAIN_EST_DTYPE = np.dtype([("r_hi", "<u8"), ("r_lo", "<u8"), ("drift", "<f8"), 
 assert CHAIN_EST_DTYPE.itemsize == 56
 CHAIN_MAP_DTYPE = np.dtype([("xs", "<f8"), ("e", "<f8"), ("cum", "<i8", (2,)), ("lo", "<i8"), ("hi", "<i8"), ("ok", "<i4"), ("info", "<i4")], align=True)
 assert CHAIN_MAP_DTYPE.itemsize == 56
+# gpsiq_chain_range_t (csrc/gpsiq_plumbing.h): what a range of blocks does to one slot's accumulator
+CHAIN_RANGE_DTYPE = np.dtype([("xs", "<f8"), ("e", "<f8"), ("t", "<i8", (4,)), ("lo", "<i8", (4,)), ("hi", "<i8", (4,)), ("cum_last", "<i8", (2,)),
+                              ("abs_end", "<f8"), ("first_prn", "<i4"), ("last_prn", "<i4"), ("ok", "<i4"), ("restart", "<i4"), ("nblocks", "<i4"),
+                              ("grid_last", "<i4")], align=True)
+assert CHAIN_RANGE_DTYPE.itemsize == 160
 CHAIN_EXACT, CHAIN_RESEEDED, CHAIN_EMPTY = 1, 2, 4
 # gpsiq_shard_carry_t
 SHARD_CARRY_DTYPE = np.dtype([("end_phase", "<u8"), ("advance", "<u8"), ("first_prn", "<i4"), ("last_prn", "<i4"),

@@ -72,10 +72,14 @@ def reference_chain_by_time(cin_own, fs, nsamp, rank, world, all_gather_bytes, c
         1. every rank summarises its range (exact phase advance), all-gather, fold the ranks before: the phase its range starts at;
         2. the same again with the modelled rounding drift, which wants that absolute phase: two exchanges of 56 bytes per slot;
         3. level 1 of its own blocks, all ranks at once;
-        4. the true states are relayed: rank r links its range (gpsiq_chain_link: an addition per block) from the accumulator
-           rank r - 1 ended on -- 12 bytes per slot and rank, one after the other."""
-    from . import chain_fold, chain_link, chain_maps, chain_summary
-    from .abi import CHAIN_EST_DTYPE, CHAIN_IN_DTYPE
+        4. the true states: every rank composes the maps of its range into ONE map per slot (gpsiq_chain_range: 160 bytes),
+           all-gather, and every rank folds the ranges before its own (gpsiq_chain_range_fold) -- the accumulator its range is
+           entered with; it links its own blocks from there, and one more all-gather of the end states (12 bytes per slot)
+           confirms that every range ended where the fold said.  Four exchanges whatever the world size.  Where a range cannot
+           be composed (a block whose map does not apply: its true walk needs the true entry state) the ranks relay one after
+           the other as before: rank r links its range from the accumulator rank r - 1 ended on."""
+    from . import chain_fold, chain_link, chain_maps, chain_range, chain_range_fold, chain_summary
+    from .abi import CHAIN_EST_DTYPE, CHAIN_IN_DTYPE, CHAIN_RANGE_DTYPE
     cin_own = np.ascontiguousarray(cin_own, dtype=CHAIN_IN_DTYPE)
     nchan = cin_own.shape[1]
 
@@ -85,6 +89,24 @@ def reference_chain_by_time(cin_own, fs, nsamp, rank, world, all_gather_bytes, c
     phase = gathered(chain_summary(cin_own, fs, nsamp))
     drift = gathered(chain_summary(cin_own, fs, nsamp, start=chain_fold(phase[:rank])))
     maps = chain_maps(cin_own, fs, nsamp, start=chain_fold(drift[:rank]), max_stretches=max_stretches, ctx=ctx)[0]
+    if world > 2:
+        ranges = np.stack([np.frombuffer(b, dtype=CHAIN_RANGE_DTYPE) for b in all_gather_bytes(chain_range(cin_own, maps, fs, nsamp).tobytes())])
+        true_end, true_prn, true_known = np.zeros((world, nchan)), np.zeros((world, nchan), dtype=np.int32), np.zeros(world, dtype=np.uint8)
+        mine = None
+        for _ in range(world + 1):                            # one round when every range composes; one more per range in a row that does not
+            _, carr_at, prn_at, known = chain_range_fold(ranges, true_end, true_prn, true_known)
+            if mine is None and known[rank].all():
+                mine = chain_link(cin_own, maps, fs, nsamp, carr_at[rank] if rank else None, prn_at[rank] if rank else None)
+            blob = bytes(1 + 12 * nchan) if mine is None else b"\x01" + mine[1].tobytes() + mine[2].astype(np.int32).tobytes()
+            for r, got in enumerate(all_gather_bytes(blob)):
+                if got[0]:
+                    true_known[r] = 1
+                    true_end[r] = np.frombuffer(got[1:1 + 8 * nchan], dtype=np.float64)
+                    true_prn[r] = np.frombuffer(got[1 + 8 * nchan:], dtype=np.int32)
+            if true_known.all():
+                _, carr_at, prn_at, _ = chain_range_fold(ranges, true_end, true_prn, true_known)
+                return mine[0], carr_at[world].copy(), prn_at[world].copy()
+        raise RuntimeError("reference_chain_by_time: the ranks did not all link their ranges")
     start, carr, prn = None, None, None
     for r in range(world):
         blob = bytes(12 * nchan)

@@ -1,5 +1,5 @@
 """One GPSIQ_NCO_REFERENCE gpsiq_generate_batch call after another into device memory, for rocprofv3 passes (kernel trace; PMC):
-2.6 Msps int8 16 ch, 2 000 and 4 130 blocks, descriptors in pageable memory (the device evaluation packs them on the pool).
+2.6 Msps int8 16 ch, 2 000 and 4 130 blocks (the headline's blocks per launch), descriptors in pageable memory (the device evaluation packs them on the pool).
 No torch (a profiled interpreter with torch loaded has been seen to hang in teardown: run it under `timeout`); the output ring
 comes from hipMalloc through ctypes.
    python scripts/exact_call_prof.py [calls per size]"""
@@ -20,10 +20,10 @@ calls = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 ctx = gpsiq.Context(0)
 hip = C.CDLL("libamdhip64.so")            # the runtime the binding has loaded
 ring = C.c_void_p()
-assert hip.hipMalloc(C.byref(ring), C.c_size_t(2 << 30)) == 0
+assert hip.hipMalloc(C.byref(ring), C.c_size_t(4130 * 520000)) == 0      # bench.py's ring: 4 130 blocks of 2.6 Msps int8
 pat = synth_blocks(64, 16)
 ctx.set_nco_mode(NCO_REFERENCE)
-for fs, ss, nb in ((2.6e6, 1, 2000), (2.6e6, 1, 4129)) + (((25e6, 2, 200),) if os.environ.get("EXACT_PROF_25M") else ()):
+for fs, ss, nb in ((2.6e6, 1, 2000), (2.6e6, 1, 4130)) + (((25e6, 2, 200),) if os.environ.get("EXACT_PROF_25M") else ()):
     ns = int(round(fs / 10))
     d = pat[np.arange(nb) % 64]
     ts = []

@@ -31,7 +31,7 @@ for step in "$@"; do
       ( timeout 600 python scripts/eval_timing.py 2 ) > gpurun_out/${TAG}_eval_timing_2threads.log 2>&1; grep -v "trace\] " gpurun_out/${TAG}_eval_timing_2threads.log ;;
     exactprof)
       ( cd /tmp && export TMPDIR=/tmp && O=$GRAFT_REPO_ROOT/gpurun_out/exact_prof && rm -rf $O && mkdir -p $O &&
-        echo '{"calls": 6, "blocks": [2000, 4129], "nsamp": 260000, "ss": 1}' > $O/meta.json &&
+        echo '{"calls": 6, "blocks": [2000, 4130], "nsamp": 260000, "ss": 1}' > $O/meta.json &&
         EXACT_PROF_25M=1 timeout 200 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $GRAFT_REPO_ROOT/scripts/exact_call_prof.py 6 > $O/kt.log 2>&1; tail -3 $O/kt.log
         timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o pmc -- python $GRAFT_REPO_ROOT/scripts/exact_call_prof.py 6 > $O/pmc_write.log 2>&1
         timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/scripts/exact_call_prof.py 6 > $O/pmc_fetch.log 2>&1

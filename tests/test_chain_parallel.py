@@ -98,6 +98,48 @@ def test_a_continued_timeline_and_ranges_of_ranks():
     assert_same_chain((np.concatenate(starts), carr, prn), want)
 
 
+@pytest.mark.parametrize("modes", [False, True])
+def test_ranges_composed_and_folded_equal_the_serial_chain(modes):
+    """The relay of a time-sharded chain (gpsiq_chain_range / gpsiq_chain_range_fold, what gpsiq/shard.py::reference_chain_by_time
+    does over an all-gather, here in one process): eight ranges of a timeline, each with its maps composed into one map per slot;
+    folding them gives the state every range is entered with; a rank whose row is known links its blocks and publishes the state
+    it ended on; repeat.  Every start state == the serial chain's, bit for bit; ordinary timelines need one or two rounds,
+    not eight."""
+    fs, ns, nb, nc = 2.6e6, 260000, 90, 9
+    rounds_total = 0
+    for seed in range(12):
+        cin = timeline(100 + seed, nb, nc, modes=modes)
+        if not modes:
+            cin["f_carr"] += np.where(np.abs(cin["f_carr"]) < 100.0, 200.0, 0.0)
+        want_start, want_end, want_prn = gpsiq.reference_chain(cin, fs, ns)
+        cuts = [0] + sorted(np.random.default_rng(seed).integers(0, nb + 1, 7).tolist()) + [nb]        # uneven, some empty
+        rng_of = lambda r: cin[cuts[r]:cuts[r + 1]]
+        phase = np.stack([gpsiq.chain_summary(rng_of(r), fs, ns) for r in range(8)])
+        drift = np.stack([gpsiq.chain_summary(rng_of(r), fs, ns, start=gpsiq.chain_fold(phase[:r])) for r in range(8)])
+        maps = [gpsiq.chain_maps(rng_of(r), fs, ns, start=gpsiq.chain_fold(drift[:r]), max_stretches=8)[0] for r in range(8)]
+        ranges = np.stack([gpsiq.chain_range(rng_of(r), maps[r], fs, ns) for r in range(8)])
+        true_end, true_prn, true_known = np.zeros((8, nc)), np.zeros((8, nc), dtype=np.int32), np.zeros(8, dtype=np.uint8)
+        got = [None] * 8
+        for rounds in range(1, 10):
+            _, carr_at, prn_at, known = gpsiq.chain_range_fold(ranges, true_end, true_prn, true_known)
+            for r in range(8):
+                if got[r] is None and known[r].all():
+                    got[r] = gpsiq.chain_link(rng_of(r), maps[r], fs, ns, carr_at[r] if r else None, prn_at[r] if r else None)
+            for r in range(8):                                    # (the exchange: what has been linked by the end of this round)
+                if got[r] is not None:
+                    true_known[r], true_end[r], true_prn[r] = 1, got[r][1], got[r][2]
+            if true_known.all():
+                break
+        assert true_known.all() and rounds <= 8, rounds
+        rounds_total += rounds
+        for r in range(8):
+            assert got[r][0].tobytes() == want_start[cuts[r]:cuts[r + 1]].tobytes(), (seed, r)
+        every, carr_at, prn_at, _ = gpsiq.chain_range_fold(ranges, true_end, true_prn, true_known)
+        assert every and carr_at[8].tobytes() == want_end.tobytes() and prn_at[8].tobytes() == want_prn.tobytes(), seed
+    print("rounds per timeline:", rounds_total / 12)
+    assert rounds_total <= (12 * 3 if not modes else 12 * 8), rounds_total
+
+
 def test_soak_program_random_and_adversarial_timelines(tmp_path):
     """tests/chain_parallel.cpp: exact-tie addends, Doppler through zero, re-seeded and unused slots, continued and
     range-sharded timelines, 1..16 stretches, all sample rates."""
