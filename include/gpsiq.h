@@ -260,10 +260,14 @@ int gpsiq_wait(gpsiq_ctx_t *ctx);
  * dst receives nblocks*2*nsamp elements; dst_is_device != 0 means dst is a device
  * pointer on the context's device (no D2H).  carr_phase_out[nchan] (may be NULL) receives
  * the carrier phase after the last block, to be put into the next batch's block 0.
- * A long batch is worked through in pieces, the host side of piece k+1 (quantiser or, in GPSIQ_NCO_REFERENCE, the
- * carrier chain and the evaluation) under the kernel of piece k; the call returns when everything has landed.  Descriptors
- * are range-checked piece by piece: when a later piece fails its check the call returns the error after earlier pieces
- * have been rendered -- dst and the resident descriptor set are then undefined; the carried phases are untouched. */
+ * ch may lie in pageable host memory, in page-locked host memory (gpsiq_host_alloc) or in device memory of the context's device:
+ * a long batch (48 blocks or more in GPSIQ_NCO_REFERENCE, 64 in the fixed-point model) is quantised -- and in
+ * GPSIQ_NCO_REFERENCE chained and evaluated -- on the device, which reads page-locked and device-resident descriptors where
+ * they lie (pageable ones are first cut down to 64 bytes each by the host pool); shorter batches, and every batch under
+ * GPSIQ_EVAL=host, take the host quantiser / walker.  Either way a long batch is worked through in pieces, piece k+1 staged
+ * under the kernel of piece k, and the call returns when everything has landed.  Descriptors are range-checked on the way: when a
+ * descriptor is refused the call returns the error (the first refused block, in the host quantiser's words) after other
+ * pieces have been rendered -- dst and the resident descriptor set are then undefined; the carried phases are untouched. */
 int gpsiq_generate_batch(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan,
                          int nsamp, double fs, int sample_size,
                          void *dst, int dst_is_device, double *carr_phase_out);

@@ -105,6 +105,7 @@ struct gpsiq_ctx {
         gpsiq::FixedCarry *d_fix = nullptr, *h_fix = nullptr;
         gpsiq_patch_t  *d_patches = nullptr, *h_patches = nullptr;  unsigned patch_cap = 0;
         gpsiq::EvalHostItem *d_host = nullptr, *h_host = nullptr;   unsigned host_cap = 0;
+        gpsiq_chan_t   *h_items = nullptr;  unsigned items_cap = 0;                       // device-resident descriptors the host walker needs, page-locked
         gpsiq::EvalSlotRow *d_slot = nullptr, *h_slot = nullptr;  size_t slot_cap = 0;    // repair: one slot's column (+ one row before), device and page-locked
         double         *d_col = nullptr, *h_col = nullptr;                                 // ... and its start states on the way back
         hipStream_t     eval_stream = nullptr, chain_stream = nullptr;   // highest priority: beside the synthesis, ahead of its workgroups

@@ -681,11 +681,12 @@ static void piece_ends(int first, int n, int chunk, std::vector<int> *ends, bool
 // The kernel's rate is MEASURED: every batch call that renders through the device evaluation times its last piece's synthesis
 // with events and keeps a running mean in the context (gpsiq_evaldev.cpp); until the first such call, and for the host rate, the
 // figures of MI355X + EPYC 9575F stand in.  GPSIQ_RATE_KERNEL (channel-samples per second, read per call) overrides both.
-static double g_rate_kernel_measured = 0.0;        // the last context's running mean (the placement rules below have no context at hand)
+static std::atomic<double> g_rate_kernel_measured{0.0};        // a running mean over every context's calls (the placement rules below have no context at hand)
 static double rate_kernel()
 {
     if (const char *e = std::getenv("GPSIQ_RATE_KERNEL")) { const double v = std::atof(e); if (v > 1e9) return v; }
-    return g_rate_kernel_measured > 0.0 ? g_rate_kernel_measured : 6.0e12;
+    const double m = g_rate_kernel_measured.load(std::memory_order_relaxed);
+    return m > 0.0 ? m : 6.0e12;
 }
 static double rate_chain_us() { return 2.2; }      // microseconds per block and channel of the serial walk on one host thread
 
@@ -1424,8 +1425,8 @@ double gpsiq_rate_kernel() { return rate_kernel(); }
 void gpsiq_note_kernel_rate(double channel_samples_per_s)
 {
     if (!(channel_samples_per_s > 1e10 && channel_samples_per_s < 1e15)) return;
-    const double old = g_rate_kernel_measured;
-    g_rate_kernel_measured = old > 0.0 ? 0.75 * old + 0.25 * channel_samples_per_s : channel_samples_per_s;
+    const double old = g_rate_kernel_measured.load(std::memory_order_relaxed);
+    g_rate_kernel_measured.store(old > 0.0 ? 0.75 * old + 0.25 * channel_samples_per_s : channel_samples_per_s, std::memory_order_relaxed);
 }
 int gpsiq_generate_reference_host(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
                                   int sample_size, void *dst, int dst_is_device, double *carr_phase_out, const double *seeds)

@@ -231,6 +231,7 @@ void gpsiq_evaldev_destroy(gpsiq_ctx *c)
     if (e.h_slot) (void) hipHostFree(e.h_slot);
     if (e.d_col) (void) hipFree(e.d_col);
     if (e.h_col) (void) hipHostFree(e.h_col);
+    if (e.h_items) (void) hipHostFree(e.h_items);
     if (e.d_host) (void) hipFree(e.d_host);
     if (e.h_host) (void) hipHostFree(e.h_host);
     for (auto &ev_ : e.linked) if (ev_) (void) hipEventDestroy(ev_);
@@ -554,12 +555,23 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
                 std::sort(keys.begin(), keys.end());
                 patches.erase(std::remove_if(patches.begin(), patches.end(), [&](const gpsiq_patch_t &p) {
                     return std::binary_search(keys.begin(), keys.end(), (uint64_t) p.block << 8 | p.slot); }), patches.end());
+                // (descriptors that lie in device memory: the few the walker needs come back in one go)
+                if (kind == kSrcDevice) {
+                    if (fin.nhost > e.items_cap) {
+                        if (e.h_items) (void) hipHostFree(e.h_items);
+                        e.h_items = nullptr; e.items_cap = 0;
+                        if (hipHostMalloc((void **) &e.h_items, ((size_t) fin.nhost + 64) * sizeof(gpsiq_chan_t), hipHostMallocDefault) == hipSuccess) e.items_cap = fin.nhost + 64;
+                    }
+                    he = e.items_cap >= fin.nhost ? hipSuccess : hipErrorOutOfMemory;
+                    for (unsigned k = 0; k < fin.nhost && he == hipSuccess; ++k)
+                        he = hipMemcpyAsync(&e.h_items[k], ch + (size_t) e.h_host[k].block * nchan + e.h_host[k].chan, sizeof(gpsiq_chan_t), hipMemcpyDeviceToHost, E);
+                    if (he == hipSuccess) he = hipStreamSynchronize(E);
+                    if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, descriptors for the host walker: %s", hipGetErrorString(he)); }
+                }
                 for (unsigned k = 0; k < fin.nhost && rc == GPSIQ_OK; ++k) {
                     const EvalHostItem &h = e.h_host[k];
-                    gpsiq_chan_t one;
                     const size_t flat = (size_t) h.block * nchan + h.chan;
-                    if (kind == kSrcDevice) (void) hipMemcpy(&one, ch + flat, sizeof one, hipMemcpyDeviceToHost);
-                    else one = ch[flat];
+                    const gpsiq_chan_t &one = kind == kSrcDevice ? e.h_items[k] : ch[flat];
                     gpsiq_qchan_t q;
                     const int erc = eval_block_host(one, h.start, &h.seed, delt, nsamp, (int) h.block, (int) h.slot, &q, &patches);
                     if (erc != GPSIQ_OK) { rc = erc; std::snprintf(err, sizeof err, "block %u: %.280s", h.block, gpsiq_last_error()); }
