@@ -261,7 +261,7 @@ int gpsiq_wait(gpsiq_ctx_t *ctx);
  * pointer on the context's device (no D2H).  carr_phase_out[nchan] (may be NULL) receives
  * the carrier phase after the last block, to be put into the next batch's block 0.
  * ch may lie in pageable host memory, in page-locked host memory (gpsiq_host_alloc) or in device memory of the context's device:
- * a long batch (48 blocks or more in GPSIQ_NCO_REFERENCE, 64 in the fixed-point model) is quantised -- and in
+ * a long batch (48 blocks or more in GPSIQ_NCO_REFERENCE; in the fixed-point model ~300 descriptors per host thread) is quantised -- and in
  * GPSIQ_NCO_REFERENCE chained and evaluated -- on the device, which reads page-locked and device-resident descriptors where
  * they lie (pageable ones are first cut down to 64 bytes each by the host pool); shorter batches, and every batch under
  * GPSIQ_EVAL=host, take the host quantiser / walker.  Either way a long batch is worked through in pieces, piece k+1 staged

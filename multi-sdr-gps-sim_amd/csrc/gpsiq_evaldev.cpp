@@ -244,22 +244,25 @@ void gpsiq_evaldev_destroy(gpsiq_ctx *c)
     e = gpsiq_ctx::EvalDev();
 }
 
-// Whether the device path takes a batch: long enough for its fixed costs (a dozen launches, two waits) to pay.
-// GPSIQ_EVAL=host / device decides by hand (read per call: A/B in one process).
-static bool device_path_wanted(const gpsiq_ctx *c, int nblocks)
+// Whether the device path takes a batch: long enough for its fixed costs (a dozen launches, two or three waits: ~0.06 ms) to pay.
+// GPSIQ_NCO_REFERENCE: from 48 blocks (measured, 2.6 and 25 Msps, 16 host threads: the host path is ahead below that).  Fixed-point
+// model: the host quantiser costs ~0.2 us per descriptor and thread, so the device takes over at ~300 descriptors per host thread
+// (16 threads: 300 blocks of 16 channels; two threads: 38).  GPSIQ_EVAL=host / device decides by hand (read per call).
+static bool device_path_wanted(const gpsiq_ctx *c, int nblocks, int nchan)
 {
     const char *e = std::getenv("GPSIQ_EVAL");
     if (e && !std::strcmp(e, "host")) return false;
     if (e && !std::strcmp(e, "device")) return nblocks >= 1;
     if (std::getenv("GPSIQ_CHAIN")) return false;          // where level 1 of the chain runs WITHIN the host evaluation: asks for that path
-    return nblocks >= (c->nco_mode == GPSIQ_NCO_REFERENCE ? 48 : 64);
+    if (c->nco_mode == GPSIQ_NCO_REFERENCE) return nblocks >= 48;
+    return (long) nblocks * nchan >= 300L * (host_threads() > 0 ? host_threads() : 1);
 }
 
 int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs, int sample_size,
                           void *dst, int dst_is_device, double *carr_phase_out, const double *seeds, int *handled)
 {
     *handled = 0;
-    if (!device_path_wanted(c, nblocks) || nsamp <= 0) return GPSIQ_OK;
+    if (!device_path_wanted(c, nblocks, nchan) || nsamp <= 0) return GPSIQ_OK;
     const bool reference = c->nco_mode == GPSIQ_NCO_REFERENCE || seeds != nullptr;
     const char *trace_env = std::getenv("GPSIQ_TRACE");
     const bool trace = trace_env != nullptr;
