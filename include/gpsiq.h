@@ -13,8 +13,8 @@
  *   gps.c:2703-2933  the 10 Hz block loop, run ahead   -> gpsiq_generate_batch()
  *   gps.c:2847-2865  HackRF 262144-element chunking /
  *                    iqfile+Pluto one-block hand-off   -> gpsiq_chunker_*()
- *   gps.c:272-309    codegen() C/A sequence             -> gpsiq_prn_code()   (table built in-library)
- *   gps.c:145-213    sinTable512 / cosTable512          -> gpsiq_carrier_table() (table built in-library)
+ *   gps.c:272-309    codegen() C/A sequence             -> built in-library (read back: gpsiq_prn_code, csrc/gpsiq_plumbing.h)
+ *   gps.c:145-213    sinTable512 / cosTable512          -> built in-library (read back: gpsiq_carrier_table, ibid.)
  *   gps.h:213-236    channel_t (fields the loop reads)  -> gpsiq_chan_t
  *   fifo.h:19-63     the block FIFO (API kept)           -> multi-sdr-gps-sim_amd/host/fifo.[ch]
  *   the rows either side of the path (host refresh, nav words, RINEX readers) -> include/gpsiq_rows.h
@@ -151,10 +151,8 @@ const char *gpsiq_version(void);
 const char *gpsiq_kernels_id(void);
 /* last error text of the calling thread ("" if none) */
 const char *gpsiq_last_error(void);
-/* C/A code of one PRN as 0/1 chips; replaces codegen() gps.c:272-309 */
-int gpsiq_prn_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN]);
-/* carrier LUTs; replace cosTable512 / sinTable512 gps.c:145-213 */
-void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512[512]);
+/* (the tables the library builds in place of codegen() gps.c:272-309 and cosTable512 / sinTable512 gps.c:145-213 can be read back
+ * for checking: gpsiq_prn_code / gpsiq_carrier_table, csrc/gpsiq_plumbing.h) */
 
 /* ---- [sharding] the quantiser on its own -------------------------------------
  * Quantise nchan descriptors for a block of nsamp samples at fs Hz.
@@ -297,13 +295,8 @@ void *gpsiq_host_alloc(size_t bytes);
 void  gpsiq_host_free(void *p);
 
 /* ---- [sharding] resident-descriptor path (benchmarks, time-sharded multi-GPU) -------- */
-/* One shard of a time-sharded run in GPSIQ_NCO_REFERENCE, whatever the context's mode: render nblocks blocks whose start
- * states are known (carr_start[nblocks][nchan], this range's rows of gpsiq_reference_chain; ch[b][i].carr_phase is not
- * read) into dst, host or device as above -- evaluated and rendered in pieces like gpsiq_generate_batch, with no reference
- * to the blocks before the range.  Synchronous.  Does not touch the carrier continuation state. */
-int gpsiq_generate_seeded(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
-                          int sample_size, const double *carr_start, void *dst, int dst_is_device);
-
+/* (One shard of a time-sharded run in GPSIQ_NCO_REFERENCE is rendered from its blocks' start states by gpsiq_generate_seeded, which
+ * goes with the carrier chain of csrc/gpsiq_plumbing.h and is declared there.) */
 /* Copy nblocks*nchan quantised descriptors ([nblocks][nchan]) to the device. */
 int gpsiq_set_descriptors(gpsiq_ctx_t *ctx, const gpsiq_qchan_t *q, int nblocks, int nchan);
 /* Patches that go with the resident descriptors (gpsiq_reference_batch); every later gpsiq_launch

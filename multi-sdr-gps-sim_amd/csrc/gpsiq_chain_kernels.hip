@@ -30,6 +30,8 @@ using lane::u128;
 
 constexpr int kPrepThreads = 256;
 constexpr int kLaneThreads = 256;
+constexpr int kTabMinSeg = 16;            // lanes per block from which a block gets its table of cycles (measured: with 8 lanes the four
+                                          // table walks per lane cost more than they save, 0.65 against 0.50 ms per 2 000 x 16 blocks)
 
 struct ScanR { u128 v; int flag; };     // f(R) = flag ? v : R + v
 struct ScanD { double v; int flag; };
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     // walker[k]: the addend of block b0 - 1 + k (raw storage: a __shared__ object may not have initialisers; setup_head writes every scalar)
     __shared__ __attribute__((aligned(16))) unsigned char walker_raw[sizeof(Walker) * (kBlocks + 1)];
     Walker *walker = reinterpret_cast<Walker *>(walker_raw);
-    __shared__ Stretch stretch[kLaneThreads];
-    __shared__ lane::Cycle cycles[kSeg >= 32 ? kLaneThreads : 1];     // cycles[blk * kSeg + k]: entry k of block blk's table
+    constexpr int kEnt = kSeg >= kTabMinSeg ? lane::kEntriesHost : 0;  // entries of a block's table of cycles (0: every cycle walked)
+    __shared__ lane::Cycle cycles[kEnt ? kBlocks * kEnt : 1];         // cycles[blk * kEnt + k]: entry k of block blk's table
     __shared__ int usable[kBlocks + 1];
     const int groups = (nblocks + kBlocks - 1) / kBlocks;
     const int i = blockIdx.x / groups, b0 = (blockIdx.x % groups) * kBlocks;
@@ -185,12 +187,15 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     const bool live = b < nblocks && usable[blk + 1];
     Prep p = {0.0, 0.0, 0.0, lane::kSkip, 0};
     if (live) p = prep[(size_t) b * nchan + i];
-    // (with fewer than 32 lanes per block the sample is too thin: a tenth of the look-ups miss, and a wave waits for its unluckiest lane)
-    const bool use_tab = live && kSeg >= 32 && __builtin_fabs(p.c) * (double) nsamp > 2.0 * kSeg;
+    // (kEnt entries whatever the number of lanes: a thinner sample misses a tenth of the look-ups, and a wave waits for its unluckiest
+    // lane -- with fewer lanes per block each walks kEnt / kSeg cycles, and a wave holds more blocks)
+    const bool use_tab = live && kEnt > 0 && __builtin_fabs(p.c) * (double) nsamp > 2.0 * kEnt;
     if (use_tab) {
-        lane::Cycle e;
-        lane::build_cycle(walker[blk + 1], t, kSeg, &e);
-        cycles[kSeg >= 32 ? tid : 0] = e;
+        for (int k = t; k < kEnt; k += kSeg) {
+            lane::Cycle e;
+            lane::build_cycle(walker[blk + 1], k, kEnt, &e);
+            cycles[kEnt ? blk * kEnt + k : 0] = e;
+        }
     }
     __syncthreads();
     int nseg = 0;
@@ -200,11 +205,9 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
         nseg = lane::stretches(p.c, nsamp, max_seg < kSeg ? max_seg : kSeg);
         if (t < nseg) {
             const Walker *prev = (!(p.flags & lane::kSeed) && usable[blk]) ? &walker[blk] : nullptr;
-            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, use_tab ? &cycles[kSeg >= 32 ? blk * kSeg : 0] : nullptr, kSeg, &st);
-            stretch[tid] = st;
+            lane::walk_stretch(walker[blk + 1], prev, p, nsamp, t, nseg, use_tab ? &cycles[kEnt ? blk * kEnt : 0] : nullptr, kEnt, &st);
         }
     }
-    __syncthreads();
     // The stretches of a block joined into its map: a scan over the block's kSeg lanes (gpsiq_lane.h, "the join as a scan") --
     // every lane takes part in the cross-lane moves, lanes without a stretch as identities.
     const bool mine = live && t < nseg;
@@ -212,7 +215,9 @@ __global__ __launch_bounds__(kLaneThreads) void chain_lanes(const Prep *__restri
     const int64_t grid = neg ? 1 : 2;
     lane::JoinLane jl;
     jl.el = lane::join_identity(); jl.D = 0; jl.fail = 0; jl.pad = 0;
-    if (mine) jl = lane::join_lane(stretch[t > 0 ? tid - 1 : tid], st, t, grid);
+    Stretch before = st;                                       // of the stretch before, the join reads where and in which state it ended
+    before.x_out = __shfl_up(st.x_out, 1, kSeg); before.n_out = __shfl_up(st.n_out, 1, kSeg);
+    if (mine) jl = lane::join_lane(before, st, t, grid);
     lane::JoinMap inc = jl.el;
     for (int off = 1; off < kSeg; off <<= 1) {
         lane::JoinMap o;

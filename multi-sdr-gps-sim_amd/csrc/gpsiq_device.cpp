@@ -1443,7 +1443,11 @@ extern "C" void *gpsiq_plumbing(const char *name)
         GPSIQ_P(gpsiq_chain_maps), GPSIQ_P(gpsiq_chain_link), GPSIQ_P(gpsiq_chain_summary), GPSIQ_P(gpsiq_chain_fold), GPSIQ_P(gpsiq_chain_stats),
         GPSIQ_P(gpsiq_chain_maps_device), GPSIQ_P(gpsiq_chain_range), GPSIQ_P(gpsiq_chain_range_fold), GPSIQ_P(gpsiq_time_launches), GPSIQ_P(gpsiq_num_variants), GPSIQ_P(gpsiq_variant_name),
         GPSIQ_P(gpsiq_device_eval_stats), GPSIQ_P(gpsiq_device_eval_host_ms),
+        GPSIQ_P(gpsiq_prn_code), GPSIQ_P(gpsiq_carrier_table), GPSIQ_P(gpsiq_generate_seeded),
 #undef GPSIQ_P
+        // the internals libgpsiq_rows.so runs on (gpsiq_rows_link.cpp): one pool, one quantiser, one error text per thread
+        {"set_error", reinterpret_cast<void *>(&gpsiq::set_error)}, {"parallel_for", reinterpret_cast<void *>(&gpsiq::parallel_for)},
+        {"quantize_one", reinterpret_cast<void *>(&gpsiq::quantize_one)}, {"chain_carrier", reinterpret_cast<void *>(&gpsiq::chain_carrier)},
     };
     if (!name) return nullptr;
     for (const auto &e : table)

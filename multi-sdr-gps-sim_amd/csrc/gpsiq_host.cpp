@@ -28,6 +28,12 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+int set_error(int code, const char *text)          // fail() for a text formatted elsewhere (libgpsiq_rows.so, through gpsiq_plumbing)
+{
+    snprintf(g_err, sizeof g_err, "%s", text ? text : "");
+    return code;
+}
+
 // ---- the host worker pool ---------------------------------------------------------------------------------
 // Spawning threads per call costs more than the work of a 4000-block batch on a 256-core host (measured: 65
 // pthread_create/join ~ 2.4 ms vs 0.6 ms of quantising), so the workers are created once, on first use, and sleep on a

@@ -16,6 +16,7 @@
 namespace gpsiq {
 
 int  fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int  set_error(int code, const char *text);
 void ca_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN]);
 void build_device_tables(DeviceTables *t);
 uint64_t carr_phase_to_fixed(double cycles);

@@ -19,6 +19,22 @@ extern "C" {
 __attribute__((visibility("default")))
 #endif
 void *gpsiq_plumbing(const char *name);
+/* Besides the functions declared below, gpsiq_plumbing() knows four names that are the library's internals as libgpsiq_rows.so (the
+ * rows either side of the path: refresh, nav message, RINEX, motion -- include/gpsiq_rows.h, gpsiq_extras.h) needs them, so that the
+ * two libraries share ONE worker pool, ONE quantiser and ONE error text per thread (csrc/gpsiq_rows_link.cpp is the other end):
+ * "set_error", "parallel_for", "quantize_one", "chain_carrier" (csrc/gpsiq_internal.h has their C++ signatures). */
+
+/* The tables the library builds in place of the reference's, read back (tests hold them against the oracle's).
+ * C/A code of one PRN as 0/1 chips (codegen() gps.c:272-309); the carrier LUTs (cosTable512 / sinTable512 gps.c:145-213). */
+int  gpsiq_prn_code(int prn, uint8_t chips[GPSIQ_CA_SEQ_LEN]);
+void gpsiq_carrier_table(int16_t cos512[512], int16_t sin512[512]);
+
+/* One shard of a time-sharded run in GPSIQ_NCO_REFERENCE, whatever the context's mode: render nblocks blocks whose start
+ * states are known (carr_start[nblocks][nchan], this range's rows of gpsiq_reference_chain; ch[b][i].carr_phase is not
+ * read) into dst, host or device as gpsiq_generate_batch -- evaluated and rendered in pieces like it, with no reference
+ * to the blocks before the range.  Synchronous.  Does not touch the carrier continuation state. */
+int gpsiq_generate_seeded(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs,
+                          int sample_size, const double *carr_start, void *dst, int dst_is_device);
 
 /* The two halves of gpsiq_reference_batch on their own, for hosts that spread GPSIQ_NCO_REFERENCE over devices or processes.
  * Only the carrier chain is serial in time (gps.c:2821-2826: block b of a channel starts where the double accumulator left
@@ -173,6 +189,22 @@ static inline int gpsiq_p_reference_chain(const gpsiq_chain_in_t *in, int nblock
 {
     typedef int (*fn_t)(const gpsiq_chain_in_t *, int, int, double, int, const double *, const int32_t *, double *, double *, int32_t *);
     return ((fn_t) gpsiq_plumbing("gpsiq_reference_chain"))(in, nblocks, nchan, fs, nsamp, carr_in, prn_in, carr_start, carr_end, last_prn);
+}
+static inline int gpsiq_p_generate_seeded(gpsiq_ctx_t *ctx, const gpsiq_chan_t *ch, int nblocks, int nchan, int nsamp, double fs, int sample_size,
+                                          const double *carr_start, void *dst, int dst_is_device)
+{
+    typedef int (*fn_t)(gpsiq_ctx_t *, const gpsiq_chan_t *, int, int, int, double, int, const double *, void *, int);
+    return ((fn_t) gpsiq_plumbing("gpsiq_generate_seeded"))(ctx, ch, nblocks, nchan, nsamp, fs, sample_size, carr_start, dst, dst_is_device);
+}
+static inline int gpsiq_p_prn_code(int prn, uint8_t *chips)
+{
+    typedef int (*fn_t)(int, uint8_t *);
+    return ((fn_t) gpsiq_plumbing("gpsiq_prn_code"))(prn, chips);
+}
+static inline void gpsiq_p_carrier_table(int16_t *cos512, int16_t *sin512)
+{
+    typedef void (*fn_t)(int16_t *, int16_t *);
+    ((fn_t) gpsiq_plumbing("gpsiq_carrier_table"))(cos512, sin512);
 }
 #endif
 #endif

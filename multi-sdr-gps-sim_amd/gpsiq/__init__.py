@@ -47,6 +47,14 @@ def _preload_shared_hip_runtime():
 
 _preload_shared_hip_runtime()
 _lib = C.CDLL(LIB_PATH)
+# the rows either side of the path (include/gpsiq_rows.h, gpsiq_extras.h): a host-only library of its own that runs on the first
+# one's worker pool and error text (its NEEDED entry "libgpsiq.so" is satisfied by the library just loaded, whatever its path)
+ROWS_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpsiq_rows.so")
+if not os.path.exists(ROWS_PATH):
+    ROWS_PATH = os.path.join(_HERE, "libgpsiq_rows.so")
+if not os.path.exists(ROWS_PATH):
+    raise ImportError(f"{ROWS_PATH} not built: make -C multi-sdr-gps-sim_amd/csrc builds it next to libgpsiq.so")
+_rows = C.CDLL(ROWS_PATH)
 
 
 class GpsiqError(RuntimeError):
@@ -56,16 +64,16 @@ class GpsiqError(RuntimeError):
 
 
 def _sig(name, restype, *argtypes):
-    """A function of the C-ABI (include/*.h: an exported symbol), or of the library's plumbing (csrc/gpsiq_plumbing.h: hidden
-    symbols, resolved through the one exported entry gpsiq_plumbing(name))."""
-    try:
-        f = getattr(_lib, name)
-    except AttributeError:
+    """A function of the C-ABI (an exported symbol: include/gpsiq.h in libgpsiq.so, include/gpsiq_rows.h and gpsiq_extras.h in
+    libgpsiq_rows.so), or of the library's plumbing (csrc/gpsiq_plumbing.h: hidden symbols, resolved through the one exported
+    entry gpsiq_plumbing(name))."""
+    f = getattr(_lib, name, None) or getattr(_rows, name, None)
+    if f is None:
         _lib.gpsiq_plumbing.restype = C.c_void_p
         _lib.gpsiq_plumbing.argtypes = [C.c_char_p]
         addr = _lib.gpsiq_plumbing(name.encode())
         if not addr:
-            raise
+            raise AttributeError(f"{name}: exported by neither libgpsiq.so nor libgpsiq_rows.so, and no plumbing entry of that name")
         return C.CFUNCTYPE(restype, *argtypes)(addr)
     f.restype = restype
     f.argtypes = list(argtypes)

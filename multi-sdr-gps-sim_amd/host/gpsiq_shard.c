@@ -85,7 +85,7 @@ int main(int argc, char **argv)
     for (int b = b0; b < b1 && !failed; b += BLOCKS_PER_CALL) {
         const int nb = b1 - b < BLOCKS_PER_CALL ? b1 - b : BLOCKS_PER_CALL;
         const int rc = reference
-            ? gpsiq_generate_seeded(gq, desc + (size_t) b * h.nchan, nb, (int) h.nchan, (int) h.nsamp, h.fs, (int) h.sample_size,
+            ? gpsiq_p_generate_seeded(gq, desc + (size_t) b * h.nchan, nb, (int) h.nchan, (int) h.nsamp, h.fs, (int) h.sample_size,
                                     start + (size_t) b * h.nchan, buf, 0)
             : gpsiq_generate_quantized(gq, q + (size_t) b * h.nchan, nb, (int) h.nchan, (int) h.nsamp, (int) h.sample_size, buf, 0);
         if (rc != GPSIQ_OK) { failed = die("generate"); break; }

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "gpsiq_extras.h"
+#include "gpsiq_plumbing.h"     /* the tables read back: gpsiq_prn_code, gpsiq_carrier_table (linked in directly here) */
 
 static uint64_t rng_state = 0x243f6a8885a308d3ull;
 static uint64_t rnd(void) { rng_state += 0x9e3779b97f4a7c15ull; uint64_t z = rng_state; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }

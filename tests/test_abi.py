@@ -15,21 +15,56 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADERS = [os.path.join(ROOT, "include", h) for h in ("gpsiq.h", "gpsiq_rows.h", "gpsiq_extras.h")]     # boundary, section 8f rows, frozen extras
 
 
-def declared_functions():
-    txt = "".join(open(h).read() for h in HEADERS)
+def declared_functions(headers=HEADERS):
+    txt = "".join(open(h).read() for h in headers)
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(gpsiq_[a-z0-9_]+)\s*\(", txt)))
 
 
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return sorted(l.split()[2] for l in out.splitlines() if " T gpsiq_" in l)
+
+
 def test_every_declared_symbol_is_exported():
-    lib = C.CDLL(gpsiq.LIB_PATH)
+    """libgpsiq.so exports the boundary (include/gpsiq.h) and its one plumbing entry, libgpsiq_rows.so the rows either side of the
+    path (gpsiq_rows.h, gpsiq_extras.h) -- each exactly what its headers declare, and the boundary stays thin."""
+    lib, rows = C.CDLL(gpsiq.LIB_PATH), C.CDLL(gpsiq.ROWS_PATH)
     names = declared_functions()
     assert len(names) >= 17, names
     # the boundary header stays the boundary: the drop-in calls + sharding, nothing of the host model
     boundary = re.sub(r"/\*.*?\*/", "", open(HEADERS[0]).read(), flags=re.S)
     assert len(open(HEADERS[0]).read().splitlines()) <= 450 and "gpsiq_rinex" not in boundary and "gpsiq_almanac" not in boundary
-    for n in names:
+    core_names, rows_names = declared_functions(HEADERS[:1]), declared_functions(HEADERS[1:])
+    for n in core_names:
         assert hasattr(lib, n), f"{n} declared in include/gpsiq.h but not exported by libgpsiq.so"
+    for n in rows_names:
+        assert hasattr(rows, n), f"{n} declared in include/gpsiq_rows.h / gpsiq_extras.h but not exported by libgpsiq_rows.so"
+    assert exported(gpsiq.LIB_PATH) == sorted(core_names + ["gpsiq_plumbing"]), "libgpsiq.so exports something its header does not declare"
+    assert exported(gpsiq.ROWS_PATH) == rows_names, "libgpsiq_rows.so exports something its headers do not declare"
+    assert len(exported(gpsiq.LIB_PATH)) <= 30
+
+
+def test_plumbing_resolves_every_name_its_header_declares():
+    """csrc/gpsiq_plumbing.h: hidden symbols behind gpsiq_plumbing(name), plus the four internals the rows library runs on."""
+    lib = C.CDLL(gpsiq.LIB_PATH)
+    lib.gpsiq_plumbing.restype = C.c_void_p
+    lib.gpsiq_plumbing.argtypes = [C.c_char_p]
+    hdr = os.path.join(ROOT, "multi-sdr-gps-sim_amd", "csrc", "gpsiq_plumbing.h")
+    names = [n for n in declared_functions([hdr]) if n != "gpsiq_plumbing" and not n.startswith("gpsiq_p_")]
+    assert len(names) >= 20, names
+    for n in names + ["set_error", "parallel_for", "quantize_one", "chain_carrier"]:
+        assert lib.gpsiq_plumbing(n.encode()), f"gpsiq_plumbing has no entry {n}"
+        assert not hasattr(lib, n), f"{n} is plumbing and exported as well"
+    assert not lib.gpsiq_plumbing(b"no_such_entry")
+
+
+def test_rows_library_shares_the_error_text_of_the_boundary_library():
+    """One gpsiq_last_error() for both libraries: a rows call that fails leaves its text where the boundary library's accessor reads it."""
+    from gpsiq.abi import EPHEM_DTYPE, IONO_DTYPE, TRACK_DTYPE
+    with pytest.raises(gpsiq.GpsiqError) as e:
+        gpsiq.refresh_batch(np.zeros(32, EPHEM_DTYPE), np.zeros(1, IONO_DTYPE), 2190, 0.0, np.zeros((2, 3)), np.zeros(17, TRACK_DTYPE))
+    assert "bad nblocks 2 / nchan 17" in str(e.value), str(e.value)       # formatted in libgpsiq_rows.so, read back from libgpsiq.so
 
 
 def test_header_compiles_as_c_and_struct_sizes_match(tmp_path):
