@@ -158,6 +158,19 @@ def cpu_baseline(desc, fs, nsamp, sample_size, nblocks, passes=3):
     out = {"value": round(passes * nblocks * nsamp / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
            "sample": f"{passes} passes over the first {nblocks} blocks ({nblocks * 0.1:.1f} s of signal) of the same workload, "
                      f"{how}, {dt:.1f} s wall"}
+    # informational: the same lines compiled at -O3 (the reference ships -Og), one core, one pass
+    try:
+        o3_path = os.path.join(ROOT, "oracle", "_ref", "libgpsref_O3.so")
+        if kind == "reference" and os.path.exists(o3_path):
+            ref3 = _oracle.Ref(o3_path)
+            ref3.run_blocks(d[:4], int(fs), sample_size, 1)
+            t3 = time.perf_counter()
+            ref3.run_blocks(d, int(fs), sample_size, 1)
+            dt3 = time.perf_counter() - t3
+            out["at_O3"] = {"value": round(nblocks * nsamp / dt3 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                            "sample": f"1 pass over the same {nblocks} blocks, the same lines at -std=c11 -O3 (no -march=native: the object is built on another host), {dt3:.1f} s wall"}
+    except Exception as e:
+        out["at_O3"] = {"error": str(e)[:100]}
     # informational: the same loop on every core this process may use (the reference itself is
     # single-threaded; blocks are independent given their descriptors, so this is the best a CPU port could do)
     try:

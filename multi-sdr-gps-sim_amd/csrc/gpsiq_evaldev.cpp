@@ -245,6 +245,16 @@ void gpsiq_evaldev_destroy(gpsiq_ctx *c)
     e = gpsiq_ctx::EvalDev();
 }
 
+// how many entries the patch / host lists of a call may hold.  (-DGPSIQ_TEST_HOOKS: GPSIQ_TEST_LIST_CAP=n makes the lists n entries
+// short, so that a test can see what a call does when they overflow -- the whole call again on the host path.)
+static inline unsigned list_cap(unsigned cap)
+{
+#ifdef GPSIQ_TEST_HOOKS
+    if (const char *s = std::getenv("GPSIQ_TEST_LIST_CAP")) { const long v = std::atol(s); if (v >= 0 && (unsigned long) v < cap) return (unsigned) v; }
+#endif
+    return cap;
+}
+
 // Whether the device path takes a batch: long enough for its fixed costs (a dozen launches, two or three waits: ~0.06 ms) to pay.
 // GPSIQ_NCO_REFERENCE: from 48 blocks (measured, 2.6 and 25 Msps, 16 host threads: the host path is ahead below that).  Fixed-point
 // model: the host quantiser costs ~0.2 us per descriptor and thread, so the device takes over at ~300 descriptors per host thread
@@ -498,7 +508,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
         }
         he = hipStreamWaitEvent(E, chained ? e.linked[k] : staged[npieces - 1], 0);
         if (he == hipSuccess)
-            he = launch_eval(d_chan, b0, nb, nchan, delt, nsamp, c->d_tab, est_rows, est_stride, e.d_patches, e.patch_cap, e.d_host, e.host_cap, e.d_ctrl,
+            he = launch_eval(d_chan, b0, nb, nchan, delt, nsamp, c->d_tab, est_rows, est_stride, e.d_patches, list_cap(e.patch_cap), e.d_host, list_cap(e.host_cap), e.d_ctrl,
                              seeds ? e.d_seeds : nullptr, E);
         if (he != hipSuccess) { rc = GPSIQ_E_DEVICE; std::snprintf(err, sizeof err, "device evaluation, piece %d evaluation: %s", k, hipGetErrorString(he)); }
     }
@@ -543,7 +553,7 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
     }
     std::vector<gpsiq_patch_t> patches;
     if (rc == GPSIQ_OK && reference) {
-        if (fin.npatch > e.patch_cap || fin.nhost > e.host_cap) fall_back = true;       // more than the lists hold (a rate far outside the design range)
+        if (fin.npatch > list_cap(e.patch_cap) || fin.nhost > list_cap(e.host_cap)) fall_back = true;       // more than the lists hold (a rate far outside the design range)
         else {
             if (fin.npatch > 1024) he = hipMemcpy(e.h_patches + 1024, e.d_patches + 1024, (size_t) (fin.npatch - 1024) * sizeof(gpsiq_patch_t), hipMemcpyDeviceToHost);
             if (he == hipSuccess && fin.nhost > 256) he = hipMemcpy(e.h_host + 256, e.d_host + 256, (size_t) (fin.nhost - 256) * sizeof(EvalHostItem), hipMemcpyDeviceToHost);

@@ -41,9 +41,9 @@ for step in "$@"; do
     refnco)
       ( timeout 1500 python -m pytest tests/test_gpu_reference_nco.py tests/test_config5_shares.py -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${TAG}_refnco_tests.log 2>&1; tail -4 gpurun_out/${TAG}_refnco_tests.log ;;
     soak)
-      for s in 1 2 3; do ( timeout 200 python tests/soak_chain_device.py ${SOAK_SECONDS:-50} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_chain_device.txt ;;
+      for s in 1 2 3; do ( timeout $(( ${SOAK_SECONDS:-50} + 150 )) python tests/soak_chain_device.py ${SOAK_SECONDS:-50} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_chain_device.txt ;;
     soakeval)
-      for s in 1 2 3; do ( timeout 400 python tests/soak_device_eval.py ${SOAK_SECONDS:-90} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_device_eval.txt ;;
+      for s in 1 2 3; do ( timeout $(( ${SOAK_SECONDS:-90} + 310 )) python tests/soak_device_eval.py ${SOAK_SECONDS:-90} $s ) 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_soak_device_eval.txt ;;
     tests)
       ( timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${TAG}_pytest_gpu.log ;;
     cpu)

@@ -2,7 +2,8 @@
 its map is also walked serially from the same start state (the reference's own additions, gps.c:2821-2826) and must end on the
 same double; a mismatch fails the call with GPSIQ_E_VERIFY (-6) and names block and slot.  The mechanism's failure mode would be
 silent wrong bytes, so the test needs a map that IS wrong: a library built with -DGPSIQ_TEST_HOOKS (fault injection, never in the
-shipped build) shifts one block's end offset on the device (device evaluation) or in the walkers' link (host path)."""
+shipped build) shifts one block's end offset on the device (device evaluation) or in the walkers' link (host path).  The same build
+shortens the device evaluation's lists on request, for the one path of it no honest input reaches: lists that overflow -> the host path."""
 import os
 import subprocess
 import sys
@@ -56,6 +57,32 @@ for how in ("device", "host"):
         else:
             assert caught is None, (how, every, caught)
     print(how, "verify ok")
+# the lists of the device evaluation too short for the call's patches (GPSIQ_TEST_LIST_CAP, a hook of this build): the call notices,
+# renders again on the host path, and the bytes and the carrier are the ones it always gives
+for k in ("GPSIQ_CHAIN_VERIFY", "GPSIQ_TEST_CORRUPT_MAP", "GPSIQ_TEST_CORRUPT_MAP_AT", "GPSIQ_CHAIN"):
+    os.environ.pop(k, None)
+fs2, ns2, nb2 = 25e6, 2500000, 50
+d2 = synth_blocks(nb2, nc, seed=45)
+os.environ["GPSIQ_EVAL"] = "host"
+carr_h = np.zeros(nc)
+want = ctx.generate_batch(d2, ns2, fs2, SC08, carr_out=carr_h)
+os.environ["GPSIQ_EVAL"] = "device"
+s0 = gpsiq.device_eval_stats()
+carr_d = np.zeros(nc)
+got = ctx.generate_batch(d2, ns2, fs2, SC08, carr_out=carr_d)
+s1 = gpsiq.device_eval_stats()
+assert s1[4] - s0[4] > 8 and s1[5] == s0[5], (s0, s1)                      # patches there are, and the lists held them
+assert np.array_equal(got, want) and carr_d.tobytes() == carr_h.tobytes()
+os.environ["GPSIQ_TEST_LIST_CAP"] = "3"
+carr_f = np.zeros(nc)
+got = ctx.generate_batch(d2, ns2, fs2, SC08, carr_out=carr_f)
+s2 = gpsiq.device_eval_stats()
+assert s2[5] == s1[5] + 1, (s1, s2)                                         # fell back
+assert np.array_equal(got, want) and carr_f.tobytes() == carr_h.tobytes()
+del os.environ["GPSIQ_TEST_LIST_CAP"]
+got = ctx.generate_batch(d2, ns2, fs2, SC08)                                # and the context is as good as before
+assert np.array_equal(got, want) and gpsiq.device_eval_stats()[5] == s2[5]
+print("fall-back ok")
 ctx.close()
 print("all ok")
 '''
