@@ -28,13 +28,50 @@ using lane::Stretch;
 using lane::Walker;
 using lane::u128;
 
-constexpr int kPrepThreads = 256;
+constexpr int kPrepThreads = 1024;          // blocks of one slot per round of chain_prepare (one block per thread, sixteen waves)
 constexpr int kLaneThreads = 256;
 constexpr int kTabMinSeg = 16;            // lanes per block from which a block gets its table of cycles (measured: with 8 lanes the four
                                           // table walks per lane cost more than they save, 0.65 against 0.50 ms per 2 000 x 16 blocks)
 
 struct ScanR { u128 v; int flag; };     // f(R) = flag ? v : R + v
 struct ScanD { double v; int flag; };
+// Segmented scans over the threads of a workgroup: inside a wave with cross-lane moves, the waves' totals through LDS -- two
+// barriers per scan (a Hillis-Steele scan over LDS took twenty, and 256 blocks per round: 0.1-0.2 ms per 4 000 blocks, in front of
+// everything else of the chain).  first p, then a: a segment start in a hides p.
+__device__ inline ScanR scan_join(const ScanR &p, ScanR a) { if (!a.flag) { a.v = p.v + a.v; a.flag = p.flag; } return a; }
+__device__ inline ScanD scan_join(const ScanD &p, ScanD a) { if (!a.flag) { a.v = p.v + a.v; a.flag = p.flag; } return a; }
+__device__ inline ScanR scan_up(const ScanR &x, int off)
+{
+    ScanR o;
+    const uint64_t hi = __shfl_up((uint64_t) (x.v >> 64), off, 64), lo = __shfl_up((uint64_t) x.v, off, 64);
+    o.v = ((u128) hi << 64) | lo; o.flag = __shfl_up(x.flag, off, 64);
+    return o;
+}
+__device__ inline ScanD scan_up(const ScanD &x, int off) { ScanD o; o.v = __shfl_up(x.v, off, 64); o.flag = __shfl_up(x.flag, off, 64); return o; }
+// -> *before: everything before this thread (identity for thread 0), *total: all threads.  s_wave: one entry per wave.
+template <class S>
+__device__ inline void block_scan(S mine, S *s_wave, S *before, S *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (int) (blockDim.x >> 6);
+    S inc = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const S o = scan_up(inc, off);
+        if (lane >= off) inc = scan_join(o, inc);
+    }
+    S exc = scan_up(inc, 1);
+    if (lane == 0) { exc.v = 0; exc.flag = 0; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    S acc; acc.v = 0; acc.flag = 0;
+    S mine_before = acc;
+    for (int w = 0; w < nwaves; ++w) {
+        if (w == wave) mine_before = acc;
+        acc = scan_join(acc, s_wave[w]);
+    }
+    *before = scan_join(mine_before, exc);
+    *total = acc;
+    __syncthreads();                                    // s_wave is free again
+}
 
 // ---- prepare ---------------------------------------------------------------------------------------------------------
 // est layout as on the host: start[nchan] may be null (the timeline begins here).
@@ -44,8 +81,8 @@ __global__ __launch_bounds__(kPrepThreads) void chain_prepare(const char *__rest
                                                               double *__restrict__ c_before, gpsiq_chain_est_t *__restrict__ end)
 {
     auto in_at = [&](size_t k) -> gpsiq_chain_in_t { return *reinterpret_cast<const gpsiq_chain_in_t *>(in_rows + k * (size_t) stride); };
-    __shared__ ScanR sr[kPrepThreads];
-    __shared__ ScanD sd[kPrepThreads];
+    __shared__ ScanR s_wr[kPrepThreads / 64];
+    __shared__ ScanD s_wd[kPrepThreads / 64];
     __shared__ int s_any_seed;
     const int i = blockIdx.x, tid = threadIdx.x;
     // the estimator before block 0
@@ -81,41 +118,19 @@ __global__ __launch_bounds__(kPrepThreads) void chain_prepare(const char *__rest
         ScanR mine;
         mine.flag = seed ? 1 : 0;
         mine.v = seed ? lane::phase_units(x_seed) + adv : adv;
-        sr[tid] = mine;
-        __syncthreads();
-        for (int off = 1; off < kPrepThreads; off <<= 1) {
-            ScanR a = sr[tid], p;
-            const bool has = tid >= off;
-            if (has) p = sr[tid - off];
-            __syncthreads();
-            if (has && !a.flag) { a.v = p.v + a.v; a.flag = p.flag; sr[tid] = a; }
-            __syncthreads();
-        }
+        ScanR pr, er;                                   // the blocks before this one inside the round; the whole round
+        block_scan(mine, s_wr, &pr, &er);
         // R at this block's first sample
-        u128 R0;
-        if (seed) R0 = lane::phase_units(x_seed);
-        else if (tid == 0) R0 = Rc;
-        else { const ScanR p = sr[tid - 1]; R0 = p.flag ? p.v : Rc + p.v; }
+        const u128 R0 = seed ? lane::phase_units(x_seed) : pr.flag ? pr.v : Rc + pr.v;
         const double r0 = lane::units_to_double(R0);
         double core = 0.0;
         if (active && __builtin_fabs(c) < 0.5) core = lane::drift_core(c, seed ? (x_seed < 1.0 ? x_seed : 0.0) : r0, nsamp);
         ScanD md;
         md.flag = seed ? 1 : 0;
         md.v = core;
-        sd[tid] = md;
-        __syncthreads();
-        for (int off = 1; off < kPrepThreads; off <<= 1) {
-            ScanD a = sd[tid], p;
-            const bool has = tid >= off;
-            if (has) p = sd[tid - off];
-            __syncthreads();
-            if (has && !a.flag) { a.v = p.v + a.v; a.flag = p.flag; sd[tid] = a; }
-            __syncthreads();
-        }
-        double D0;
-        if (seed) D0 = 0.0;
-        else if (tid == 0) D0 = Dc;
-        else { const ScanD p = sd[tid - 1]; D0 = p.flag ? p.v : Dc + p.v; }
+        ScanD pd, ed;
+        block_scan(md, s_wd, &pd, &ed);
+        const double D0 = seed ? 0.0 : pd.flag ? pd.v : Dc + pd.v;
         if (live) {
             Prep p = {0.0, 0.0, 0.0, lane::kSkip, 0};
             if (active) {
@@ -126,9 +141,7 @@ __global__ __launch_bounds__(kPrepThreads) void chain_prepare(const char *__rest
             }
             prep[(size_t) b * nchan + i] = p;
         }
-        // the chunk's carry
-        const ScanR er = sr[kPrepThreads - 1];
-        const ScanD ed = sd[kPrepThreads - 1];
+        // the round's carry
         if (seed) atomicOr(&s_any_seed, 1);
         const int n_here = nblocks - base < kPrepThreads ? nblocks - base : kPrepThreads;
         __syncthreads();

@@ -34,7 +34,7 @@ using ev::DChan;
 using ev::Link;
 using lane::Rec;
 
-constexpr int kPackThreads = 256;
+constexpr int kPackThreads = 128;           // (x 296 bytes of rows in LDS: 37 KB)
 constexpr int kLinkThreads = 256;
 constexpr int kEvalThreads = 128;
 
@@ -62,24 +62,49 @@ __device__ inline void reduce_params(bool counts, unsigned long long code_step, 
     const long long blk_active = sum16(counts ? 1 : 0);
     const unsigned long long ms = wave_max_u64(counts ? code_step : 0);
     const long long ma = wave_max_i64(blk_amp), mc = wave_max_i64(blk_active);
+    // (a thousand waves' atomics on three words take their turns at the L2: 35 of pack_raw's 43 us for 66 000 rows.  A wave looks first:
+    // a maximum that is already there needs no atomic, and a stale look only costs one that was not needed)
     if ((threadIdx.x & 63) == 0) {
-        if (ms) atomicMax(&ctrl->max_code_step, ms);
-        if (ma) atomicMax(&ctrl->max_amp, ma);
-        if (mc) atomicMax(&ctrl->max_active, (int) mc);
+        if (ms > __hip_atomic_load(&ctrl->max_code_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctrl->max_code_step, ms);
+        if (ma > __hip_atomic_load(&ctrl->max_amp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctrl->max_amp, ma);
+        if ((int) mc > __hip_atomic_load(&ctrl->max_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctrl->max_active, (int) mc);
     }
 }
 
 // ---- pack ----------------------------------------------------------------------------------------------------------------
+// A gpsiq_chan_t is 296 bytes: lanes that each read their own row make every load touch 64 cache lines (43 us per 66 000 rows).  The
+// workgroup's rows are contiguous in memory, so they come in as one coalesced stream of 8-byte words into LDS, and a lane takes what it
+// needs of its row from there (the struct read through a pointer to LDS: the same ev::pack_chan as on the host).
+constexpr int kPackRows = kPackThreads;                        // rows a workgroup stages at most (16 lanes per block, nchan <= 16 of them live)
+constexpr int kRowWords = (int) (sizeof(gpsiq_chan_t) / 8);    // 37
+static_assert(sizeof(gpsiq_chan_t) % 8 == 0, "rows are streamed as 8-byte words");
 __global__ __launch_bounds__(kPackThreads) void pack_raw(const gpsiq_chan_t *__restrict__ ch, int nblocks, int nchan, double delt,
                                                          DChan *__restrict__ out, EvalCtrl *__restrict__ ctrl)
 {
-    const long gid = (long) blockIdx.x * kPackThreads + threadIdx.x;
-    const int b = (int) (gid >> 4), i = (int) (gid & 15);
-    const bool live = b < nblocks && i < nchan;
+    __shared__ __attribute__((aligned(16))) uint64_t rows[kPackRows * kRowWords];
+    constexpr int kBlocksPerWg = kPackThreads / 16;
+    const int blk0 = (int) blockIdx.x * kBlocksPerWg;
+    const int nblk = nblocks - blk0 < kBlocksPerWg ? nblocks - blk0 : kBlocksPerWg;
+    const size_t first = (size_t) blk0 * nchan;
+    const int words = nblk > 0 ? nblk * nchan * kRowWords : 0;
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(ch + first);
+    // (sixteen loads in flight per lane before the first one is waited for: three round trips to memory per workgroup, not thirty-seven)
+    constexpr int kInFlight = 16;
+    for (int w0 = threadIdx.x; w0 < words; w0 += kPackThreads * kInFlight) {
+        uint64_t t[kInFlight];
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) { const int w = w0 + j * kPackThreads; t[j] = w < words ? src[w] : 0; }
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) { const int w = w0 + j * kPackThreads; if (w < words) rows[w] = t[j]; }
+    }
+    __syncthreads();
+    const int lb = (int) (threadIdx.x >> 4), i = (int) (threadIdx.x & 15);
+    const int b = blk0 + lb;
+    const bool live = lb < nblk && i < nchan;
     DChan d;
     d.f_carr = 0.0; d.carr_phase = 0.0; d.prn = 0; d.pos = 0; d.f_code = 0.0; d.code_phase = 0.0; d.gain = 0.0; d.nav = 0; d.start = 0.0;
     if (live) {
-        ev::pack_chan(ch[(size_t) b * nchan + i], &d);
+        ev::pack_chan(*reinterpret_cast<const gpsiq_chan_t *>(&rows[(size_t) (lb * nchan + i) * kRowWords]), &d);
         out[(size_t) b * nchan + i] = d;
     }
     const double code_inc = d.f_code * delt;
@@ -327,59 +352,88 @@ __global__ __launch_bounds__(kEvalThreads) void quantize_fixed(const DChan *__re
 // p_{b+1} = p_b + nsamp*step_b (mod 2^59) down slot i while it keeps its satellite; block 0 continues carry0 where cont0 says so
 // (chain_carrier of gpsiq_host.cpp).  One workgroup per slot; then the block's descriptors are compacted in place by a second
 // kernel (compact_blocks), since a slot's scan must not move rows another slot's scan still reads.
+// The scan: four consecutive blocks per thread in registers, the threads' totals across the wave with cross-lane moves, the four
+// waves' totals through LDS -- 1 024 blocks per round and two barriers (a Hillis-Steele scan over LDS took sixteen barriers per 256
+// blocks: 44 us per 4 130 blocks, on the critical path in front of the first synthesis).
 struct FixScan { uint64_t v; int flag; };
+__device__ inline FixScan fix_join(const FixScan &p, FixScan a)                  // first p, then a: a segment start in a hides p
+{
+    if (!a.flag) { a.v = (p.v + a.v) & ev::kEvCarrMask; a.flag = p.flag; }
+    return a;
+}
+constexpr int kFixPer = 4;                                                       // blocks per thread and round
 __global__ __launch_bounds__(kLinkThreads) void carry_prefix(gpsiq_qchan_t *__restrict__ q, int b0, int nb, int nchan, int nsamp,
                                                              FixedCarry *__restrict__ carry)
 {
-    __shared__ FixScan ss[kLinkThreads];
+    __shared__ FixScan s_wave[kLinkThreads / 64];
     __shared__ FixedCarry s_carry;
-    const int i = blockIdx.x, tid = threadIdx.x;
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = carry[i];
     __syncthreads();
     constexpr uint64_t mask = ev::kEvCarrMask;
-    for (int base = 0; base < nb; base += kLinkThreads) {
-        const int b = b0 + base + tid;
-        const bool live = base + tid < nb;
+    constexpr int kRound = kLinkThreads * kFixPer;
+    for (int base = 0; base < nb; base += kRound) {
         const FixedCarry cy = s_carry;
-        gpsiq_qchan_t d;
-        d.carr_phase = 0; d.carr_step = 0; d.prn = 0;
-        int prev_prn = cy.prn;
-        if (live) {
-            d = q[(size_t) b * nchan + i];
-            if (base + tid > 0) prev_prn = q[(size_t) (b - 1) * nchan + i].prn;
+        const int n_here = nb - base < kRound ? nb - base : kRound;
+        const int k0 = tid * kFixPer;                                             // this thread's first block inside the round
+        FixScan run[kFixPer];                                                     // inclusive scan of the thread's own blocks
+        bool cont[kFixPer];
+        int last_prn = 0;                                                         // satellite of the thread's last live block (0: unused slot)
+        int prev_prn = cy.prn;                                                    // (the launch's first block: what the piece before left)
+        if (base + k0 > 0 && k0 < n_here) prev_prn = (int) q[(size_t) (b0 + base + k0 - 1) * nchan + i].prn;
+#pragma unroll
+        for (int j = 0; j < kFixPer; ++j) {
+            const int k = k0 + j, b = b0 + base + k;
+            const bool live = k < n_here;
+            uint64_t phase = 0, step = 0;
+            int prn = 0;
+            if (live) { const gpsiq_qchan_t &d = q[(size_t) b * nchan + i]; phase = d.carr_phase; step = d.carr_step; prn = (int) d.prn; }
+            const bool active = live && prn != 0;
+            // a block seeds the slot from its own phase unless it continues the block before (same satellite); the call's first block
+            // continues what the caller says it does (cont0 of chain_carrier)
+            cont[j] = active && (b == 0 ? cy.cont != 0 : prev_prn == prn);
+            const uint64_t adv = active ? (step * (uint64_t) nsamp) & mask : 0;
+            FixScan mine;
+            mine.flag = live && !cont[j] ? 1 : 0;
+            mine.v = (mine.flag ? phase + adv : adv) & mask;
+            run[j] = j ? fix_join(run[j - 1], mine) : mine;
+            if (live) { prev_prn = prn; last_prn = active ? prn : 0; }
         }
-        const bool active = live && d.prn != 0;
-        // a block seeds the slot from its own phase unless it continues the block before (same satellite); the call's first block
-        // continues what the caller says it does (cont0 of chain_carrier)
-        const bool cont = active && (b == 0 ? cy.cont != 0 : prev_prn == (int) d.prn);
-        const uint64_t adv = active ? ((uint64_t) d.carr_step * (uint64_t) nsamp) & mask : 0;
-        FixScan mine;
-        mine.flag = live && !cont ? 1 : 0;
-        mine.v = (mine.flag ? d.carr_phase + adv : adv) & mask;
-        ss[tid] = mine;
+        // the threads' totals: inclusive scan across the wave, then the waves before this one
+        FixScan inc = run[kFixPer - 1];
+        for (int off = 1; off < 64; off <<= 1) {
+            FixScan o;
+            o.v = __shfl_up(inc.v, off, 64); o.flag = __shfl_up(inc.flag, off, 64);
+            if (lane >= off) inc = fix_join(o, inc);
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        FixScan exc;                                                              // everything before this thread's blocks, inside the round
+        exc.v = __shfl_up(inc.v, 1, 64); exc.flag = __shfl_up(inc.flag, 1, 64);
+        if (lane == 0) { exc.v = 0; exc.flag = 0; }
         __syncthreads();
-        for (int off = 1; off < kLinkThreads; off <<= 1) {
-            FixScan a = ss[tid], p;
-            const bool has = tid >= off;
-            if (has) p = ss[tid - off];
-            __syncthreads();
-            if (has && !a.flag) { a.v = (p.v + a.v) & mask; a.flag = p.flag; ss[tid] = a; }
-            __syncthreads();
+        FixScan before; before.v = 0; before.flag = 0;
+        for (int w = 0; w < wave; ++w) before = fix_join(before, s_wave[w]);
+        exc = fix_join(before, exc);
+        // the phase a block starts from: what the blocks before it leave behind
+#pragma unroll
+        for (int j = 0; j < kFixPer; ++j) {
+            if (!cont[j]) continue;
+            const FixScan p = j ? fix_join(exc, run[j - 1]) : exc;
+            const uint64_t p0 = p.flag ? p.v : (cy.phase + p.v) & mask;
+            q[(size_t) (b0 + base + k0 + j) * nchan + i].carr_phase = p0 & mask;
         }
-        // the phase this block starts from: what the blocks before leave behind
-        if (cont) {
-            uint64_t p0;
-            if (tid == 0) p0 = cy.phase;
-            else { const FixScan p = ss[tid - 1]; p0 = p.flag ? p.v : (cy.phase + p.v) & mask; }
-            q[(size_t) b * nchan + i].carr_phase = p0 & mask;
-        }
-        const int n_here = nb - base < kLinkThreads ? nb - base : kLinkThreads;
-        const FixScan e = ss[n_here - 1];
+        // the round's carry: the thread that holds the round's last block knows the inclusive total and the slot's satellite
+        const int t_last = (n_here - 1) / kFixPer;
         __syncthreads();
-        if (tid == n_here - 1) {
+        if (tid == t_last) {
+            const int jl = (n_here - 1) % kFixPer;
+            FixScan rl = run[0];                                                  // (selected, not indexed: the array stays in registers)
+#pragma unroll
+            for (int j = 1; j < kFixPer; ++j) if (j == jl) rl = run[j];
+            const FixScan e = fix_join(exc, rl);
             FixedCarry c;
             c.phase = e.flag ? e.v : (cy.phase + e.v) & mask;
-            c.prn = active ? (int) d.prn : 0;
+            c.prn = last_prn;
             c.cont = 1;
             s_carry = c;
         }
