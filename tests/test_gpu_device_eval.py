@@ -63,7 +63,8 @@ def render(ctx, d, ns, fs, ss, mode, how, monkeypatch, kind="pageable"):
 
 @pytest.mark.parametrize("mode", [NCO_REFERENCE, NCO_FIXED])
 @pytest.mark.parametrize("fs,ns,nb,nc,ss", [(2.6e6, 260000, 150, 16, SC08), (2.6e6, 26000, 700, 12, SC16), (10e6, 1000000, 70, 16, SC16),
-                                            (25e6, 2500000, 60, 16, SC08)])
+                                            (25e6, 2500000, 60, 16, SC08),
+                                            (2.6e6, 26000, 2500, 16, SC08), (2.6e6, 13000, 3100, 7, SC16)])    # (several rounds of the 1 024-block scans)
 def test_device_evaluation_equals_the_host_path(ctx, monkeypatch, mode, fs, ns, nb, nc, ss):
     d = synth_blocks(nb, nc, seed=int(fs) % 1000 + nb)
     before = gpsiq.device_eval_stats()
