@@ -621,7 +621,7 @@ def main():
             #   packed kernels (larger gains):             3 x 4.3 + 2 x 2.5 + 2 x 4.4 = 26.7 cycles
             # peak = every SIMD of 256 CUs issuing only that core at the 2.4 GHz maximum clock.
             cnt = counters_obj(f"{int(fs)}_{nchan}_{ss}_{nblocks}", launch_ms) or {}
-            # not a roofline: the kernel against the cost of its OWN instruction stream (profiles/r05_synth_tile_row_loop.txt)
+            # not a roofline: the kernel against the cost of its OWN instruction stream (profiles/r06_synth_tile_row_loop.txt)
             cnt["own_stream_efficiency"] = {"note": "launch time vs the issue cost of the kernel's own seven-instruction core at the measured "
                                             "single-instruction rates; says how close the kernel runs to its stream, not that the stream is minimal",
                                             "core_cycles": core_cycles,
