@@ -366,21 +366,14 @@ int gpsiq_generate_device(gpsiq_ctx *c, const gpsiq_chan_t *ch, int nblocks, int
             he = hipMemcpyAsync(e.d_raw + off, ch + off, cnt * sizeof(gpsiq_chan_t), hipMemcpyHostToDevice, S);
             if (he == hipSuccess) he = launch_pack_raw(e.d_raw + off, nb, nchan, delt, d_chan + off, e.d_ctrl, S);
         } else {
-            // (a long piece in runs of ~1 000 blocks: the upload of one run crosses PCIe while the pool packs the next)
             const double tp = gpsiq_wall_ms();
-            const int runs = nb >= 2048 ? (nb + 1023) / 1024 : 1;
-            he = hipSuccess;
-            for (int r = 0; r < runs && he == hipSuccess; ++r) {
-                const int r0 = (int) ((long) nb * r / runs), r1 = (int) ((long) nb * (r + 1) / runs);
-                const size_t roff = off + (size_t) r0 * nchan;
-                PackJob part = pj;
-                part.ch = ch + roff; part.out = h_chan + roff;
-                pack_host(&part, r1 - r0);
-                pj.mx = part.mx > pj.mx ? part.mx : pj.mx; pj.max_active = part.max_active > pj.max_active ? part.max_active : pj.max_active;
-                pj.max_amp = part.max_amp > pj.max_amp ? part.max_amp : pj.max_amp;
-                he = hipMemcpyAsync(d_chan + roff, h_chan + roff, (size_t) (r1 - r0) * nchan * sizeof(ev::DChan), hipMemcpyHostToDevice, S);
-            }
+            PackJob part = pj;
+            part.ch = ch + off; part.out = h_chan + off;
+            pack_host(&part, nb);
+            pj.mx = part.mx > pj.mx ? part.mx : pj.mx; pj.max_active = part.max_active > pj.max_active ? part.max_active : pj.max_active;
+            pj.max_amp = part.max_amp > pj.max_amp ? part.max_amp : pj.max_amp;
             e.host_ms += gpsiq_wall_ms() - tp; host_part[0] += gpsiq_wall_ms() - tp;
+            he = hipMemcpyAsync(d_chan + off, h_chan + off, cnt * sizeof(ev::DChan), hipMemcpyHostToDevice, S);
         }
         if (he == hipSuccess && chained)
             he = launch_chain(d_chan + off, (int) sizeof(ev::DChan), nb, nchan, delt, nsamp, k ? c->chain.d_est + (size_t) k * GPSIQ_MAX_CHAN : nullptr, 0,
